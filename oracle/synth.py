@@ -1,0 +1,115 @@
+"""Deterministic synthetic checkpoints and inputs (test infrastructure).
+
+No real DISSC checkpoint exists offline (Google-Drive links, reference
+README.md:76,93,117,142), so parity is pinned on synthetic weights laid out
+exactly like the reference's checkpoints:
+
+* vocoder  ``g_########`` = ``{'generator': state_dict}`` with 97 weight-normed
+  conv layers x {bias, weight_g, weight_v} + ``dict.weight`` + ``spkr.weight``
+  (reference sr/train.py:205-214, sr/models.py:72-96,125-135).
+* predictors ``best_model.pth`` = plain ``state_dict`` (reference
+  train_len_predictor.py:101-103, train_f0_predictor.py:98-100).
+
+Everything is drawn from ``numpy.random.RandomState`` (frozen legacy stream) so
+the same seed gives the same bytes in this container and on the GPU box.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+VCTK_CONFIG = {
+    "resblock": "1",
+    "upsample_rates": [5, 4, 4, 2, 2],
+    "upsample_kernel_sizes": [11, 8, 8, 4, 4],
+    "upsample_initial_channel": 512,
+    "resblock_kernel_sizes": [3, 7, 11],
+    "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+    "num_embeddings": 100,
+    "embedding_dim": 128,
+    "model_in_dim": 257,
+    "code_hop_size": 320,
+    "f0": True,
+    "multispkr": "_",
+    "f0_normalize": False,
+    "sampling_rate": 16000,
+}
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))
+
+
+def _wn_conv(rs, sd, name, shape, fan_in, gain, g_dim0):
+    """weight_v ~ N(0,1); weight_g = ||v|| * N(1,0.1)*gain/sqrt(fan_in)*sqrt(numel/g_dim0)
+    so the folded weight has std ~ gain/sqrt(fan_in)."""
+    v = rs.standard_normal(shape)
+    norm = np.sqrt((v.reshape(shape[0], -1) ** 2).sum(1))
+    per = np.sqrt(np.prod(shape[1:]))
+    g = (gain / np.sqrt(fan_in)) * per * (1.0 + 0.1 * rs.standard_normal(shape[0]))
+    # g multiplies v/||v||: effective per-element std = g/per
+    del norm
+    sd[name + ".weight_g"] = _t(g.reshape((shape[0],) + (1,) * (len(shape) - 1)))
+    sd[name + ".weight_v"] = _t(v)
+
+
+def synth_generator_state_dict(h=None, seed=0):
+    """State dict with the reference's 293 keys."""
+    h = h or VCTK_CONFIG
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    c0 = h["upsample_initial_channel"]
+    in_dim = h.get("model_in_dim", 128)
+    # conv_pre: Conv1d(in_dim, c0, 7)
+    sd["conv_pre.bias"] = _t(0.1 * rs.standard_normal(c0))
+    _wn_conv(rs, sd, "conv_pre", (c0, in_dim, 7), in_dim * 7, 1.0, c0)
+    # ups: ConvTranspose1d weight [Cin, Cout, k]; weight_g is per *input* channel
+    for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+        cin, cout = c0 // 2 ** i, c0 // 2 ** (i + 1)
+        sd[f"ups.{i}.bias"] = _t(0.1 * rs.standard_normal(cout))
+        _wn_conv(rs, sd, f"ups.{i}", (cin, cout, k), cin * k / u, 1.4, cin)
+    # resblocks
+    nk = len(h["resblock_kernel_sizes"])
+    for i in range(len(h["upsample_rates"])):
+        ch = c0 // 2 ** (i + 1)
+        for j, k in enumerate(h["resblock_kernel_sizes"]):
+            idx = i * nk + j
+            for grp, gain in (("convs1", 1.4), ("convs2", 0.6)):
+                for m in range(3):
+                    name = f"resblocks.{idx}.{grp}.{m}"
+                    sd[name + ".bias"] = _t(0.1 * rs.standard_normal(ch))
+                    _wn_conv(rs, sd, name, (ch, ch, k), ch * k, gain, ch)
+    ch = c0 // 2 ** len(h["upsample_rates"])
+    sd["conv_post.bias"] = _t(0.05 * rs.standard_normal(1))
+    _wn_conv(rs, sd, "conv_post", (1, ch, 7), ch * 7, 0.35, 1)
+    sd["dict.weight"] = _t(rs.standard_normal((h["num_embeddings"], h["embedding_dim"])))
+    sd["spkr.weight"] = _t(rs.standard_normal((200, h["embedding_dim"])))
+    return sd
+
+
+def synth_generator_inputs(B, T, seed=1234, ragged=False, n_spk=108, n_codes=100):
+    """runs of a uniform symbol (geometric, mean 2.5 frames),
+    f0 ~ N(0,1) with ~35% exact-zero unvoiced runs, spkr uniform."""
+    rs = np.random.RandomState(seed)
+    code = np.zeros((B, T), dtype=np.int64)
+    f0 = np.zeros((B, 1, T), dtype=np.float32)
+    for b in range(B):
+        t = 0
+        while t < T:
+            run = rs.geometric(1 / 2.5)
+            code[b, t:t + run] = rs.randint(0, n_codes)
+            t += run
+        f0[b, 0] = rs.standard_normal(T)
+        t = 0
+        while t < T:
+            run = rs.geometric(1 / 12.0)
+            if rs.rand() < 0.35:
+                f0[b, 0, t:t + run] = 0.0
+            t += run
+    spkr = rs.randint(0, n_spk, size=(B, 1)).astype(np.int64)
+    if ragged:
+        lengths = rs.randint(max(1, T // 2), T + 1, size=B).astype(np.int32)
+        lengths[0] = T
+    else:
+        lengths = np.full(B, T, dtype=np.int32)
+    return code, f0, spkr, lengths

@@ -1,0 +1,82 @@
+"""The CPU oracle (oracle/) against outputs of the reference itself.
+
+tests/golden/gen_vctk.npz was produced by tests/golden/make_golden.py, which ran
+the unmodified reference CodeGenerator (reference sr/models.py) in the build
+container.  These tests pin the oracle before anything else trusts it."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import generator_ref as gr
+from oracle import synth
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "gen_vctk.npz"))
+
+
+@pytest.fixture(scope="module")
+def folded():
+    return gr.fold_state_dict(synth.synth_generator_state_dict(seed=0))
+
+
+def test_state_dict_layout():
+    sd = synth.synth_generator_state_dict(seed=0)
+    assert len(sd) == 293  # 97 convs x {bias, weight_g, weight_v} + dict + spkr
+    assert sd["ups.0.weight_g"].shape == (512, 1, 1)  # per INPUT channel for ConvTranspose1d
+    assert sd["resblocks.14.convs2.2.weight_v"].shape == (16, 16, 11)
+
+
+def test_fold_matches_reference_bitwise(gold, folded):
+    for name in ("conv_pre", "ups.0", "ups.3", "resblocks.0.convs1.2", "resblocks.14.convs2.0", "conv_post"):
+        wt = folded[name + ".weight"].double()
+        got = np.array([wt.sum().item(), wt.abs().sum().item(), (wt * wt).sum().item()])
+        np.testing.assert_array_equal(got, gold[f"s0/fold/{name}"])
+    np.testing.assert_array_equal(folded["ups.4.weight"].numpy(), gold["s0/fold/ups.4.weight"])
+
+
+@pytest.mark.parametrize("T", [1, 2, 7, 33, 99])
+def test_waveform_matches_reference(gold, folded, T):
+    code, f0, spkr, _ = synth.synth_generator_inputs(1, T, seed=100 + T)
+    taps = {}
+    y = gr.code_generator(folded, synth.VCTK_CONFIG, code, f0, spkr, taps=taps).numpy()
+    ref = gold[f"s0/T{T}/wav"]
+    assert y.shape == ref.shape == (1, 1, 320 * T)
+    # same ops in the same order on the same CPU backend: expect (near) bit equality
+    assert np.abs(y - ref).max() <= 1e-6
+    if T == 7:
+        for k in ["conv_pre"] + [f"up{i}" for i in range(5)]:
+            assert np.abs(taps[k].numpy() - gold[f"s0/T7/{k}"]).max() <= 1e-5, k
+        for i in range(4):
+            want = gold[f"s0/T7/lrelu_mrf{i}"]
+            got = torch.nn.functional.leaky_relu(taps[f"mrf{i}"], 0.1).numpy()
+            assert np.abs(got - want).max() <= 1e-5, i
+
+
+def test_resblocks_match_reference(gold, folded):
+    x = torch.from_numpy(gold["s0/T7/up2"])
+    for j, k in enumerate((3, 7, 11)):
+        r = gr.resblock1(folded, f"resblocks.{2 * 3 + j}", x, k)
+        assert np.abs(r.numpy() - gold[f"s0/T7/rb{6 + j}"]).max() <= 1e-5
+
+
+def test_ragged_batch_is_per_utterance(gold, folded):
+    code, f0, spkr, _ = synth.synth_generator_inputs(4, 40, seed=777)
+    lengths = gold["s0/ragged/lengths"]
+    y = gr.code_generator(folded, synth.VCTK_CONFIG, code, f0, spkr, lengths=lengths).numpy()
+    for b in range(4):
+        n = int(lengths[b]) * 320
+        assert np.abs(y[b, :, :n] - gold[f"s0/ragged/wav{b}"][0]).max() <= 1e-6
+        assert not y[b, :, n:].any()
+
+
+def test_wav_postprocess_truncates_and_wraps():
+    y = np.array([0.0, 0.99999, -0.99999, 1.0, -1.0, 0.5 / 32768, -0.5 / 32768, 3.7 / 32768, -3.7 / 32768],
+                 dtype=np.float32)
+    i16 = (y * 32768.0).astype("int16")  # what the reference does (numpy semantics)
+    want = i16.astype(np.float32) / np.abs(i16.astype(np.float32)).max()
+    np.testing.assert_array_equal(gr.wav_postprocess(y), want)
+    assert gr.wav_postprocess(np.zeros(5, np.float32)).tolist() == [0.0] * 5
