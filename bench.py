@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""Headline benchmark: HiFi-GAN resynthesis throughput (audio-seconds per wall-second)
+of the HIP generator on 10 s x batch-32 utterances per GPU (BASELINE.json metric,
+configs[2] workload: "Batch-32 VCTK val-set resynthesis only").
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the generator over one batch of 32 synthetic 10 s utterances
+per rank (inputs resident in HBM), followed -- for N > 1 -- by the path's single RCCL
+all-gather of the decoded waveforms.  Weak scaling: per-GPU work is fixed.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+
+
+def cpu_baseline(synth, sd, code, f0, spkr, budget_s=12.0, max_utts=6):
+    """The CPU oracle (kind='port': plain-PyTorch restatement pinned to the reference,
+    tests/test_oracle_golden.py) timed the way the reference runs: B=1 per utterance,
+    all host cores.  Bounded sample of the same workload."""
+    from oracle import generator_ref as gr
+    w = gr.fold_state_dict(sd)
+    # Host cores actually usable (cgroup/affinity aware); oneDNN degrades badly when
+    # oversubscribed, so probe a few thread counts on a short utterance and keep the best.
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    best, threads = None, 1
+    for th in sorted({min(avail, c) for c in (8, 16, 32, 64, avail)}):
+        torch.set_num_threads(th)
+        gr.code_generator(w, synth.VCTK_CONFIG, code[:1, :60], f0[:1, :, :60], spkr[:1])  # warm-up
+        t = time.perf_counter()
+        gr.code_generator(w, synth.VCTK_CONFIG, code[:1, :60], f0[:1, :, :60], spkr[:1])
+        t = time.perf_counter() - t
+        if best is None or t < best:
+            best, threads = t, th
+    torch.set_num_threads(threads)
+    n, t0 = 0, time.perf_counter()
+    while n < max_utts and (time.perf_counter() - t0 < budget_s or n == 0):
+        b = n % code.shape[0]
+        gr.code_generator(w, synth.VCTK_CONFIG, code[b:b + 1], f0[b:b + 1], spkr[b:b + 1])
+        n += 1
+    dt = time.perf_counter() - t0
+    sec = n * code.shape[1] * 320 / 16000.0
+    return {"value": round(sec / dt, 2), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
+            "sample": f"{n} x 10 s utterances, B=1 each (reference style), torch CPU fp32, "
+                      f"{threads} threads (best of a probe; {avail} logical CPUs available), {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import dissc_amd
+    from oracle import synth  # synthetic weights/inputs + the cpu_baseline leg only
+
+    sd = synth.synth_generator_state_dict(seed=0)
+    g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to(dev)
+    g.load_state_dict(sd)
+    g.eval()
+    g.remove_weight_norm()
+
+    B, T = a.batch, a.frames
+    code, f0, spkr, _ = synth.synth_generator_inputs(B, T, seed=1234 + rank)
+    d_code = torch.from_numpy(code).to(dev)
+    d_f0 = torch.from_numpy(f0).to(dev)
+    d_spkr = torch.from_numpy(spkr).to(dev)
+    hop = 320
+    gathered = torch.empty(world * B, 1, hop * T, device=dev) if world > 1 else None
+
+    def step():
+        y = g(code=d_code, f0=d_f0, spkr=d_spkr)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, y)  # the path's single RCCL collective
+        return y
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    gen_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ev0.record()
+        y = g(code=d_code, f0=d_f0, spkr=d_spkr)
+        ev1.record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, y)
+        ev1.synchronize()
+        gen_ms += ev0.elapsed_time(ev1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    audio_sec_per_step = world * B * T * hop / 16000.0
+    value = audio_sec_per_step * a.steps / dt
+
+    if rank == 0:
+        flops_step = g.flops(B * T)          # algorithmic 2*MAC per rank per step
+        kern_s = gen_ms / a.steps / 1e3      # HIP-event time of the generator launches
+        ach = flops_step / kern_s / 1e12
+        out = {
+            "metric": "audio-sec/sec (RTF) HiFi-GAN resynth, 10s x32 batch",
+            "value": round(value, 1), "unit": "audio-sec/sec", "n_gpus": n_gpus,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded codes/f0/speakers, seeded random weights in the reference checkpoint layout)",
+            "config": {"workload": "HiFi-GAN generator only (sr/inference.py generate()), "
+                                   f"B={B} x T={T} frames (10 s @16 kHz) per GPU, VCTK hubert100_lut config",
+                       "batch_per_gpu": B, "frames": T, "parallelism": f"dp{n_gpus}",
+                       "collective": "1 all_gather of waveforms per step" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None,
+                         "kernel": "conv_mfma_kernel (all generator convs; fp32 v_mfma_f32_16x16x4)",
+                         "flops_per_step": flops_step, "kernel_ms_per_step": round(kern_s * 1e3, 3)},
+        }
+        if not a.no_cpu_baseline and n_gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(synth, sd, torch.from_numpy(code), torch.from_numpy(f0),
+                                               torch.from_numpy(spkr))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

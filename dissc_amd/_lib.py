@@ -1,0 +1,100 @@
+"""ctypes binding of libdissc_hip.so (C ABI: include/dissc_hip.h).
+
+torch is imported first on purpose: the library's DT_NEEDED libamdhip64.so.7 then
+resolves to the HIP runtime PyTorch already loaded, so device pointers and
+hipStream_t handles are shared between PyTorch (allocator, streams, RCCL) and the
+kernels.  If the library is missing this module raises -- there is no fallback.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL load, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libdissc_hip.so"
+
+
+def library_path():
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+class DisscError(RuntimeError):
+    pass
+
+
+class DisscTensor(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.c_void_p),
+                ("shape", ctypes.c_int64 * 4), ("ndim", ctypes.c_int32)]
+
+
+MAX_UPS, MAX_RK = 8, 4
+
+
+class DisscGenConfig(ctypes.Structure):
+    _fields_ = [("model_in_dim", ctypes.c_int32), ("upsample_initial_channel", ctypes.c_int32),
+                ("num_upsamples", ctypes.c_int32), ("upsample_rates", ctypes.c_int32 * MAX_UPS),
+                ("upsample_kernel_sizes", ctypes.c_int32 * MAX_UPS), ("num_kernels", ctypes.c_int32),
+                ("resblock_kernel_sizes", ctypes.c_int32 * MAX_RK),
+                ("resblock_dilations", (ctypes.c_int32 * 3) * MAX_RK),
+                ("num_embeddings", ctypes.c_int32), ("embedding_dim", ctypes.c_int32),
+                ("num_speakers", ctypes.c_int32), ("has_f0", ctypes.c_int32), ("has_spkr", ctypes.c_int32)]
+
+
+def _load():
+    path = library_path()
+    if not os.path.exists(path):
+        raise DisscError(
+            f"{path} not found: build the HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()').  "
+            "dissc_amd has no CPU fallback.")
+    L = ctypes.CDLL(path)
+    vp, i32, i64p = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+    L.dissc_last_error.restype = ctypes.c_char_p
+    L.dissc_abi_version.restype = i32
+    L.dissc_device_count.restype = i32
+    L.dissc_device_name.argtypes = [i32, ctypes.c_char_p, ctypes.c_size_t]
+    L.dissc_gen_create.argtypes = [ctypes.POINTER(DisscGenConfig), ctypes.POINTER(DisscTensor),
+                                   ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.dissc_gen_destroy.argtypes = [vp]
+    L.dissc_gen_destroy.restype = None
+    L.dissc_gen_hop.argtypes = [vp]
+    L.dissc_gen_workspace_bytes.argtypes = [vp, i32, i32]
+    L.dissc_gen_workspace_bytes.restype = ctypes.c_size_t
+    L.dissc_gen_flops.argtypes = [vp, ctypes.c_int64]
+    L.dissc_gen_flops.restype = ctypes.c_double
+    L.dissc_gen_forward.argtypes = [vp, i64p, vp, i64p, vp, i32, i32, vp, vp, ctypes.c_size_t, vp]
+    L.dissc_conv1d.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
+                               ctypes.c_float, vp]
+    L.dissc_conv_transpose1d.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
+                                         ctypes.c_float, vp]
+    L.dissc_wav_postprocess.argtypes = [vp, vp, i32, i32, vp]
+    return L
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.dissc_last_error()
+        raise DisscError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def current_stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def make_tensor_table(named):
+    """{name: contiguous fp32 CPU tensor} -> (ctypes array, keep-alive list)."""
+    arr = (DisscTensor * len(named))()
+    keep = []
+    for i, (k, t) in enumerate(named.items()):
+        t = t.detach().to("cpu", torch.float32).contiguous()
+        nb = k.encode()
+        keep.append((t, nb))
+        arr[i].name = nb
+        arr[i].data = t.data_ptr()
+        arr[i].ndim = t.dim()
+        for d in range(t.dim()):
+            arr[i].shape[d] = t.shape[d]
+    return arr, keep

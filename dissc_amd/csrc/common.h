@@ -1,0 +1,87 @@
+// Shared declarations for libdissc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dissc_hip.h"
+
+namespace dissc {
+
+void set_error(const char* fmt, ...);
+
+#define DISSC_HIP_CHECK(expr)                                                       \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      dissc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                       __FILE__, __LINE__);                                         \
+      return DISSC_EHIP;                                                            \
+    }                                                                               \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Channels staged per LDS chunk of the implicit-GEMM conv (= 4 MFMA k-steps of 4).
+constexpr int KC = 16;
+
+// Epilogue modes of the conv kernel.
+enum Epi : int {
+  EPI_STORE = 0,    // out = conv
+  EPI_RES = 1,      // out = conv + res                         (ResBlock1: x = xt + x)
+  EPI_MRF_SET = 2,  // acc = conv + res                         (xs = resblock_0(x))
+  EPI_MRF_ADD = 3,  // acc = acc + (conv + res)                 (xs += resblock_j(x))
+  EPI_MRF_DIV = 4,  // acc = (acc + (conv + res)) / mrf_div     (x = xs / num_kernels)
+};
+
+// One dilated "same" Conv1d (or a phase-decomposed ConvTranspose1d when up > 1)
+// as an implicit GEMM on v_mfma_f32_16x16x4_f32:  D[M, time] += Wpack[M, K] * Xwin[K, time].
+struct ConvArgs {
+  const float* x;       // [B][CIN][ldx]
+  const float* wpack;   // packed A fragments, see pack_conv_weights()
+  const float* bias;    // [Mpad] one per GEMM row
+  const float* res;     // residual, same layout as out (EPI_RES / EPI_MRF_*)
+  float* out;           // [B][M/up][ldo]
+  float* acc;           // MRF accumulator (EPI_MRF_*), same layout as out
+  const int32_t* lengths;  // [B] valid frames, or nullptr
+  int len_default;      // used when lengths == nullptr (already in this layer's units)
+  int len_mul;          // layer length = lengths[b] * len_mul
+  int CIN, M, KS, dil, nchunk;
+  int XW;               // LDS row stride (floats), XW % 32 == 16
+  int ldx, ldo;
+  long long x_bstride, o_bstride;
+  float slope;          // leaky-ReLU slope applied to x on load (1 = identity)
+  float mrf_div;
+  int epi;
+  int up;               // 1 = conv; s = ConvTranspose stride (rows are co*s+p)
+};
+
+// Pick a tile shape for M rows / Lmax columns and launch.  Returns a DISSC_* code.
+int launch_conv(const ConvArgs& a, int B, int Lmax, hipStream_t stream);
+// LDS row stride for a (KS, dil) conv with time tile BN.
+int conv_tile_bn(int M);
+int conv_xw(int M, int KS, int dil);
+
+// Host-side weight packing.  w: [Cout][Cin][KS] (Conv1d layout).  Returns the packed
+// buffer (Mpad/16 * nchunk * KS * 64 float4) and Mpad (M rounded up to 16).
+void pack_conv_weights(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
+                       int& Mpad, int& nchunk);
+// ConvTranspose1d [Cin][Cout][k], stride s, padding (k-s)/2  ->  3-tap conv with
+// M = Cout*s rows (row = co*s + p), taps delta = -1,0,+1.
+void convT_to_conv(const float* w, int Cin, int Cout, int k, int s, std::vector<float>& w3);
+
+// misc kernels (gen_misc.hip)
+void launch_embed_concat(const int64_t* code, const float* f0, const int64_t* spkr,
+                         const float* dict_w, const float* spkr_w, const int32_t* lengths, int B,
+                         int T, int E, int has_f0, int has_spkr, int n_codes, int n_spk, float* x,
+                         int ldx, hipStream_t stream);
+void launch_conv_post(const float* x, const float* w, const float* bias, const int32_t* lengths,
+                      int len_mul, int B, int C, int KS, int L, int ldx, long long x_bstride,
+                      float slope, float* wav, int ldw, hipStream_t stream);
+void launch_wav_postprocess(float* wav, const int32_t* n_samples, int B, int ld,
+                            hipStream_t stream);
+
+}  // namespace dissc

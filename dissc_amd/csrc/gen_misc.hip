@@ -1,0 +1,133 @@
+// Small bandwidth-bound kernels around the generator's conv stack.
+#include "common.h"
+
+namespace dissc {
+
+// x[b, c, t] = [ dict[code[b,t]] (E) | f0[b,t] (1) | spkr_emb[spkr[b]] (E) ]
+// Replaces nn.Embedding x2 + _upsample + torch.cat, reference sr/models.py:189,207-215.
+__global__ void embed_concat_kernel(const int64_t* __restrict__ code, const float* __restrict__ f0,
+                                    const int64_t* __restrict__ spkr,
+                                    const float* __restrict__ dict_w,
+                                    const float* __restrict__ spkr_w,
+                                    const int32_t* __restrict__ lengths, int T, int E, int has_f0,
+                                    int has_spkr, int n_codes, int n_spk, float* __restrict__ x,
+                                    int ldx, int C) {
+  const int b = blockIdx.z;
+  const int c = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int len = lengths ? lengths[b] : T;
+  if (t >= len) return;
+  float v;
+  if (c < E) {
+    long long id = code[(size_t)b * T + t];
+    id = id < 0 ? 0 : (id >= n_codes ? n_codes - 1 : id);  // out-of-range ids are clamped, never read OOB
+    v = dict_w[(size_t)id * E + c];
+  } else if (has_f0 && c == E) {
+    v = f0[(size_t)b * T + t];
+  } else {
+    long long id = spkr[b];
+    id = id < 0 ? 0 : (id >= n_spk ? n_spk - 1 : id);
+    v = spkr_w[(size_t)id * E + (c - E - (has_f0 ? 1 : 0))];
+  }
+  x[((size_t)b * C + c) * ldx + t] = v;
+}
+
+void launch_embed_concat(const int64_t* code, const float* f0, const int64_t* spkr,
+                         const float* dict_w, const float* spkr_w, const int32_t* lengths, int B,
+                         int T, int E, int has_f0, int has_spkr, int n_codes, int n_spk, float* x,
+                         int ldx, hipStream_t stream) {
+  const int C = E + (has_f0 ? 1 : 0) + (has_spkr ? E : 0);
+  dim3 grid((T + 127) / 128, C, B);
+  hipLaunchKernelGGL(embed_concat_kernel, grid, dim3(128), 0, stream, code, f0, spkr, dict_w,
+                     spkr_w, lengths, T, E, has_f0, has_spkr, n_codes, n_spk, x, ldx, C);
+}
+
+// wav[b, t] = tanh(bias + sum_{ci,j} w[ci,j] * lrelu(x[b,ci,t+j-KS/2], slope)), 0 beyond length.
+// Replaces F.leaky_relu -> conv_post -> tanh, reference sr/models.py:110-112.
+constexpr int POST_TILE = 512;
+__global__ void __launch_bounds__(256) conv_post_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        const int32_t* __restrict__ lengths,
+                                                        int len_mul, int C, int KS, int L, int ldx,
+                                                        long long x_bstride, float slope,
+                                                        float* __restrict__ wav, int ldw) {
+  extern __shared__ float xs[];  // [C][POST_TILE + KS - 1]
+  const int b = blockIdx.y;
+  const int len = lengths ? lengths[b] * len_mul : L;
+  const int t0 = blockIdx.x * POST_TILE;
+  float* wb = wav + (size_t)b * ldw;
+  if (t0 >= len) {
+    for (int i = threadIdx.x; i < POST_TILE; i += 256)
+      if (t0 + i < L) wb[t0 + i] = 0.f;
+    return;
+  }
+  const int halo = KS / 2;
+  const int W = POST_TILE + KS - 1;
+  const float* xb = x + (size_t)b * x_bstride;
+  for (int e = threadIdx.x; e < C * W; e += 256) {
+    const int ci = e / W, u = e - ci * W;
+    const int t = t0 - halo + u;
+    float v = 0.f;
+    if (t >= 0 && t < len) {
+      v = xb[(size_t)ci * ldx + t];
+      v = v > 0.f ? v : v * slope;
+    }
+    xs[e] = v;
+  }
+  __syncthreads();
+  const float bz = bias[0];
+#pragma unroll
+  for (int i = 0; i < POST_TILE / 256; ++i) {
+    const int u = threadIdx.x + i * 256;
+    const int t = t0 + u;
+    if (t >= L) continue;
+    float s = bz;
+    for (int ci = 0; ci < C; ++ci)
+      for (int j = 0; j < KS; ++j) s = fmaf(w[ci * KS + j], xs[ci * W + u + j], s);
+    wb[t] = t < len ? tanhf(s) : 0.f;
+  }
+}
+
+void launch_conv_post(const float* x, const float* w, const float* bias, const int32_t* lengths,
+                      int len_mul, int B, int C, int KS, int L, int ldx, long long x_bstride,
+                      float slope, float* wav, int ldw, hipStream_t stream) {
+  dim3 grid((L + POST_TILE - 1) / POST_TILE, B);
+  const size_t lds = (size_t)C * (POST_TILE + KS - 1) * sizeof(float);
+  hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), lds, stream, x, w, bias, lengths, len_mul,
+                     C, KS, L, ldx, x_bstride, slope, wav, ldw);
+}
+
+// (y*32768) -> int16 with C truncation + two's-complement wrap -> float -> / max|.|
+// Replaces reference sr/inference.py:73-75 and librosa.util.normalize at :206/:250.
+__global__ void __launch_bounds__(1024) wav_postprocess_kernel(float* __restrict__ wav,
+                                                               const int32_t* __restrict__ n_samples,
+                                                               int ld) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  const int n = n_samples[b];
+  float* w = wav + (size_t)b * ld;
+  float peak = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    int v = (int)truncf(w[i] * 32768.0f);
+    v = ((v + 32768) & 65535) - 32768;
+    const float f = (float)v;
+    w[i] = f;
+    peak = fmaxf(peak, fabsf(f));
+  }
+  for (int off = 32; off > 0; off >>= 1) peak = fmaxf(peak, __shfl_xor(peak, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = peak;
+  __syncthreads();
+  peak = red[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) peak = fmaxf(peak, red[i]);
+  if (peak < 1.17549435e-38f) return;  // librosa: norms below tiny are left as is
+  for (int i = threadIdx.x; i < n; i += 1024) w[i] = __fdiv_rn(w[i], peak);
+}
+
+void launch_wav_postprocess(float* wav, const int32_t* n_samples, int B, int ld,
+                            hipStream_t stream) {
+  hipLaunchKernelGGL(wav_postprocess_kernel, dim3(B), dim3(1024), 0, stream, wav, n_samples, ld);
+}
+
+}  // namespace dissc

@@ -1,0 +1,423 @@
+// dissc_gen_*: the unit/F0/speaker-conditioned HiFi-GAN generator on one MI355X.
+// Orchestrates ~100 launches of conv_mfma_kernel per forward on the caller's stream;
+// all activations live in the caller-provided workspace (no allocation here).
+//
+// Workspace = 4 buffers of B * max_i(C_i * ld_i) floats:
+//   X   stage input (ConvTranspose output), read by the 3 resblocks
+//   TMP conv1 output of the current (conv1, conv2) pair
+//   XK  running x of the current resblock
+//   ACC MRF accumulator; becomes the next stage's ConvTranspose input
+// Activations are channels-first [B][C][ld] fp32 (time contiguous => coalesced tile
+// loads and MFMA-row stores), ld = stage length rounded up to 4.
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+
+#include "common.h"
+
+namespace dissc {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct DevConv {
+  float* wpack = nullptr;
+  float* bias = nullptr;
+  int CIN = 0, M = 0, KS = 0, dil = 1, nchunk = 0, up = 1;
+  double macs_per_t = 0;  // MACs per input time step (algorithmic, zero taps excluded)
+};
+
+static int upload(const std::vector<float>& h, float** d) {
+  DISSC_HIP_CHECK(hipMalloc((void**)d, h.size() * sizeof(float)));
+  DISSC_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  return DISSC_OK;
+}
+
+static int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int dil,
+                     DevConv& dc) {
+  std::vector<float> packed;
+  int Mpad, nchunk;
+  pack_conv_weights(w, Cout, Cin, KS, packed, Mpad, nchunk);
+  std::vector<float> b(Mpad, 0.f);
+  if (bias) memcpy(b.data(), bias, Cout * sizeof(float));
+  dc.CIN = Cin; dc.M = Cout; dc.KS = KS; dc.dil = dil; dc.nchunk = nchunk; dc.up = 1;
+  dc.macs_per_t = (double)Cout * Cin * KS;
+  int rc = upload(packed, &dc.wpack);
+  if (rc) return rc;
+  return upload(b, &dc.bias);
+}
+
+static int make_convT(const float* w, const float* bias, int Cin, int Cout, int k, int s,
+                      DevConv& dc) {
+  std::vector<float> w3;
+  convT_to_conv(w, Cin, Cout, k, s, w3);
+  std::vector<float> b3((size_t)Cout * s);
+  for (int co = 0; co < Cout; ++co)
+    for (int p = 0; p < s; ++p) b3[co * s + p] = bias ? bias[co] : 0.f;
+  int rc = make_conv(w3.data(), b3.data(), Cout * s, Cin, 3, 1, dc);
+  dc.up = s;
+  dc.macs_per_t = (double)Cin * Cout * k;  // per INPUT step: every (ci,co,kk) used once
+  return rc;
+}
+
+static void free_conv(DevConv& dc) {
+  if (dc.wpack) (void)hipFree(dc.wpack);
+  if (dc.bias) (void)hipFree(dc.bias);
+  dc.wpack = dc.bias = nullptr;
+}
+
+}  // namespace dissc
+
+using namespace dissc;
+
+struct dissc_gen {
+  DisscGenConfig cfg;
+  int hop = 1;
+  DevConv conv_pre;
+  std::vector<DevConv> ups;
+  std::vector<DevConv> rb1, rb2;  // [stage*nk*3 + j*3 + m]
+  float* post_w = nullptr;
+  float* post_b = nullptr;
+  int post_C = 0, post_KS = 0;
+  float* dict_w = nullptr;
+  float* spkr_w = nullptr;
+  std::vector<int> stage_C, stage_mul;  // channels / length multiplier after ups[i]
+  ~dissc_gen() {
+    free_conv(conv_pre);
+    for (auto& c : ups) free_conv(c);
+    for (auto& c : rb1) free_conv(c);
+    for (auto& c : rb2) free_conv(c);
+    if (post_w) (void)hipFree(post_w);
+    if (post_b) (void)hipFree(post_b);
+    if (dict_w) (void)hipFree(dict_w);
+    if (spkr_w) (void)hipFree(spkr_w);
+  }
+};
+
+static inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+extern "C" {
+
+const char* dissc_last_error(void) { return g_err; }
+int dissc_abi_version(void) { return 1; }
+
+int dissc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int dissc_device_name(int dev, char* buf, size_t buflen) {
+  hipDeviceProp_t p;
+  DISSC_HIP_CHECK(hipGetDeviceProperties(&p, dev));
+  snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return DISSC_OK;
+}
+
+int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size_t n_weights,
+                     dissc_gen_t* out) {
+  if (!cfg || !weights || !out) {
+    set_error("dissc_gen_create: null argument");
+    return DISSC_EINVAL;
+  }
+  if (cfg->num_upsamples < 1 || cfg->num_upsamples > DISSC_MAX_UPS || cfg->num_kernels < 1 ||
+      cfg->num_kernels > DISSC_MAX_RK) {
+    set_error("dissc_gen_create: unsupported num_upsamples=%d / num_kernels=%d", cfg->num_upsamples,
+              cfg->num_kernels);
+    return DISSC_EINVAL;
+  }
+  std::map<std::string, const DisscTensor*> byname;
+  for (size_t i = 0; i < n_weights; ++i) byname[weights[i].name] = &weights[i];
+  auto get = [&](const std::string& name, std::initializer_list<int64_t> shape,
+                 const float** p) -> int {
+    auto it = byname.find(name);
+    if (it == byname.end()) {
+      set_error("dissc_gen_create: missing tensor '%s'", name.c_str());
+      return DISSC_ENOTFOUND;
+    }
+    const DisscTensor* t = it->second;
+    size_t d = 0;
+    bool ok = (size_t)t->ndim == shape.size();
+    for (int64_t s : shape) {
+      if (ok && t->shape[d] != s) ok = false;
+      ++d;
+    }
+    if (!ok) {
+      set_error("dissc_gen_create: tensor '%s' has the wrong shape", name.c_str());
+      return DISSC_EINVAL;
+    }
+    *p = t->data;
+    return DISSC_OK;
+  };
+
+  dissc_gen* g = new dissc_gen();
+  g->cfg = *cfg;
+  int rc = DISSC_OK;
+  const float *w = nullptr, *b = nullptr;
+  const int c0 = cfg->upsample_initial_channel;
+  const int in_dim = cfg->model_in_dim;
+  const int E = cfg->embedding_dim;
+  auto fail = [&](int code) {
+    delete g;
+    return code;
+  };
+  if (in_dim != E + (cfg->has_f0 ? 1 : 0) + (cfg->has_spkr ? E : 0)) {
+    set_error("dissc_gen_create: model_in_dim %d != embedding_dim %d (+1 f0) (+%d spkr)", in_dim, E, E);
+    return fail(DISSC_EINVAL);
+  }
+  if ((rc = get("conv_pre.weight", {c0, in_dim, 7}, &w))) return fail(rc);
+  if ((rc = get("conv_pre.bias", {c0}, &b))) return fail(rc);
+  if ((rc = make_conv(w, b, c0, in_dim, 7, 1, g->conv_pre))) return fail(rc);
+
+  int ch = c0, mul = 1;
+  g->ups.resize(cfg->num_upsamples);
+  const int nk = cfg->num_kernels;
+  g->rb1.resize((size_t)cfg->num_upsamples * nk * 3);
+  g->rb2.resize((size_t)cfg->num_upsamples * nk * 3);
+  for (int i = 0; i < cfg->num_upsamples; ++i) {
+    const int s = cfg->upsample_rates[i], k = cfg->upsample_kernel_sizes[i];
+    if (s < 1 || k < s || (k - s) % 2 != 0) {  // L_out = s * L_in needs k - s even
+      set_error("dissc_gen_create: upsample k=%d s=%d unsupported", k, s);
+      return fail(DISSC_EINVAL);
+    }
+    {  // every tap kk must map to delta in {-1,0,1}: kk = p + pad - s*delta
+      const int pad = (k - s) / 2;
+      bool ok = true;
+      for (int p = 0; p < s && ok; ++p)
+        for (int kk = (p + pad) % s; kk < k; kk += s) {
+          const int delta = (p + pad - kk) / s;  // exact
+          if (delta < -1 || delta > 1) ok = false;
+        }
+      if (!ok) {
+        set_error("dissc_gen_create: upsample k=%d s=%d needs more than 3 phase taps", k, s);
+        return fail(DISSC_EINVAL);
+      }
+    }
+    const int cout = ch / 2;
+    char name[96];
+    snprintf(name, sizeof(name), "ups.%d.weight", i);
+    if ((rc = get(name, {ch, cout, k}, &w))) return fail(rc);
+    snprintf(name, sizeof(name), "ups.%d.bias", i);
+    if ((rc = get(name, {cout}, &b))) return fail(rc);
+    if ((rc = make_convT(w, b, ch, cout, k, s, g->ups[i]))) return fail(rc);
+    ch = cout;
+    mul *= s;
+    g->stage_C.push_back(ch);
+    g->stage_mul.push_back(mul);
+    for (int j = 0; j < nk; ++j) {
+      const int rk = cfg->resblock_kernel_sizes[j];
+      if (rk % 2 != 1) {
+        set_error("dissc_gen_create: even resblock kernel size %d unsupported", rk);
+        return fail(DISSC_EINVAL);
+      }
+      for (int m = 0; m < 3; ++m) {
+        const int d = cfg->resblock_dilations[j][m];
+        const size_t idx = ((size_t)i * nk + j) * 3 + m;
+        snprintf(name, sizeof(name), "resblocks.%d.convs1.%d.weight", i * nk + j, m);
+        if ((rc = get(name, {ch, ch, rk}, &w))) return fail(rc);
+        snprintf(name, sizeof(name), "resblocks.%d.convs1.%d.bias", i * nk + j, m);
+        if ((rc = get(name, {ch}, &b))) return fail(rc);
+        if ((rc = make_conv(w, b, ch, ch, rk, d, g->rb1[idx]))) return fail(rc);
+        snprintf(name, sizeof(name), "resblocks.%d.convs2.%d.weight", i * nk + j, m);
+        if ((rc = get(name, {ch, ch, rk}, &w))) return fail(rc);
+        snprintf(name, sizeof(name), "resblocks.%d.convs2.%d.bias", i * nk + j, m);
+        if ((rc = get(name, {ch}, &b))) return fail(rc);
+        if ((rc = make_conv(w, b, ch, ch, rk, 1, g->rb2[idx]))) return fail(rc);
+      }
+    }
+  }
+  g->hop = mul;
+  if ((rc = get("conv_post.weight", {1, ch, 7}, &w))) return fail(rc);
+  if ((rc = get("conv_post.bias", {1}, &b))) return fail(rc);
+  g->post_C = ch;
+  g->post_KS = 7;
+  if ((rc = upload(std::vector<float>(w, w + ch * 7), &g->post_w))) return fail(rc);
+  if ((rc = upload(std::vector<float>(b, b + 1), &g->post_b))) return fail(rc);
+  if ((rc = get("dict.weight", {cfg->num_embeddings, E}, &w))) return fail(rc);
+  if ((rc = upload(std::vector<float>(w, w + (size_t)cfg->num_embeddings * E), &g->dict_w)))
+    return fail(rc);
+  if (cfg->has_spkr) {
+    if ((rc = get("spkr.weight", {cfg->num_speakers, E}, &w))) return fail(rc);
+    if ((rc = upload(std::vector<float>(w, w + (size_t)cfg->num_speakers * E), &g->spkr_w)))
+      return fail(rc);
+  }
+  *out = g;
+  return DISSC_OK;
+}
+
+void dissc_gen_destroy(dissc_gen_t g) { delete g; }
+
+int dissc_gen_hop(dissc_gen_t g) { return g ? g->hop : 0; }
+
+static size_t gen_buf_floats(const dissc_gen* g, int B, int Tmax) {
+  size_t per = (size_t)g->cfg.upsample_initial_channel * round_up(Tmax, 4);
+  per = std::max(per, (size_t)g->cfg.model_in_dim * round_up(Tmax, 4));
+  for (size_t i = 0; i < g->stage_C.size(); ++i)
+    per = std::max(per, (size_t)g->stage_C[i] * round_up((size_t)Tmax * g->stage_mul[i], 4));
+  return round_up(per * B, 64);
+}
+
+size_t dissc_gen_workspace_bytes(dissc_gen_t g, int B, int Tmax) {
+  if (!g || B <= 0 || Tmax <= 0) return 0;
+  return 4 * gen_buf_floats(g, B, Tmax) * sizeof(float) + 256;
+}
+
+double dissc_gen_flops(dissc_gen_t g, int64_t frames) {
+  if (!g) return 0;
+  double macs = g->conv_pre.macs_per_t;
+  int mul = 1;
+  const int nk = g->cfg.num_kernels;
+  for (int i = 0; i < g->cfg.num_upsamples; ++i) {
+    macs += g->ups[i].macs_per_t * mul;
+    mul = g->stage_mul[i];
+    for (int j = 0; j < nk * 3; ++j)
+      macs += (g->rb1[(size_t)i * nk * 3 + j].macs_per_t + g->rb2[(size_t)i * nk * 3 + j].macs_per_t) * mul;
+  }
+  macs += (double)g->post_C * g->post_KS * mul;
+  return 2.0 * macs * (double)frames;
+}
+
+static int run_conv(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
+                    const int32_t* lengths, int len_default, int len_mul, int B, int C_x, int ldx,
+                    int ldo, int Lmax, float slope, int epi, float mrf_div, hipStream_t stream) {
+  ConvArgs a;
+  a.x = x; a.wpack = dc.wpack; a.bias = dc.bias; a.res = res; a.out = out; a.acc = acc;
+  a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul;
+  a.CIN = dc.CIN; a.M = dc.M; a.KS = dc.KS; a.dil = dc.dil; a.nchunk = dc.nchunk;
+  a.XW = conv_xw(dc.M, dc.KS, dc.dil);
+  a.ldx = ldx; a.ldo = ldo;
+  a.x_bstride = (long long)C_x * ldx;
+  a.o_bstride = (long long)(dc.M / dc.up) * ldo;
+  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.up = dc.up;
+  return launch_conv(a, B, Lmax, stream);
+}
+
+int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const int64_t* spkr,
+                      const int32_t* lengths, int B, int Tmax, float* wav_out, void* workspace,
+                      size_t workspace_bytes, void* stream_) {
+  if (!g || !code || !wav_out || !workspace || (g->cfg.has_f0 && !f0) ||
+      (g->cfg.has_spkr && !spkr)) {
+    set_error("dissc_gen_forward: null argument");
+    return DISSC_EINVAL;
+  }
+  if (B <= 0 || Tmax <= 0) {
+    set_error("dissc_gen_forward: B=%d Tmax=%d", B, Tmax);
+    return DISSC_EINVAL;
+  }
+  if ((long long)Tmax * g->hop > 2000000000LL) {
+    set_error("dissc_gen_forward: Tmax=%d too long", Tmax);
+    return DISSC_EINVAL;
+  }
+  if (workspace_bytes < dissc_gen_workspace_bytes(g, B, Tmax)) {
+    set_error("dissc_gen_forward: workspace %zu < %zu bytes", workspace_bytes,
+              dissc_gen_workspace_bytes(g, B, Tmax));
+    return DISSC_ENOMEM;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t nbuf = gen_buf_floats(g, B, Tmax);
+  float* base = (float*)round_up((size_t)workspace, 256);
+  float* X = base;
+  float* TMP = base + nbuf;
+  float* XK = base + 2 * nbuf;
+  float* ACC = base + 3 * nbuf;
+  const DisscGenConfig& c = g->cfg;
+  int rc;
+
+  // 1. conditioning -> TMP [B, in_dim, ld0]
+  const int ld0 = (int)round_up(Tmax, 4);
+  launch_embed_concat(code, f0, spkr, g->dict_w, g->spkr_w, lengths, B, Tmax, c.embedding_dim,
+                      c.has_f0, c.has_spkr, c.num_embeddings, c.num_speakers, TMP, ld0, stream);
+  // 2. conv_pre -> ACC [B, c0, ld0]
+  if ((rc = run_conv(g->conv_pre, TMP, ACC, nullptr, nullptr, lengths, Tmax, 1, B, c.model_in_dim,
+                     ld0, ld0, Tmax, 1.0f, EPI_STORE, 1.f, stream)))
+    return rc;
+  int ch = c.upsample_initial_channel, mul = 1, ld = ld0;
+  const int nk = c.num_kernels;
+  for (int i = 0; i < c.num_upsamples; ++i) {
+    const int s = c.upsample_rates[i];
+    const int ch_out = ch / 2, mul_out = mul * s;
+    const int ld_out = (int)round_up((size_t)Tmax * mul_out, 4);
+    // lrelu(0.1) -> ConvTranspose: ACC [B,ch,ld] -> X [B,ch_out,ld_out]
+    if ((rc = run_conv(g->ups[i], ACC, X, nullptr, nullptr, lengths, Tmax * mul, mul, B, ch, ld,
+                       ld_out, Tmax * mul, 0.1f, EPI_STORE, 1.f, stream)))
+      return rc;
+    ch = ch_out; mul = mul_out; ld = ld_out;
+    const int L = Tmax * mul;
+    for (int j = 0; j < nk; ++j) {
+      for (int m = 0; m < 3; ++m) {
+        const size_t idx = ((size_t)i * nk + j) * 3 + m;
+        const float* xin = (m == 0) ? X : XK;
+        if ((rc = run_conv(g->rb1[idx], xin, TMP, nullptr, nullptr, lengths, L, mul, B, ch, ld, ld,
+                           L, 0.1f, EPI_STORE, 1.f, stream)))
+          return rc;
+        int epi = EPI_RES;
+        if (m == 2) epi = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET)
+                                   : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
+        if ((rc = run_conv(g->rb2[idx], TMP, XK, xin, ACC, lengths, L, mul, B, ch, ld, ld, L, 0.1f,
+                           epi, (float)nk, stream)))
+          return rc;
+      }
+    }
+  }
+  // tail: lrelu(0.01) -> conv_post -> tanh
+  launch_conv_post(ACC, g->post_w, g->post_b, lengths, mul, B, ch, g->post_KS, Tmax * mul, ld,
+                   (long long)ch * ld, 0.01f, wav_out, Tmax * mul, stream);
+  DISSC_HIP_CHECK(hipGetLastError());
+  return DISSC_OK;
+}
+
+int dissc_wav_postprocess(float* wav, const int32_t* n_samples, int B, int ld, void* stream) {
+  if (!wav || !n_samples || B <= 0) {
+    set_error("dissc_wav_postprocess: bad argument");
+    return DISSC_EINVAL;
+  }
+  launch_wav_postprocess(wav, n_samples, B, ld, (hipStream_t)stream);
+  DISSC_HIP_CHECK(hipGetLastError());
+  return DISSC_OK;
+}
+
+// ---- stand-alone conv entry points (weights packed per call: tests only) ----------------
+static int conv_once(DevConv& dc, const float* x, float* y, const int32_t* lengths, int B,
+                     int ldx, int ldo, int Lmax, float in_slope, hipStream_t stream) {
+  int rc = run_conv(dc, x, y, nullptr, nullptr, lengths, Lmax, 1, B, dc.CIN, ldx, ldo, Lmax,
+                    in_slope, EPI_STORE, 1.f, stream);
+  hipError_t e = hipStreamSynchronize(stream);
+  free_conv(dc);
+  if (rc) return rc;
+  DISSC_HIP_CHECK(e);
+  return DISSC_OK;
+}
+
+int dissc_conv1d(const float* x, const float* w_host, const float* bias_host, float* y,
+                 const int32_t* lengths, int B, int Cin, int Cout, int k, int dilation, int ldx,
+                 int ldo, int Lmax, float in_slope, void* stream) {
+  if (!x || !w_host || !y || k % 2 != 1 || dilation < 1) {
+    set_error("dissc_conv1d: bad argument");
+    return DISSC_EINVAL;
+  }
+  DevConv dc;
+  int rc = make_conv(w_host, bias_host, Cout, Cin, k, dilation, dc);
+  if (rc) return rc;
+  return conv_once(dc, x, y, lengths, B, ldx, ldo, Lmax, in_slope, (hipStream_t)stream);
+}
+
+int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bias_host, float* y,
+                           const int32_t* lengths, int B, int Cin, int Cout, int k, int stride,
+                           int ldx, int ldo, int Lmax, float in_slope, void* stream) {
+  if (!x || !w_host || !y || stride < 1 || (k - stride) % 2 != 0) {
+    set_error("dissc_conv_transpose1d: bad argument");
+    return DISSC_EINVAL;
+  }
+  DevConv dc;
+  int rc = make_convT(w_host, bias_host, Cin, Cout, k, stride, dc);
+  if (rc) return rc;
+  return conv_once(dc, x, y, lengths, B, ldx, ldo, Lmax, in_slope, (hipStream_t)stream);
+}
+
+}  // extern "C"

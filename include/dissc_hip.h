@@ -1,0 +1,129 @@
+/*
+ * dissc_hip.h -- C ABI of libdissc_hip.so, the MI355X (gfx950) implementation of
+ * the DISSC inference hot path.
+ *
+ * The reference (gallilmaimon/DISSC) has no FFI layer: the hot path sits behind
+ * four nn.Module call signatures.  Each entry point below
+ * names the reference interface it replaces; the dissc_amd Python package re-creates those
+ * Python signatures on top of this ABI through ctypes.
+ *
+ * Conventions
+ *   - every data pointer passed to a *_forward / kernel entry point is a DEVICE
+ *     pointer owned by the caller (PyTorch's allocator in practice); pointers
+ *     passed to *_create are HOST pointers (weights are copied and re-packed
+ *     once, the library owns the device copy);
+ *   - no allocation and no synchronisation inside *_forward: work is enqueued
+ *     on the given hipStream_t (passed as void*; NULL = the null stream);
+ *   - return 0 on success, a negative DISSC_E* code on failure; nothing throws
+ *     across the ABI; dissc_last_error() returns a thread-local message;
+ *   - one handle per process/GPU, handles are independent, no global state.
+ */
+#ifndef DISSC_HIP_H
+#define DISSC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DISSC_OK 0
+#define DISSC_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define DISSC_ENOMEM (-2)   /* workspace too small / device allocation failed */
+#define DISSC_EHIP (-3)     /* a HIP runtime call failed */
+#define DISSC_ENOTFOUND (-4) /* a required weight tensor is missing */
+
+/* A named host tensor (fp32, contiguous, PyTorch layout). */
+typedef struct {
+  const char* name;   /* state_dict key after weight-norm folding, e.g. "ups.0.weight" */
+  const float* data;  /* host pointer */
+  int64_t shape[4];
+  int32_t ndim;
+} DisscTensor;
+
+const char* dissc_last_error(void);
+/* ABI version of this header: bumped when a signature changes. */
+int dissc_abi_version(void);
+/* Number of HIP devices visible / name of device `dev` (for diagnostics). */
+int dissc_device_count(void);
+int dissc_device_name(int dev, char* buf, size_t buflen);
+
+/* ------------------------------------------------------------------------- *
+ * HiFi-GAN unit/F0/speaker-conditioned generator.
+ * Replaces: CodeGenerator.forward + Generator.forward + ResBlock1.forward,
+ *           reference sr/models.py:179-225, :98-114, :34-41 (called from
+ *           generate(), reference sr/inference.py:67-76).
+ * ------------------------------------------------------------------------- */
+#define DISSC_MAX_UPS 8
+#define DISSC_MAX_RK 4
+
+typedef struct {
+  int32_t model_in_dim;             /* 257 = 128 code | 1 f0 | 128 spkr  (config "model_in_dim") */
+  int32_t upsample_initial_channel; /* 512 */
+  int32_t num_upsamples;            /* 5 */
+  int32_t upsample_rates[DISSC_MAX_UPS];        /* 5,4,4,2,2 */
+  int32_t upsample_kernel_sizes[DISSC_MAX_UPS]; /* 11,8,8,4,4 */
+  int32_t num_kernels;              /* 3 */
+  int32_t resblock_kernel_sizes[DISSC_MAX_RK];      /* 3,7,11 */
+  int32_t resblock_dilations[DISSC_MAX_RK][3];      /* 1,3,5 each */
+  int32_t num_embeddings;           /* 100 */
+  int32_t embedding_dim;            /* 128 */
+  int32_t num_speakers;             /* 200 rows in spkr.weight (reference sr/models.py:133) */
+  int32_t has_f0;                   /* config "f0" */
+  int32_t has_spkr;                 /* config "multispkr" */
+} DisscGenConfig;
+
+typedef struct dissc_gen* dissc_gen_t;
+
+/* weights: folded (weight-norm removed) tensors named like the reference's
+ * state_dict after remove_weight_norm(): "conv_pre.weight/.bias",
+ * "ups.{i}.weight/.bias" ([Cin,Cout,k]), "resblocks.{n}.convs{1,2}.{m}.weight/.bias",
+ * "conv_post.weight/.bias", "dict.weight", "spkr.weight". */
+int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size_t n_weights,
+                     dissc_gen_t* out);
+void dissc_gen_destroy(dissc_gen_t g);
+/* samples produced per input frame (= prod(upsample_rates) = 320) */
+int dissc_gen_hop(dissc_gen_t g);
+size_t dissc_gen_workspace_bytes(dissc_gen_t g, int B, int Tmax);
+/* FLOPs (2*MAC) of one forward for `frames` total valid frames (roofline accounting) */
+double dissc_gen_flops(dissc_gen_t g, int64_t frames);
+/*
+ * code    i64 [B,Tmax]   unit ids in [0,num_embeddings)
+ * f0      f32 [B,Tmax]   one value per frame (reference shape [B,1,T])
+ * spkr    i64 [B]        speaker ids in [0,num_speakers)
+ * lengths i32 [B]        valid frames per utterance (NULL = all Tmax).  Every
+ *                        layer treats positions >= length as the zero padding the
+ *                        reference's B=1 run would see, so a ragged batch is
+ *                        sample-exact with per-utterance runs.
+ * wav_out f32 [B,hop*Tmax]  samples >= hop*length[b] are written as 0.
+ */
+int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const int64_t* spkr,
+                      const int32_t* lengths, int B, int Tmax, float* wav_out, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* Stand-alone conv entry points (unit-testable building blocks of the above).
+ * x f32 [B,Cin,ldx] -> y f32 [B,Cout,ldo]; "same" zero padding at both ends of
+ * each utterance's valid length; in_slope = leaky-ReLU slope applied to the
+ * input on load (1.0 = none).  w: HOST pointer [Cout,Cin,k] (re-packed per call:
+ * test/debug path only). */
+int dissc_conv1d(const float* x, const float* w_host, const float* bias_host, float* y,
+                 const int32_t* lengths, int B, int Cin, int Cout, int k, int dilation, int ldx,
+                 int ldo, int Lmax, float in_slope, void* stream);
+/* ConvTranspose1d(Cin,Cout,k,stride,padding=(k-stride)/2); w HOST [Cin,Cout,k];
+ * y [B,Cout,ldo] with length stride*len. */
+int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bias_host, float* y,
+                           const int32_t* lengths, int B, int Cin, int Cout, int k, int stride,
+                           int ldx, int ldo, int Lmax, float in_slope, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Waveform post-processing.
+ * Replaces: generate(), reference sr/inference.py:73-75 ((y*32768).astype(int16),
+ * C truncation + wrap) and librosa.util.normalize at :206/:250 (x / max|x|).
+ * wav f32 [B,ld] (in place), lengths in SAMPLES per utterance.
+ * ------------------------------------------------------------------------- */
+int dissc_wav_postprocess(float* wav, const int32_t* n_samples, int B, int ld, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISSC_HIP_H */

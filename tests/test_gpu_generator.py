@@ -1,0 +1,172 @@
+"""GPU parity tests of the HIP generator path (through the C ABI) against the CPU
+oracle and the committed reference golden vectors.  Run with -m gpu on an MI355X."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dissc_amd
+    from dissc_amd import _lib
+    from oracle import generator_ref as gr
+    from oracle import synth
+    sd = synth.synth_generator_state_dict(seed=0)
+    g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
+    g.load_state_dict(sd)
+    g.eval()
+    g.remove_weight_norm()
+    return dict(lib=_lib.lib, _lib=_lib, gr=gr, synth=synth, g=g, folded=gr.fold_state_dict(sd))
+
+
+def _rms(a):
+    return float(np.sqrt(np.mean(np.square(np.asarray(a, dtype=np.float64)))))
+
+
+def _run_conv(env, x, w, b, lengths, k, d, slope, transpose=False, stride=1):
+    lib, _lib = env["lib"], env["_lib"]
+    B, Cin, L = x.shape
+    ldx = (L + 3) // 4 * 4
+    xd = torch.zeros(B, Cin, ldx, device="cuda")
+    xd[:, :, :L] = x.cuda()
+    # poison the padding beyond each utterance's length: the kernel must never read it
+    if lengths is not None:
+        for i, n in enumerate(lengths):
+            xd[i, :, int(n):] = float("nan")
+    Cout = w.shape[1] if transpose else w.shape[0]
+    Lo = L * stride
+    ldo = (Lo + 3) // 4 * 4
+    yd = torch.full((B, Cout, ldo), -7.0, device="cuda")
+    ld = None if lengths is None else torch.as_tensor(lengths, dtype=torch.int32).cuda()
+    wc, bc = w.contiguous(), b.contiguous()
+    if transpose:
+        rc = lib.dissc_conv_transpose1d(xd.data_ptr(), wc.data_ptr(), bc.data_ptr(), yd.data_ptr(),
+                                        None if ld is None else ld.data_ptr(), B, Cin, Cout, k, stride,
+                                        ldx, ldo, L, ctypes.c_float(slope), None)
+    else:
+        rc = lib.dissc_conv1d(xd.data_ptr(), wc.data_ptr(), bc.data_ptr(), yd.data_ptr(),
+                              None if ld is None else ld.data_ptr(), B, Cin, Cout, k, d, ldx, ldo, L,
+                              ctypes.c_float(slope), None)
+    _lib.check(rc, "conv")
+    torch.cuda.synchronize()
+    return yd.cpu()[:, :, :Lo]
+
+
+@pytest.mark.parametrize("C,k,d", [(16, 3, 1), (16, 11, 5), (32, 7, 3), (64, 11, 1), (128, 3, 5),
+                                   (256, 7, 1), (48, 5, 2), (20, 3, 1)])
+def test_conv1d_matches_torch(env, C, k, d):
+    rs = np.random.RandomState(C * 100 + k * 10 + d)
+    B, L = 3, 700
+    lengths = [700, 333, 1]
+    x = torch.from_numpy(rs.standard_normal((B, C, L)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(C).astype(np.float32))
+    y = _run_conv(env, x, w, b, lengths, k, d, 0.1)
+    for i, n in enumerate(lengths):
+        ref = F.conv1d(F.leaky_relu(x[i:i + 1, :, :n], 0.1), w, b, padding=(k - 1) * d // 2, dilation=d)
+        err = (y[i, :, :n] - ref[0]).abs().max().item()
+        assert err <= 2e-5, (i, err)
+        assert (y[i, :, n:] == -7.0).all()  # nothing written beyond the utterance
+
+
+def test_conv1d_rect_and_identity_slope(env):
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.standard_normal((2, 257, 130)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((512, 257, 7)) / 42.0).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(512).astype(np.float32))
+    y = _run_conv(env, x, w, b, None, 7, 1, 1.0)
+    ref = F.conv1d(x, w, b, padding=3)
+    assert (y - ref).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("cin,k,s", [(512, 11, 5), (256, 8, 4), (128, 8, 4), (64, 4, 2), (32, 4, 2)])
+def test_conv_transpose_matches_torch(env, cin, k, s):
+    rs = np.random.RandomState(cin + k)
+    B, L = 2, 150
+    lengths = [150, 37]
+    cout = cin // 2
+    x = torch.from_numpy(rs.standard_normal((B, cin, L)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((cin, cout, k)) / np.sqrt(cin * k / s)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(cout).astype(np.float32))
+    y = _run_conv(env, x, w, b, lengths, k, 1, 0.1, transpose=True, stride=s)
+    for i, n in enumerate(lengths):
+        ref = F.conv_transpose1d(F.leaky_relu(x[i:i + 1, :, :n], 0.1), w, b, stride=s, padding=(k - s) // 2)
+        assert ref.shape[-1] == n * s
+        err = (y[i, :, :n * s] - ref[0]).abs().max().item()
+        assert err <= 2e-5, (i, err)
+
+
+@pytest.mark.parametrize("T", [1, 2, 7, 33, 99])
+def test_generator_matches_reference_golden(env, golden_dir, T):
+    gold = np.load(os.path.join(golden_dir, "gen_vctk.npz"))
+    code, f0, spkr, _ = env["synth"].synth_generator_inputs(1, T, seed=100 + T)
+    y = env["g"](code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr))
+    torch.cuda.synchronize()
+    ref = gold[f"s0/T{T}/wav"]
+    assert tuple(y.shape) == ref.shape
+    err = y.cpu().numpy() - ref
+    # north_star tolerance: <= 1e-4 RMS vs the reference CPU path (and 1e-3 relative)
+    assert _rms(err) <= 1e-4, _rms(err)
+    assert _rms(err) <= 1e-3 * _rms(ref)
+    assert np.abs(err).max() <= 1e-3
+
+
+def test_generator_ragged_batch_matches_reference_golden(env, golden_dir):
+    gold = np.load(os.path.join(golden_dir, "gen_vctk.npz"))
+    code, f0, spkr, _ = env["synth"].synth_generator_inputs(4, 40, seed=777)
+    lengths = gold["s0/ragged/lengths"]
+    # poison inputs beyond each length
+    code2, f02 = code.copy(), f0.copy()
+    for b in range(4):
+        code2[b, lengths[b]:] = 99
+        f02[b, 0, lengths[b]:] = 1e9
+    y = env["g"](code=torch.from_numpy(code2), f0=torch.from_numpy(f02), spkr=torch.from_numpy(spkr),
+                 lengths=torch.from_numpy(lengths)).cpu().numpy()
+    for b in range(4):
+        n = int(lengths[b]) * 320
+        ref = gold[f"s0/ragged/wav{b}"][0]
+        assert _rms(y[b, :, :n] - ref) <= 1e-4
+        assert not y[b, :, n:].any()
+
+
+def test_generator_full_size_properties(env):
+    """BASELINE config: B=32 x T=500.  Oracle on 2 utterances + batch-independence
+    (an utterance's samples do not depend on what it is batched with)."""
+    g, gr, synth = env["g"], env["gr"], env["synth"]
+    code, f0, spkr, _ = synth.synth_generator_inputs(32, 500, seed=1234)
+    tc, tf, ts = torch.from_numpy(code), torch.from_numpy(f0), torch.from_numpy(spkr)
+    y = g(code=tc, f0=tf, spkr=ts).cpu()
+    assert tuple(y.shape) == (32, 1, 160000)
+    assert torch.isfinite(y).all() and y.abs().max() <= 1.0
+    for b in (0, 31):
+        ref = gr.code_generator(env["folded"], synth.VCTK_CONFIG, code[b:b + 1], f0[b:b + 1], spkr[b:b + 1])
+        e = (y[b:b + 1] - ref).numpy()
+        assert _rms(e) <= 1e-4 and _rms(e) <= 1e-3 * _rms(ref.numpy())
+    y1 = g(code=tc[7:8], f0=tf[7:8], spkr=ts[7:8]).cpu()
+    assert torch.equal(y1[0], y[7])
+    # determinism: same launch twice -> identical bits
+    y2 = g(code=tc, f0=tf, spkr=ts).cpu()
+    assert torch.equal(y, y2)
+
+
+def test_wav_postprocess_matches_oracle(env):
+    from dissc_amd.generator import wav_postprocess_
+    rs = np.random.RandomState(0)
+    y = np.tanh(rs.standard_normal((3, 1, 5000)).astype(np.float32) * 2)
+    y[0, 0, :4] = [1.0, -1.0, 0.99999, 3.5 / 32768]
+    n = np.array([5000, 1234, 1], dtype=np.int32)
+    d = torch.from_numpy(y.copy()).cuda()
+    wav_postprocess_(d, n)
+    out = d.cpu().numpy()
+    for b in range(3):
+        want = env["gr"].wav_postprocess(y[b, 0, :n[b]])
+        np.testing.assert_array_equal(out[b, 0, :n[b]], want)
+        np.testing.assert_array_equal(out[b, 0, n[b]:], y[b, 0, n[b]:])
