@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
 
 
-def cpu_baseline(synth, sd, code, f0, spkr, budget_s=12.0, max_utts=6):
+def cpu_baseline(synth, sd, code, f0, spkr, budget_s=12.0, max_utts=400):
     """The CPU oracle (kind='port': plain-PyTorch restatement pinned to the reference,
     tests/test_oracle_golden.py) timed the way the reference runs: B=1 per utterance,
     all host cores.  Bounded sample of the same workload."""
