@@ -67,6 +67,9 @@ def _load():
                                ctypes.c_float, vp]
     L.dissc_conv_transpose1d.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                                          ctypes.c_float, vp]
+    L.dissc_mfma_peak.argtypes = [i32, ctypes.POINTER(ctypes.c_float)]
+    L.dissc_set_option.argtypes = [ctypes.c_char_p, i32]
+    L.dissc_conv_bench.argtypes = [i32] * 9 + [ctypes.POINTER(ctypes.c_float)]
     L.dissc_wav_postprocess.argtypes = [vp, vp, i32, i32, vp]
     return L
 

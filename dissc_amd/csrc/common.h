@@ -59,10 +59,14 @@ struct ConvArgs {
   int up;               // 1 = conv; s = ConvTranspose stride (rows are co*s+p)
 };
 
+constexpr int MAX_TAP_SPAN = 60;  // (KS-1)*dil supported by the staging register budget
+
 // Pick a tile shape for M rows / Lmax columns and launch.  Returns a DISSC_* code.
 int launch_conv(const ConvArgs& a, int B, int Lmax, hipStream_t stream);
 // LDS row stride for a (KS, dil) conv with time tile BN.
 int conv_tile_bn(int M);
+int conv_cfg(int M);
+void conv_set_cfg(int bm_class, int cfg);  // tuning hook (dissc_conv_bench / dissc_set_option)
 int conv_xw(int M, int KS, int dil);
 
 // Host-side weight packing.  w: [Cout][Cin][KS] (Conv1d layout).  Returns the packed

@@ -5,25 +5,33 @@
 //
 // GEMM view: M = output rows (Cout, or Cout*stride for ConvTranspose), N = time,
 // K = Cin*KS.  One workgroup owns a BM x BN output tile of ONE utterance:
-//   - the input window [KC channels][BN + (KS-1)*dil] is staged through LDS once per
-//     16-channel chunk (coalesced along time, leaky-ReLU and the utterance's zero
-//     padding applied on the way in), and is shared by all waves / all taps;
+//   - the input window [16 channels][BN + (KS-1)*dil] of chunk c+1 is fetched with
+//     16-byte aligned loads into registers while chunk c is on the matrix pipe, then
+//     written (leaky-ReLU + the utterance's zero padding applied) to the other half of a
+//     double-buffered LDS tile: one barrier per chunk, HBM latency hidden behind MFMAs;
 //   - the weight (A) fragments are pre-packed on the host in exactly the MFMA lane
-//     order, so every wave streams them L2 -> VGPR with one coalesced dwordx4 per
-//     lane per (16 rows x 16 channels x 1 tap), prefetched one tap ahead;
+//     order, so every wave streams them L2 -> VGPR with one coalesced dwordx4 per lane
+//     per (16 rows x 16 channels x 1 tap), prefetched one tap ahead;
 //   - B fragments are ds_read_b32 (lanes 0-15 / 16-31 hit rows XW apart, XW%32==16
-//     => conflict free).
+//     => conflict free);
+//   - the epilogue transposes each wave's accumulators through a private LDS patch so
+//     bias/residual/MRF traffic is 16 B per lane in >=256 B runs per output row.
 // Replaces the MIOpen/cuDNN conv1d / conv_transpose1d calls behind reference
 // sr/models.py:34-41 (ResBlock1), :99-102 (conv_pre, ups).
 #include "common.h"
 
 namespace dissc {
 
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
 template <int MI, int NI, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BN = 16 * NI * WN;
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [KC][XW]
+  constexpr int XW_MAX = (BN + MAX_TAP_SPAN + 3 + 31) / 32 * 32 + 16;
+  constexpr int SV = (KC * (XW_MAX / 4) + NT - 1) / NT;  // float4 staging slots per thread
+  constexpr int CW = 16 * NI + 4;                        // epilogue patch row stride
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x [KC][XW] | NW x [16][CW]
 
   const int b = blockIdx.z;
   const int len = (a.lengths ? a.lengths[b] * a.len_mul : a.len_default);
@@ -36,10 +44,57 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvArgs 
   const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, g = lane >> 4;
   const int XW = a.XW;
+  const int NV = XW >> 2;
   const int halo = ((a.KS - 1) * a.dil) >> 1;
-  const int span = BN + (a.KS - 1) * a.dil;
+  const int tb = (t0 - halo) & ~3;   // 16-byte aligned window start (may be negative)
+  const int sh = t0 - halo - tb;     // 0..3
   const int nq = a.nchunk * a.KS;
   const int ms0 = blockIdx.y * (MI * WM) + wm * MI;
+  const float slope = a.slope;
+  const float* xb = a.x + (size_t)b * a.x_bstride;
+
+  // this thread's float4 staging slots: slot i = tid + i*NT -> (row r, vec v)
+  const int r0 = tid / NV, v0 = tid - r0 * NV;
+  const int dr = NT / NV, dv = NT - dr * NV;
+
+  // Staging: every slot issues an unconditional, in-bounds 16-byte load (addresses are
+  // clamped, never predicated, so nothing waits at the load site); zero padding, the
+  // ragged tail and leaky-ReLU are applied when the registers are written to LDS.
+  f32x4 sv[SV];
+  auto stage_load = [&](int c) {
+    int r = r0, v = v0;
+#pragma unroll
+    for (int i = 0; i < SV; ++i) {
+      int ci = c * KC + (r < KC ? r : KC - 1);
+      ci = ci < a.CIN ? ci : a.CIN - 1;
+      int t = tb + 4 * v;
+      t = t < 0 ? 0 : (t > a.ldx - 4 ? a.ldx - 4 : t);
+      sv[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)ci * a.ldx + t);
+      v += dv;
+      r += dr;
+      if (v >= NV) { v -= NV; ++r; }
+    }
+  };
+  auto stage_store = [&](float* buf, int c) {
+    int r = r0, v = v0;
+#pragma unroll
+    for (int i = 0; i < SV; ++i) {
+      if (r < KC) {
+        const int t = tb + 4 * v;
+        const bool rowok = (c * KC + r) < a.CIN;
+        f32x4 val = sv[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = rowok && (t + e) >= 0 && (t + e) < len;
+          val[e] = ok ? lrelu(val[e], slope) : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(buf + r * XW + 4 * v) = val;
+      }
+      v += dv;
+      r += dr;
+      if (v >= NV) { v -= NV; ++r; }
+    }
+  };
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -55,90 +110,140 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvArgs 
     av[mi] = wp[mi][0];
   }
 
-  const float* xb = a.x + (size_t)b * a.x_bstride;
-  const float slope = a.slope;
-  const float* bbase = xs + g * XW + wn * (16 * NI) + l15;
+  stage_load(0);
+  stage_store(xs, 0);
+  __syncthreads();
 
+#define DISSC_MFMA_STEP(CQ, BV)                                                              \
+  _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                          \
+  _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                          \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][CQ], BV[ni], acc[mi][ni], 0, 0, 0);
+
+  const int boff = g * XW + sh + wn * (16 * NI) + l15;
+  const int XW4 = 4 * XW;
   int q = 0;
   for (int c = 0; c < a.nchunk; ++c) {
-    __syncthreads();  // everyone is done reading the previous chunk
-    for (int r = wave; r < KC; r += NT / 64) {
-      const int ci = c * KC + r;
-      const bool crow = ci < a.CIN;
-      const float* row = xb + (size_t)ci * a.ldx;
-      float* dst = xs + r * XW;
-      for (int u = lane; u < span; u += 64) {
-        const int t = t0 - halo + u;
-        float v = 0.f;
-        if (crow && t >= 0 && t < len) {
-          v = row[t];
-          v = v > 0.f ? v : v * slope;
-        }
-        dst[u] = v;
-      }
-    }
-    __syncthreads();
-
+    const float* bj = xs + (c & 1) * (KC * XW) + boff;
+    const bool more = c + 1 < a.nchunk;
+    float b0[NI], b1[NI], b2[NI], b3[NI], b0n[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b0[ni] = bj[ni * 16];
     for (int j = 0; j < a.KS; ++j, ++q) {
       const int qn = (q + 1 < nq) ? q + 1 : q;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][(size_t)qn * 64];
-      const float* bj = bbase + j * a.dil;
+      if (j == 0 && more) stage_load(c + 1);  // in flight behind this chunk's MFMAs
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of the MFMAs
 #pragma unroll
-      for (int cq = 0; cq < 4; ++cq) {
-        float bv[NI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bv[ni] = bj[cq * 4 * XW + ni * 16];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][cq], bv[ni], acc[mi][ni], 0, 0, 0);
+      for (int ni = 0; ni < NI; ++ni) {
+        b1[ni] = bj[XW4 + ni * 16];
+        b2[ni] = bj[2 * XW4 + ni * 16];
+        b3[ni] = bj[3 * XW4 + ni * 16];
       }
+      DISSC_MFMA_STEP(0, b0)
+      bj += a.dil;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b0n[ni] = bj[ni * 16];  // next tap's first k-step
+      DISSC_MFMA_STEP(1, b1)
+      DISSC_MFMA_STEP(2, b2)
+      DISSC_MFMA_STEP(3, b3)
+      __builtin_amdgcn_sched_barrier(0);  // the register rotation below must not creep upwards
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b0[ni] = b0n[ni];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) av[mi] = avn[mi];
     }
+    if (more) stage_store(xs + ((c + 1) & 1) * (KC * XW), c + 1);
+    __syncthreads();
+  }
+#undef DISSC_MFMA_STEP
+
+  const int epi = a.epi;
+  const size_t ob = (size_t)b * a.o_bstride;
+  if (a.up != 1) {
+    // ConvTranspose pixel shuffle straight from registers: row = co*up + p -> out[co][t*up + p].
+    // C/D layout of 16x16x4: col = lane & 15 (time), row = 4*(lane>>4) + r.
+    const int tbase = t0 + wn * (16 * NI) + l15;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (ms0 + mi) * 16 + g * 4 + r;
+        if (row >= a.M) continue;
+        const float bz = a.bias[row];
+        const int co = row / a.up;
+        const int p = row - co * a.up;
+        const size_t rowoff = ob + (size_t)co * a.ldo + p;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int t = tbase + ni * 16;
+          if (t < len) a.out[rowoff + (size_t)t * a.up] = acc[mi][ni][r] + bz;
+        }
+      }
+    }
+    return;
   }
 
-  // Epilogue.  C/D layout of 16x16x4: col = lane & 15 (time), row = 4*(lane>>4) + r.
-  const int tbase = t0 + wn * (16 * NI) + l15;
-  const size_t boff = (size_t)b * a.o_bstride;
-  const int epi = a.epi;
+  // Transposed epilogue: registers -> wave-private LDS patch [16][CW] -> 16 B per lane.
+  float* ep = xs + wave * (16 * CW);
+  constexpr int LPR = 4 * NI;        // float4 lanes per output row
+  constexpr int RPP = 64 / LPR;      // rows per pass
+  const int prow = lane / LPR, pc4 = lane % LPR;
+  const int tcol = t0 + wn * (16 * NI) + 4 * pc4;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = (ms0 + mi) * 16 + g * 4 + r;
-      if (row >= a.M) continue;
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ep[(4 * g + r) * CW + ni * 16 + l15] = acc[mi][ni][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < NI; ++p) {
+      const int rl = p * RPP + prow;
+      const int row = (ms0 + mi) * 16 + rl;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * CW + 4 * pc4);
+      if (row >= a.M || tcol >= len) continue;
       const float bz = a.bias[row];
-      size_t rowoff;
-      int tmul = 1, tadd = 0;
-      if (a.up == 1) {
-        rowoff = boff + (size_t)row * a.ldo;
-      } else {
-        const int co = row / a.up;
-        tadd = row - co * a.up;
-        tmul = a.up;
-        rowoff = boff + (size_t)co * a.ldo;
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int t = tbase + ni * 16;
-        if (t >= len) continue;
-        const float v = acc[mi][ni][r] + bz;
-        const size_t idx = rowoff + (size_t)t * tmul + tadd;
+      v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
+      const size_t idx = ob + (size_t)row * a.ldo + tcol;
+      const int nv = len - tcol;  // >= 1
+      if (nv >= 4) {
         if (epi == EPI_STORE) {
-          a.out[idx] = v;
-        } else if (epi == EPI_RES) {
-          a.out[idx] = v + a.res[idx];
+          *reinterpret_cast<f32x4*>(a.out + idx) = v;
         } else {
-          const float rr = v + a.res[idx];
-          if (epi == EPI_MRF_SET) {
-            a.acc[idx] = rr;
-          } else if (epi == EPI_MRF_ADD) {
-            a.acc[idx] = a.acc[idx] + rr;
+          const f32x4 rs = *reinterpret_cast<const f32x4*>(a.res + idx);
+          v[0] += rs[0]; v[1] += rs[1]; v[2] += rs[2]; v[3] += rs[3];
+          if (epi == EPI_RES) {
+            *reinterpret_cast<f32x4*>(a.out + idx) = v;
+          } else if (epi == EPI_MRF_SET) {
+            *reinterpret_cast<f32x4*>(a.acc + idx) = v;
           } else {
-            a.acc[idx] = __fdiv_rn(a.acc[idx] + rr, a.mrf_div);
+            const f32x4 ac = *reinterpret_cast<const f32x4*>(a.acc + idx);
+            v[0] = ac[0] + v[0]; v[1] = ac[1] + v[1]; v[2] = ac[2] + v[2]; v[3] = ac[3] + v[3];
+            if (epi == EPI_MRF_DIV) {
+              v[0] = __fdiv_rn(v[0], a.mrf_div); v[1] = __fdiv_rn(v[1], a.mrf_div);
+              v[2] = __fdiv_rn(v[2], a.mrf_div); v[3] = __fdiv_rn(v[3], a.mrf_div);
+            }
+            *reinterpret_cast<f32x4*>(a.acc + idx) = v;
+          }
+        }
+      } else {
+        for (int e = 0; e < nv; ++e) {
+          float x = v[e];
+          if (epi == EPI_STORE) {
+            a.out[idx + e] = x;
+          } else {
+            x += a.res[idx + e];
+            if (epi == EPI_RES) {
+              a.out[idx + e] = x;
+            } else if (epi == EPI_MRF_SET) {
+              a.acc[idx + e] = x;
+            } else {
+              x = a.acc[idx + e] + x;
+              if (epi == EPI_MRF_DIV) x = __fdiv_rn(x, a.mrf_div);
+              a.acc[idx + e] = x;
+            }
           }
         }
       }
@@ -157,19 +262,45 @@ static int pick_bm(int M) {
   return 16;
 }
 
+// Tile shapes: wave tile = (16*MI) x (16*NI), WM x WN waves, BM = 16*MI*WM, BN = 16*NI*WN.
+struct TileCfg { int MI, NI, WM, WN; };
+static const TileCfg kCfgs[] = {
+    {4, 4, 4, 1},  // 0: 256 x 64
+    {4, 4, 2, 2},  // 1: 128 x 128
+    {4, 4, 1, 4},  // 2:  64 x 256
+    {2, 8, 1, 4},  // 3:  32 x 512
+    {1, 8, 1, 4},  // 4:  16 x 512
+    {2, 4, 1, 4},  // 5:  32 x 256
+    {1, 4, 1, 4},  // 6:  16 x 256
+    {2, 4, 2, 2},  // 7:  64 x 128
+    {2, 4, 4, 1},  // 8: 128 x 64
+    {4, 2, 4, 2},  // 9: 256 x 64, 8 waves
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+static int g_cfg_for_bm[5] = {6, 5, 7, 1, 0};  // index log2(BM/16) -> cfg id (tunable)
+
+void conv_set_cfg(int bm_class, int cfg) {
+  if (bm_class >= 0 && bm_class < 5 && cfg >= 0 && cfg < kNumCfgs) g_cfg_for_bm[bm_class] = cfg;
+}
+
+int conv_cfg(int M) {
+  const int bm = pick_bm(M);
+  int cls = 0;
+  while ((16 << cls) < bm) ++cls;
+  int cfg = g_cfg_for_bm[cls];
+  if (16 * kCfgs[cfg].MI * kCfgs[cfg].WM > bm) cfg = 4 - cls;  // override must divide the padded M
+  return cfg;
+}
+
 int conv_tile_bn(int M) {
-  switch (pick_bm(M)) {
-    case 256: return 64;
-    case 128: return 128;
-    case 64: return 256;
-    default: return 512;
-  }
+  const TileCfg& c = kCfgs[conv_cfg(M)];
+  return 16 * c.NI * c.WN;
 }
 
 int conv_xw(int M, int KS, int dil) {
-  const int span = conv_tile_bn(M) + (KS - 1) * dil;
-  int xw = (span + 31) / 32 * 32 + 16;
-  if (xw - 32 >= span) xw -= 32;
+  const int need = conv_tile_bn(M) + (KS - 1) * dil + 3;  // +3: 16-byte aligned window start
+  int xw = (need + 31) / 32 * 32 + 16;
+  if (xw - 32 >= need) xw -= 32;
   return xw;
 }
 
@@ -209,18 +340,19 @@ void convT_to_conv(const float* w, int Cin, int Cout, int k, int s, std::vector<
 
 template <int MI, int NI, int WM, int WN>
 static int launch_t(const ConvArgs& a, int B, int Lmax, hipStream_t stream) {
-  constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN;
+  constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, NW = WM * WN;
+  constexpr int CW = 16 * NI + 4;
   const int Mpad = (a.M + BM - 1) / BM * BM;
   dim3 grid((Lmax + BN - 1) / BN, Mpad / BM, B);
-  const size_t lds = (size_t)KC * a.XW * sizeof(float);
-  if (lds > 65536) {
-    static bool done = false;
-    if (!done) {
-      DISSC_HIP_CHECK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&conv_mfma_kernel<MI, NI, WM, WN>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      done = true;
-    }
+  size_t lds_f = (size_t)2 * KC * a.XW;
+  if (lds_f < (size_t)NW * 16 * CW) lds_f = (size_t)NW * 16 * CW;
+  const size_t lds = lds_f * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    DISSC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv_mfma_kernel<MI, NI, WM, WN>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
   }
   hipLaunchKernelGGL((conv_mfma_kernel<MI, NI, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
@@ -233,12 +365,27 @@ int launch_conv(const ConvArgs& a, int B, int Lmax, hipStream_t stream) {
     set_error("launch_conv: batch %d exceeds grid.z limit", B);
     return DISSC_EINVAL;
   }
-  switch (pick_bm(a.M)) {
-    case 256: return launch_t<4, 4, 4, 1>(a, B, Lmax, stream);
-    case 128: return launch_t<4, 4, 2, 2>(a, B, Lmax, stream);
-    case 64: return launch_t<4, 4, 1, 4>(a, B, Lmax, stream);
-    case 32: return launch_t<2, 8, 1, 4>(a, B, Lmax, stream);
-    default: return launch_t<1, 8, 1, 4>(a, B, Lmax, stream);
+  if ((a.KS - 1) * a.dil > MAX_TAP_SPAN || (a.KS & 1) == 0) {
+    set_error("launch_conv: kernel %d x dilation %d unsupported (odd k, (k-1)*d <= %d)", a.KS, a.dil,
+              MAX_TAP_SPAN);
+    return DISSC_EINVAL;
+  }
+  if ((a.ldx & 3) || (a.ldo & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.out & 15 && a.out) ||
+      ((uintptr_t)a.res & 15) || ((uintptr_t)a.acc & 15)) {
+    set_error("launch_conv: activations must be 16-byte aligned with row strides %% 4 == 0");
+    return DISSC_EINVAL;
+  }
+  switch (conv_cfg(a.M)) {
+    case 0: return launch_t<4, 4, 4, 1>(a, B, Lmax, stream);
+    case 1: return launch_t<4, 4, 2, 2>(a, B, Lmax, stream);
+    case 2: return launch_t<4, 4, 1, 4>(a, B, Lmax, stream);
+    case 3: return launch_t<2, 8, 1, 4>(a, B, Lmax, stream);
+    case 4: return launch_t<1, 8, 1, 4>(a, B, Lmax, stream);
+    case 5: return launch_t<2, 4, 1, 4>(a, B, Lmax, stream);
+    case 6: return launch_t<1, 4, 1, 4>(a, B, Lmax, stream);
+    case 7: return launch_t<2, 4, 2, 2>(a, B, Lmax, stream);
+    case 8: return launch_t<2, 4, 4, 1>(a, B, Lmax, stream);
+    default: return launch_t<4, 2, 4, 2>(a, B, Lmax, stream);
   }
 }
 

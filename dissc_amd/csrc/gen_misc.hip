@@ -131,3 +131,45 @@ void launch_wav_postprocess(float* wav, const int32_t* n_samples, int B, int ld,
 }
 
 }  // namespace dissc
+
+// ---- diagnostics: sustained fp32 MFMA rate of this GPU at its real clocks -------------
+namespace dissc {
+__global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters) {
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f + 1.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678f) out[0] = s;
+}
+}  // namespace dissc
+
+extern "C" int dissc_mfma_peak(int iters, float* tflops) {
+  using namespace dissc;
+  if (!tflops || iters <= 0) return DISSC_EINVAL;
+  float* d = nullptr;
+  DISSC_HIP_CHECK(hipMalloc((void**)&d, 16));
+  hipEvent_t e0, e1;
+  DISSC_HIP_CHECK(hipEventCreate(&e0));
+  DISSC_HIP_CHECK(hipEventCreate(&e1));
+  const int blocks = 256 * 4;  // 4 blocks x 4 waves per CU
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, d, 100);
+  DISSC_HIP_CHECK(hipEventRecord(e0, nullptr));
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, d, iters);
+  DISSC_HIP_CHECK(hipEventRecord(e1, nullptr));
+  DISSC_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  DISSC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = 2.0 * 16 * 16 * 4 * 8.0 * iters * 4.0 * blocks;  // per MFMA x 8 x iters x waves
+  *tflops = (float)(flops / (ms * 1e-3) / 1e12);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(d);
+  return DISSC_OK;
+}

@@ -10,6 +10,7 @@
 // Activations are channels-first [B][C][ld] fp32 (time contiguous => coalesced tile
 // loads and MFMA-row stores), ld = stage length rounded up to 4.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -418,6 +419,74 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
   int rc = make_convT(w_host, bias_host, Cin, Cout, k, stride, dc);
   if (rc) return rc;
   return conv_once(dc, x, y, lengths, B, ldx, ldo, Lmax, in_slope, (hipStream_t)stream);
+}
+
+int dissc_set_option(const char* key, int value) {
+  if (!key) return DISSC_EINVAL;
+  if (strncmp(key, "conv_cfg_bm", 11) == 0) {  // "conv_cfg_bm16|32|64|128|256" -> tile config id
+    const int bm = atoi(key + 11);
+    int cls = 0;
+    while ((16 << cls) < bm) ++cls;
+    conv_set_cfg(cls, value);
+    return DISSC_OK;
+  }
+  set_error("dissc_set_option: unknown key %s", key);
+  return DISSC_EINVAL;
+}
+
+// Diagnostics: average ms of `iters` launches of one conv layer on synthetic data.
+int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int epi, int iters,
+                     int flags, float* ms_out) {
+  if (!ms_out || B <= 0 || L <= 0 || iters <= 0) {
+    set_error("dissc_conv_bench: bad argument");
+    return DISSC_EINVAL;
+  }
+  std::vector<float> w((size_t)Cout * Cin * k), bias(Cout, 0.1f);
+  uint32_t s = 12345u;
+  for (auto& v : w) {
+    s = s * 1664525u + 1013904223u;
+    v = ((s >> 8) / 16777216.0f - 0.5f) * 0.05f;
+  }
+  DevConv dc;
+  int rc = make_conv(w.data(), bias.data(), Cout, Cin, k, dilation, dc);
+  if (rc) return rc;
+  const int ld = (L + 3) / 4 * 4;
+  const size_t nx = (size_t)B * Cin * ld, no = (size_t)B * Cout * ld;
+  float *x = nullptr, *y = nullptr, *r = nullptr, *a = nullptr;
+  std::vector<float> hx(nx);
+  for (auto& v : hx) {
+    s = s * 1664525u + 1013904223u;
+    v = ((s >> 8) / 16777216.0f - 0.5f) * 2.f;
+  }
+  DISSC_HIP_CHECK(hipMalloc((void**)&x, nx * 4));
+  DISSC_HIP_CHECK(hipMalloc((void**)&y, no * 4));
+  DISSC_HIP_CHECK(hipMalloc((void**)&r, no * 4));
+  DISSC_HIP_CHECK(hipMalloc((void**)&a, no * 4));
+  DISSC_HIP_CHECK(hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice));
+  DISSC_HIP_CHECK(hipMemset(r, 0, no * 4));
+  DISSC_HIP_CHECK(hipMemset(a, 0, no * 4));
+  hipEvent_t e0, e1;
+  DISSC_HIP_CHECK(hipEventCreate(&e0));
+  DISSC_HIP_CHECK(hipEventCreate(&e1));
+  const int saved_cls = (flags >> 16) & 0xf;
+  if (flags & 0x8000) conv_set_cfg(saved_cls, (flags >> 8) & 0x3f);
+  for (int it = 0; it < 2 && !rc; ++it)
+    rc = run_conv(dc, x, y, r, a, nullptr, L, 1, B, Cin, ld, ld, L, 0.1f, epi, 3.f, nullptr);
+  DISSC_HIP_CHECK(hipEventRecord(e0, nullptr));
+  for (int it = 0; it < iters && !rc; ++it)
+    rc = run_conv(dc, x, y, r, a, nullptr, L, 1, B, Cin, ld, ld, L, 0.1f, epi, 3.f, nullptr);
+  DISSC_HIP_CHECK(hipEventRecord(e1, nullptr));
+  hipError_t e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(x); (void)hipFree(y); (void)hipFree(r); (void)hipFree(a);
+  free_conv(dc);
+  if (rc) return rc;
+  DISSC_HIP_CHECK(e);
+  return DISSC_OK;
 }
 
 }  // extern "C"

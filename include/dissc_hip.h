@@ -115,6 +115,21 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
                            const int32_t* lengths, int B, int Cin, int Cout, int k, int stride,
                            int ldx, int ldo, int Lmax, float in_slope, void* stream);
 
+/* Tuning hook: "conv_cfg_bm{16,32,64,128,256}" = tile-shape id used for convs whose GEMM
+ * M falls in that class (see kCfgs in conv_mfma.hip).  Process-wide; set before create. */
+int dissc_set_option(const char* key, int value);
+
+/* Diagnostics (not on the product path): average milliseconds of `iters` launches of
+ * one Conv1d layer shape on synthetic device data; `epi` 0 plain, 1 +residual,
+ * 2..4 MRF accumulate modes; `flags` = 0x8000 | cfg<<8 | bm_class<<16 overrides the
+ * tile shape for this process (0 = keep). */
+int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int epi, int iters,
+                     int flags, float* ms_out);
+
+/* Diagnostics: sustained fp32 v_mfma_f32_16x16x4_f32 rate (TFLOP/s) of this GPU at its
+ * real clocks -- the practical ceiling the conv kernels are compared with. */
+int dissc_mfma_peak(int iters, float* tflops);
+
 /* ------------------------------------------------------------------------- *
  * Waveform post-processing.
  * Replaces: generate(), reference sr/inference.py:73-75 ((y*32768).astype(int16),
