@@ -57,6 +57,17 @@ def cpu_baseline(synth, sd, code, f0, spkr, budget_s=12.0, max_utts=400):
                       f"{threads} threads (best of a probe; {avail} logical CPUs available), {dt:.1f} s wall"}
 
 
+def hbm_traffic(B, T):
+    """HBM bytes per step from the committed PMC capture (profiles/r01/hbm_traffic.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950
+    correction applied); only valid for the shape it was captured on."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")))
+        return j["bytes_per_step_B32_T500"] if (B, T) == (32, 500) else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,7 +160,7 @@ def main():
                        "collective": "1 all_gather of waveforms per step" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None,
+                         "traffic": hbm_traffic(B, T),
                          "kernel": "conv_mfma_kernel (all generator convs; fp32 v_mfma_f32_16x16x4)",
                          "flops_per_step": flops_step, "kernel_ms_per_step": round(kern_s * 1e3, 3)},
         }
