@@ -113,3 +113,89 @@ def synth_generator_inputs(B, T, seed=1234, ragged=False, n_spk=108, n_codes=100
     else:
         lengths = np.full(B, T, dtype=np.int32)
     return code, f0, spkr, lengths
+
+
+# ----------------------------------------------------------------------------------------------
+# predictors (reference model/len_predictor.py, model/pitch_predictor.py)
+# ----------------------------------------------------------------------------------------------
+def _conv(rs, sd, name, cout, cin, k, gain=1.4):
+    sd[name + ".weight"] = _t(rs.standard_normal((cout, cin, k)) * gain / np.sqrt(cin * k))
+    sd[name + ".bias"] = _t(0.1 * rs.standard_normal(cout))
+
+
+def _bn(rs, sd, name, c=128):
+    sd[name + ".weight"] = _t(1.0 + 0.2 * rs.standard_normal(c))
+    sd[name + ".bias"] = _t(0.1 * rs.standard_normal(c))
+    sd[name + ".running_mean"] = _t(0.2 * rs.standard_normal(c))
+    sd[name + ".running_var"] = _t(0.5 + rs.rand(c))
+    sd[name + ".num_batches_tracked"] = torch.tensor(1000, dtype=torch.int64)
+
+
+def synth_len_state_dict(n_tokens=100, n_speakers=108, seed=1):
+    """53 keys: token_emb, spk_emb, cnn1/bn1, cnn11..16/bn11..16, cnn2."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    sd["token_emb.weight"] = _t(rs.standard_normal((n_tokens + 1, 32)))
+    sd["spk_emb.weight"] = _t(rs.standard_normal((n_speakers, 32)))
+    _conv(rs, sd, "cnn1", 128, 64, 3)
+    _bn(rs, sd, "bn1")
+    for i in range(1, 7):
+        _conv(rs, sd, f"cnn1{i}", 128, 128, 3)
+        _bn(rs, sd, f"bn1{i}")
+    _conv(rs, sd, "cnn2", 1, 128, 3, gain=0.12)  # lens ~ 2.6 +- 0.5 for any seed / speaker count
+    return sd
+
+
+def synth_len_norm_stats():
+    """len_norm_stats.pth = (mean, std) tensors (reference train_len_predictor.py:32)."""
+    return torch.tensor(2.6), torch.tensor(1.7)
+
+
+def synth_pitch_state_dict(kind="new", n_tokens=100, n_speakers=108, seed=2):
+    """'new': 34 keys incl. buffer pe.pe [1,850,32]; 'base': 78 keys (BN after every conv but cnn2)."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    sd["token_emb.weight"] = _t(rs.standard_normal((n_tokens + 1, 32)))
+    sd["spk_emb.weight"] = _t(rs.standard_normal((n_speakers + 1, 32)))
+    if kind == "new":
+        lin = torch.linspace(0, 1, 850).unsqueeze(-1)
+        sd["pe.pe"] = torch.cat([lin.repeat_interleave(16, -1), torch.linspace(1, 0, 850).unsqueeze(-1)
+                                 .repeat_interleave(16, -1)], -1).unsqueeze(0)
+    names = ["cnn1"] + [f"cnn1{i}" for i in range(1, 8)]
+    for n in names:
+        _conv(rs, sd, n, 128, 64 if n == "cnn1" else 128, 3)
+        if kind == "base":
+            _bn(rs, sd, "bn" + n[3:])
+    if kind == "new":
+        _bn(rs, sd, "bn2")
+    _conv(rs, sd, "cnn2", 128, 128, 3)
+    _conv(rs, sd, "cnn_class1", 128, 128, 3)
+    if kind == "base":
+        _bn(rs, sd, "bn_c1")
+    _conv(rs, sd, "cnn_class2", 1, 128, 1, gain=1.0)
+    _conv(rs, sd, "cnn_reg1", 128, 128, 3)
+    if kind == "base":
+        _bn(rs, sd, "bn_r1")
+    _conv(rs, sd, "cnn_reg2", 1, 128, 1, gain=1.0)
+    return sd
+
+
+def synth_unit_sequences(n, T_lo=60, T_hi=500, seed=99, n_codes=100):
+    """Random unit sequences with geometric run lengths (mean 2.5), like encode output."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        T = int(rs.randint(T_lo, T_hi + 1))
+        seq = np.zeros(T, dtype=np.int64)
+        t = 0
+        prev = -1
+        while t < T:
+            run = rs.geometric(1 / 2.5)
+            c = int(rs.randint(0, n_codes))
+            if c == prev:
+                c = (c + 1) % n_codes
+            seq[t:t + run] = c
+            prev = c
+            t += run
+        out.append(seq)
+    return out

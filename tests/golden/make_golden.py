@@ -90,7 +90,115 @@ def make_generator():
     print("gen_vctk.npz", len(out), "arrays")
 
 
+def _import_ref_root():
+    """reference infer.py imports root utils.py -> `from tensorflow import summary`
+    (reference utils.py:2); tensorflow is not installed, a stub module is enough."""
+    tf = types.ModuleType("tensorflow")
+    tf.summary = None
+    sys.modules.setdefault("tensorflow", tf)
+    for m in ("utils", "models", "dataset"):
+        sys.modules.pop(m, None)  # sr/utils.py may be cached under the same name
+    if os.path.join(REF, "sr") in sys.path:
+        sys.path.remove(os.path.join(REF, "sr"))
+    sys.path.insert(0, REF)
+    import argparse
+    import infer as ref_infer
+    from model.len_predictor import LenPredictor
+    from model.pitch_predictor import PitchPredictor, PitchPredictorBase
+    ref_infer.args = argparse.Namespace(n_tokens=100)
+    return ref_infer, LenPredictor, PitchPredictor, PitchPredictorBase
+
+
+def make_predictors():
+    import json as _json
+    import tempfile
+    ref_infer, LenPredictor, PitchPredictor, PitchPredictorBase = _import_ref_root()
+    out = {}
+    n_spk = 108
+    len_sd = synth.synth_len_state_dict(100, n_spk)
+    mean, std = synth.synth_len_norm_stats()
+    lm = LenPredictor(n_tokens=100, n_speakers=n_spk)
+    lm.load_state_dict(len_sd, strict=True)
+    lm.eval()
+    lm.norm_mean, lm.norm_std = mean, std
+    rs = np.random.RandomState(7)
+    id2mean = torch.from_numpy((150 + 60 * rs.rand(n_spk)).astype(np.float32))
+    id2std = torch.from_numpy((20 + 20 * rs.rand(n_spk)).astype(np.float32))
+    out["id2pitch_mean"], out["id2pitch_std"] = id2mean.numpy(), id2std.numpy()
+    pms = {}
+    for kind, cls in (("new", PitchPredictor), ("base", PitchPredictorBase)):
+        pm = cls(100, n_spk, id2pitch_mean=id2mean, id2pitch_std=id2std)
+        pm.load_state_dict(synth.synth_pitch_state_dict(kind, 100, n_spk), strict=True)
+        pm.eval()
+        pms[kind] = pm
+    seqs = synth.synth_unit_sequences(6, 8, 420, seed=99) + [np.array([5], dtype=np.int64),
+                                                             np.array([3, 3, 3, 9], dtype=np.int64)]
+    spks = [0, 17, 107, 3, 55, 9, 1, 2]
+    out["n_seqs"] = np.array(len(seqs))
+    with torch.no_grad():
+        for i, (seq, spk) in enumerate(zip(seqs, spks)):
+            out[f"seq{i}"] = seq
+            out[f"spk{i}"] = np.array(spk)
+            vals, counts = ref_infer.dedup_seq(seq)
+            out[f"dd_vals{i}"], out[f"dd_counts{i}"] = np.array(vals), np.array(counts)
+            dd = torch.tensor(vals).unsqueeze(0)
+            spk_id = torch.tensor([[spk]])
+            lens = lm(dd, spk_id)
+            out[f"lens{i}"] = lens.numpy()
+            fixed = ref_infer.len_carryover_correction(lens)
+            out[f"lens_int{i}"] = fixed.numpy().astype(np.int64)
+            exp = torch.repeat_interleave(dd, fixed).view(1, -1)
+            out[f"expanded{i}"] = exp.numpy()
+            for kind, pm in pms.items():
+                if (exp.shape[-1] > 850 and kind == "new") or exp.shape[-1] == 0:
+                    continue  # the reference itself crashes on an empty expansion / > 850 frames
+                out[f"f0_{kind}_norm{i}"] = pm.infer_freq(exp, spk_id, True).numpy()
+                out[f"f0_{kind}_hz{i}"] = pm.infer_freq(exp, spk_id, False).numpy()
+        # direct carry-over vectors incl. .5 ties and values < 1
+        for j, v in enumerate([[0.2, 0.49, 2.5, 3.5, 1.5, 0.5, 7.99, 1.01, 4.5, 2.49999],
+                               [1.4] * 7 + [2.6] * 5 + [0.1] * 9, [1.0], [3.3, 3.3, 3.4, 0.0, -2.0, 9.7]]):
+            t = torch.tensor([v], dtype=torch.float32)
+            out[f"carry_in{j}"] = t.numpy()
+            out[f"carry_out{j}"] = ref_infer.len_carryover_correction(t).numpy().astype(np.int64)
+    # end-to-end reference infer_wild() on a JSONL manifest -> output JSONL (units exact, f0 floats)
+    import pickle
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(f"{td}/len"); os.makedirs(f"{td}/pitch"); os.makedirs(f"{td}/out")
+        torch.save(len_sd, f"{td}/len/best_model.pth")
+        torch.save((mean, std), f"{td}/len/len_norm_stats.pth")
+        torch.save(synth.synth_pitch_state_dict("base", 100, 10), f"{td}/pitch/best_model.pth")
+        spk_names = pickle.load(open(os.path.join(REF, "data/ESD/hubert100/id_to_spkr.pkl"), "rb"))
+        f0_stats = os.path.join(REF, "data/ESD/hubert100/f0_stats.pkl")
+        len_sd10 = synth.synth_len_state_dict(100, 10)
+        torch.save(len_sd10, f"{td}/len/best_model.pth")
+        man = f"{td}/wild.txt"
+        wild = synth.synth_unit_sequences(3, 30, 200, seed=5)
+        with open(man, "w") as f:
+            for i, s in enumerate(wild):
+                f.write(_json.dumps({"units": s.tolist(), "f0": [0.0] * len(s), "audio": f"s1_{i}.wav"}) + "\n")
+        import argparse
+        a = argparse.Namespace(input_path=man, out_path=f"{td}/out", len_model=f"{td}/len/",
+                               f0_model=f"{td}/pitch/", f0_model_type="base", n_tokens=100, device="cpu",
+                               f0_path=f0_stats, norm_pitch=True, target_speakers=[spk_names[2], spk_names[7]],
+                               id_to_spkr=os.path.join(REF, "data/ESD/hubert100/id_to_spkr.pkl"))
+        ref_infer.args = a
+        ref_infer.infer_wild(man, "cpu", a)
+        for t in a.target_speakers:
+            lines = open(f"{td}/out/{t}_wild.txt").read().strip().split("\n")
+            for i, ln in enumerate(lines):
+                d = _json.loads(ln)
+                out[f"wild/{t}/{i}/units"] = np.array(d["units"], dtype=np.int64)
+                out[f"wild/{t}/{i}/f0"] = np.array(d["f0"], dtype=np.float64)
+        out["wild/targets"] = np.array(a.target_speakers)
+        for i, s in enumerate(wild):
+            out[f"wild/in{i}"] = s
+    np.savez_compressed(os.path.join(HERE, "pred.npz"), **out)
+    print("pred.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["generator"]
+    which = sys.argv[1:] or ["generator", "predictors"]
     if "generator" in which:
         make_generator()
+    if "predictors" in which:
+        make_predictors()

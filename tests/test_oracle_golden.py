@@ -80,3 +80,67 @@ def test_wav_postprocess_truncates_and_wraps():
     want = i16.astype(np.float32) / np.abs(i16.astype(np.float32)).max()
     np.testing.assert_array_equal(gr.wav_postprocess(y), want)
     assert gr.wav_postprocess(np.zeros(5, np.float32)).tolist() == [0.0] * 5
+
+
+# ------------------------------------------------------------------------------------------
+# predictors + infer.py sample logic (golden: tests/golden/pred.npz, made by running the
+# reference's model/*.py and infer.py)
+# ------------------------------------------------------------------------------------------
+from oracle import predictors_ref as pr  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def pgold(golden_dir):
+    return np.load(os.path.join(golden_dir, "pred.npz"))
+
+
+def test_predictor_state_dict_layouts():
+    assert len(synth.synth_len_state_dict()) == 53
+    assert len(synth.synth_pitch_state_dict("new")) == 34
+    assert len(synth.synth_pitch_state_dict("base")) == 78
+
+
+def test_dedup_and_carryover_match_reference(pgold):
+    for i in range(int(pgold["n_seqs"])):
+        vals, counts = pr.dedup_seq(pgold[f"seq{i}"])
+        np.testing.assert_array_equal(vals, pgold[f"dd_vals{i}"])
+        np.testing.assert_array_equal(counts, pgold[f"dd_counts{i}"])
+        got = pr.len_carryover_correction(torch.from_numpy(pgold[f"lens{i}"]))
+        np.testing.assert_array_equal(got.numpy(), pgold[f"lens_int{i}"])
+    for j in range(4):
+        got = pr.len_carryover_correction(torch.from_numpy(pgold[f"carry_in{j}"]))
+        np.testing.assert_array_equal(got.numpy(), pgold[f"carry_out{j}"])
+
+
+def test_len_and_pitch_predictors_match_reference(pgold):
+    len_sd = synth.synth_len_state_dict(100, 108)
+    mean, std = synth.synth_len_norm_stats()
+    id2m, id2s = torch.from_numpy(pgold["id2pitch_mean"]), torch.from_numpy(pgold["id2pitch_std"])
+    for i in range(int(pgold["n_seqs"])):
+        spk = torch.tensor([[int(pgold[f"spk{i}"])]])
+        dd = torch.from_numpy(pgold[f"dd_vals{i}"]).unsqueeze(0)
+        lens = pr.len_predictor(len_sd, dd, spk, mean, std)
+        assert np.abs(lens.numpy() - pgold[f"lens{i}"]).max() <= 1e-6
+        exp = torch.from_numpy(pgold[f"expanded{i}"])
+        for kind in ("new", "base"):
+            sd = synth.synth_pitch_state_dict(kind, 100, 108)
+            f_n = pr.pitch_predictor(sd, exp, spk, kind, True)
+            f_h = pr.pitch_predictor(sd, exp, spk, kind, False, id2m, id2s)
+            assert np.abs(f_n.numpy() - pgold[f"f0_{kind}_norm{i}"]).max() <= 1e-6
+            assert np.abs(f_h.numpy() - pgold[f"f0_{kind}_hz{i}"]).max() <= 1e-4
+            # unvoiced frames are exactly zero
+            assert ((f_n.numpy() == 0) == (pgold[f"f0_{kind}_norm{i}"] == 0)).all()
+
+
+def test_infer_sample_matches_reference_infer_wild(pgold):
+    len_sd = synth.synth_len_state_dict(100, 10)
+    pitch_sd = synth.synth_pitch_state_dict("base", 100, 10)
+    stats = synth.synth_len_norm_stats()
+    import pickle
+    spk_names = pickle.load(open(os.path.join(os.path.dirname(__file__), "golden", "esd_id_to_spkr.pkl"), "rb"))
+    for t in pgold["wild/targets"]:
+        spk = spk_names.index(str(t))
+        for i in range(3):
+            units, f0 = pr.infer_sample(pgold[f"wild/in{i}"], spk, len_sd, stats, pitch_sd, "base", True)
+            np.testing.assert_array_equal(units, pgold[f"wild/{t}/{i}/units"])
+            assert np.abs(np.array(f0) - pgold[f"wild/{t}/{i}/f0"]).max() <= 1e-6
