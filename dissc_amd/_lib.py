@@ -67,6 +67,18 @@ def _load():
                                ctypes.c_float, vp]
     L.dissc_conv_transpose1d.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                                          ctypes.c_float, vp]
+    L.dissc_pred_create.argtypes = [i32, ctypes.POINTER(DisscTensor), ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.dissc_pred_destroy.argtypes = [vp]
+    L.dissc_pred_destroy.restype = None
+    L.dissc_pred_workspace_bytes.argtypes = [vp, i32, i32]
+    L.dissc_pred_workspace_bytes.restype = ctypes.c_size_t
+    L.dissc_len_set_norm.argtypes = [vp, ctypes.c_float, ctypes.c_float]
+    L.dissc_len_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, vp, ctypes.c_size_t, vp]
+    L.dissc_pitch_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp,
+                                      ctypes.c_size_t, vp]
+    L.dissc_dedup.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
+    L.dissc_len_carryover.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.dissc_expand.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp]
     L.dissc_mfma_peak.argtypes = [i32, ctypes.POINTER(ctypes.c_float)]
     L.dissc_set_option.argtypes = [ctypes.c_char_p, i32]
     L.dissc_conv_bench.argtypes = [i32] * 9 + [ctypes.POINTER(ctypes.c_float)]

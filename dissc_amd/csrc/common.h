@@ -43,6 +43,8 @@ struct ConvArgs {
   const float* x;       // [B][CIN][ldx]
   const float* wpack;   // packed A fragments, see pack_conv_weights()
   const float* bias;    // [Mpad] one per GEMM row
+  const float* scale;   // [Mpad] optional per-row affine after bias (nullptr = none)
+  const float* shift;
   const float* res;     // residual, same layout as out (EPI_RES / EPI_MRF_*)
   float* out;           // [B][M/up][ldo]
   float* acc;           // MRF accumulator (EPI_MRF_*), same layout as out
@@ -76,6 +78,24 @@ void pack_conv_weights(const float* w, int Cout, int Cin, int KS, std::vector<fl
 // ConvTranspose1d [Cin][Cout][k], stride s, padding (k-s)/2  ->  3-tap conv with
 // M = Cout*s rows (row = co*s + p), taps delta = -1,0,+1.
 void convT_to_conv(const float* w, int Cin, int Cout, int k, int s, std::vector<float>& w3);
+
+// Device-resident conv layer (conv_host.hip).
+struct DevConv {
+  float* wpack = nullptr;
+  float* bias = nullptr;
+  float* scale = nullptr;  // optional per-row affine applied after bias: v*scale + shift
+  float* shift = nullptr;  // (eval-mode BatchNorm1d / label de-normalisation)
+  int CIN = 0, M = 0, KS = 0, dil = 1, nchunk = 0, up = 1;
+  double macs_per_t = 0;  // MACs per input time step (algorithmic, zero taps excluded)
+};
+int upload(const std::vector<float>& h, float** d);
+int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int dil, DevConv& dc);
+int make_convT(const float* w, const float* bias, int Cin, int Cout, int k, int s, DevConv& dc);
+int set_affine(DevConv& dc, const float* scale, const float* shift, int n);  // host pointers
+void free_conv(DevConv& dc);
+int run_conv(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
+             const int32_t* lengths, int len_default, int len_mul, int B, int C_x, int ldx, int ldo,
+             int Lmax, float slope, int epi, float mrf_div, hipStream_t stream);
 
 // misc kernels (gen_misc.hip)
 void launch_embed_concat(const int64_t* code, const float* f0, const int64_t* spkr,

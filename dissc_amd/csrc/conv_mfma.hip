@@ -206,6 +206,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
       if (row >= a.M || tcol >= len) continue;
       const float bz = a.bias[row];
       v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
+      if (a.scale) {  // eval-mode BatchNorm1d as PyTorch evaluates it: x * alpha + beta
+        const float sc = a.scale[row], sf = a.shift[row];
+        v[0] = v[0] * sc + sf; v[1] = v[1] * sc + sf; v[2] = v[2] * sc + sf; v[3] = v[3] * sc + sf;
+      }
       const size_t idx = ob + (size_t)row * a.ldo + tcol;
       const int nv = len - tcol;  // >= 1
       if (nv >= 4) {

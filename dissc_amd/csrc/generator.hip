@@ -27,52 +27,6 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-struct DevConv {
-  float* wpack = nullptr;
-  float* bias = nullptr;
-  int CIN = 0, M = 0, KS = 0, dil = 1, nchunk = 0, up = 1;
-  double macs_per_t = 0;  // MACs per input time step (algorithmic, zero taps excluded)
-};
-
-static int upload(const std::vector<float>& h, float** d) {
-  DISSC_HIP_CHECK(hipMalloc((void**)d, h.size() * sizeof(float)));
-  DISSC_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-  return DISSC_OK;
-}
-
-static int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int dil,
-                     DevConv& dc) {
-  std::vector<float> packed;
-  int Mpad, nchunk;
-  pack_conv_weights(w, Cout, Cin, KS, packed, Mpad, nchunk);
-  std::vector<float> b(Mpad, 0.f);
-  if (bias) memcpy(b.data(), bias, Cout * sizeof(float));
-  dc.CIN = Cin; dc.M = Cout; dc.KS = KS; dc.dil = dil; dc.nchunk = nchunk; dc.up = 1;
-  dc.macs_per_t = (double)Cout * Cin * KS;
-  int rc = upload(packed, &dc.wpack);
-  if (rc) return rc;
-  return upload(b, &dc.bias);
-}
-
-static int make_convT(const float* w, const float* bias, int Cin, int Cout, int k, int s,
-                      DevConv& dc) {
-  std::vector<float> w3;
-  convT_to_conv(w, Cin, Cout, k, s, w3);
-  std::vector<float> b3((size_t)Cout * s);
-  for (int co = 0; co < Cout; ++co)
-    for (int p = 0; p < s; ++p) b3[co * s + p] = bias ? bias[co] : 0.f;
-  int rc = make_conv(w3.data(), b3.data(), Cout * s, Cin, 3, 1, dc);
-  dc.up = s;
-  dc.macs_per_t = (double)Cin * Cout * k;  // per INPUT step: every (ci,co,kk) used once
-  return rc;
-}
-
-static void free_conv(DevConv& dc) {
-  if (dc.wpack) (void)hipFree(dc.wpack);
-  if (dc.bias) (void)hipFree(dc.bias);
-  dc.wpack = dc.bias = nullptr;
-}
-
 }  // namespace dissc
 
 using namespace dissc;
@@ -282,21 +236,6 @@ double dissc_gen_flops(dissc_gen_t g, int64_t frames) {
   }
   macs += (double)g->post_C * g->post_KS * mul;
   return 2.0 * macs * (double)frames;
-}
-
-static int run_conv(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
-                    const int32_t* lengths, int len_default, int len_mul, int B, int C_x, int ldx,
-                    int ldo, int Lmax, float slope, int epi, float mrf_div, hipStream_t stream) {
-  ConvArgs a;
-  a.x = x; a.wpack = dc.wpack; a.bias = dc.bias; a.res = res; a.out = out; a.acc = acc;
-  a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul;
-  a.CIN = dc.CIN; a.M = dc.M; a.KS = dc.KS; a.dil = dc.dil; a.nchunk = dc.nchunk;
-  a.XW = conv_xw(dc.M, dc.KS, dc.dil);
-  a.ldx = ldx; a.ldo = ldo;
-  a.x_bstride = (long long)C_x * ldx;
-  a.o_bstride = (long long)(dc.M / dc.up) * ldo;
-  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.up = dc.up;
-  return launch_conv(a, B, Lmax, stream);
 }
 
 int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const int64_t* spkr,

@@ -126,6 +126,46 @@ int dissc_set_option(const char* key, int value);
 int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int epi, int iters,
                      int flags, float* ms_out);
 
+/* ------------------------------------------------------------------------- *
+ * Length / pitch predictors and infer.py's integer sample logic.
+ * Replaces: LenPredictor.forward (reference model/len_predictor.py:35-52),
+ *   PitchPredictor / PitchPredictorBase .infer_freq (model/pitch_predictor.py:72-104,
+ *   145-176), dedup_seq (dataset/utils.py:14-16), len_carryover_correction
+ *   (infer.py:158-172), torch.repeat_interleave (infer.py:32).
+ * The reference runs B=1 per (utterance x target); these take a ragged batch
+ * (lengths i32 [B], NULL = all Lmax) and are sample-exact with B=1 runs.
+ * ------------------------------------------------------------------------- */
+typedef struct dissc_pred* dissc_pred_t;
+/* kind: 0 = LenPredictor, 1 = PitchPredictor ("new", positional encoding, BN on cnn2),
+ * 2 = PitchPredictorBase.  weights: the state_dict tensors by name; every eval-mode
+ * BatchNorm is passed pre-folded as "<conv>.bn_scale" / "<conv>.bn_shift"
+ * (alpha = weight/sqrt(var+eps), beta = bias - mean*alpha). */
+int dissc_pred_create(int kind, const DisscTensor* weights, size_t n_weights, dissc_pred_t* out);
+void dissc_pred_destroy(dissc_pred_t p);
+size_t dissc_pred_workspace_bytes(dissc_pred_t p, int B, int Lmax);
+/* LenPredictor.norm_mean / norm_std (reference infer.py:72: len_norm_stats.pth) */
+int dissc_len_set_norm(dissc_pred_t p, float mean, float std);
+/* seq i64 [B,Lmax] dedup'd units, spk i64 [B] -> out f32 [B,ldo] frames per unit */
+int dissc_len_forward(dissc_pred_t p, const int64_t* seq, const int64_t* spk, const int32_t* lengths,
+                      int B, int Lmax, float* out, int ldo, void* workspace, size_t workspace_bytes,
+                      void* stream);
+/* seq i64 [B,Tmax] frame-rate units -> out f32 [B,ldo]: (class_logit > 0) * f0; norm != 0 keeps
+ * the speaker-normalised value, else f0*id2std[spk] + id2mean[spk] (device arrays). */
+int dissc_pitch_forward(dissc_pred_t p, const int64_t* seq, const int64_t* spk,
+                        const int32_t* lengths, int B, int Tmax, int norm, const float* id2mean,
+                        const float* id2std, float* out, int ldo, void* workspace,
+                        size_t workspace_bytes, void* stream);
+/* run-length encode: units i64 [B,Tmax] -> vals i64 [B,Tmax], counts i32 [B,Tmax], n i32 [B] */
+int dissc_dedup(const int64_t* units, const int32_t* lengths, int B, int Tmax, int64_t* vals,
+                int32_t* counts, int32_t* n_out, void* stream);
+/* error-diffusion rounding of predicted lengths: lens f32 [B,ld] (n[b] valid) ->
+ * lens_int i32 [B,ld], totals i32 [B] = frames after expansion */
+int dissc_len_carryover(const float* lens, const int32_t* n, int B, int ld, int32_t* lens_int,
+                        int32_t* totals, void* stream);
+/* repeat_interleave: vals i64 [B,ld_in], lens_int i32 [B,ld_in] -> out i64 [B,ld_out] */
+int dissc_expand(const int64_t* vals, const int32_t* lens_int, const int32_t* n, int B, int ld_in,
+                 int64_t* out, int ld_out, void* stream);
+
 /* Diagnostics: sustained fp32 v_mfma_f32_16x16x4_f32 rate (TFLOP/s) of this GPU at its
  * real clocks -- the practical ceiling the conv kernels are compared with. */
 int dissc_mfma_peak(int iters, float* tflops);

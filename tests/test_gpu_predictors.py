@@ -1,0 +1,141 @@
+"""GPU parity of the predictors + infer.py sample logic vs golden outputs of the reference."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from dissc_amd import predictors as P
+    from oracle import synth
+    g = np.load(os.path.join(golden_dir, "pred.npz"))
+    lm = P.LenPredictor(n_tokens=100, n_speakers=108).to("cuda:0")
+    lm.load_state_dict(synth.synth_len_state_dict(100, 108))
+    lm.eval()
+    lm.norm_mean, lm.norm_std = synth.synth_len_norm_stats()
+    id2m, id2s = torch.from_numpy(g["id2pitch_mean"]), torch.from_numpy(g["id2pitch_std"])
+    pms = {}
+    for kind, cls in (("new", P.PitchPredictor), ("base", P.PitchPredictorBase)):
+        pm = cls(100, 108, id2pitch_mean=id2m, id2pitch_std=id2s).to("cuda:0")
+        pm.load_state_dict(synth.synth_pitch_state_dict(kind, 100, 108))
+        pm.eval()
+        pms[kind] = pm
+    return dict(P=P, synth=synth, g=g, lm=lm, pms=pms)
+
+
+def test_integer_logic_is_bit_exact(env):
+    P, g = env["P"], env["g"]
+    n = int(g["n_seqs"])
+    T = max(len(g[f"seq{i}"]) for i in range(n))
+    units = torch.full((n, T), 77, dtype=torch.int64)
+    lens = torch.zeros(n, dtype=torch.int32)
+    for i in range(n):
+        s = g[f"seq{i}"]
+        units[i, :len(s)] = torch.from_numpy(s)
+        lens[i] = len(s)
+    vals, counts, nn = P.dedup(units.cuda(), lens.cuda())
+    for i in range(n):
+        k = int(nn[i])
+        np.testing.assert_array_equal(vals[i, :k].cpu().numpy(), g[f"dd_vals{i}"])
+        np.testing.assert_array_equal(counts[i, :k].cpu().numpy(), g[f"dd_counts{i}"])
+    # carry-over rounding on the reference's own float predictions -> must match bit for bit
+    L = max(g[f"lens{i}"].shape[1] for i in range(n))
+    lf = torch.zeros(n, L)
+    for i in range(n):
+        lf[i, :g[f"lens{i}"].shape[1]] = torch.from_numpy(g[f"lens{i}"][0])
+    li, tot = P.len_carryover_correction(lf.cuda(), nn)
+    for i in range(n):
+        k = int(nn[i])
+        np.testing.assert_array_equal(li[i, :k].cpu().numpy(), g[f"lens_int{i}"])
+        assert int(tot[i]) == g[f"expanded{i}"].shape[1]
+    ex = P.expand(vals[:, :L].contiguous(), li, nn, int(tot.max()))
+    for i in range(n):
+        np.testing.assert_array_equal(ex[i, :int(tot[i])].cpu().numpy(), g[f"expanded{i}"][0])
+    for j in range(4):
+        x = torch.from_numpy(g[f"carry_in{j}"]).cuda()
+        got, _ = P.len_carryover_correction(x)
+        np.testing.assert_array_equal(got[0].cpu().numpy(), g[f"carry_out{j}"])
+
+
+def test_len_predictor_matches_reference(env):
+    g, lm = env["g"], env["lm"]
+    n = int(g["n_seqs"])
+    # one by one (reference style) and as one ragged batch: both must match
+    L = max(len(g[f"dd_vals{i}"]) for i in range(n))
+    seq = torch.full((n, L), 100, dtype=torch.int64)
+    lens = torch.zeros(n, dtype=torch.int32)
+    spk = torch.zeros(n, 1, dtype=torch.int64)
+    for i in range(n):
+        v = g[f"dd_vals{i}"]
+        seq[i, :len(v)] = torch.from_numpy(v)
+        lens[i] = len(v)
+        spk[i, 0] = int(g[f"spk{i}"])
+        one = lm(torch.from_numpy(v).unsqueeze(0), spk[i:i + 1]).cpu().numpy()
+        assert np.abs(one - g[f"lens{i}"]).max() <= 2e-5, i
+    batch = lm(seq, spk, lengths=lens).cpu().numpy()
+    for i in range(n):
+        k = int(lens[i])
+        assert np.abs(batch[i, :k] - g[f"lens{i}"][0]).max() <= 2e-5
+        # integer lengths after rounding agree with the reference's
+        from dissc_amd import predictors as P
+        li, _ = P.len_carryover_correction(torch.from_numpy(batch[i:i + 1, :k]).cuda())
+        np.testing.assert_array_equal(li[0].cpu().numpy(), g[f"lens_int{i}"])
+
+
+@pytest.mark.parametrize("kind", ["new", "base"])
+def test_pitch_predictor_matches_reference(env, kind):
+    g, pm = env["g"], env["pms"][kind]
+    n = int(g["n_seqs"])
+    T = max(g[f"expanded{i}"].shape[1] for i in range(n))
+    seq = torch.zeros(n, T, dtype=torch.int64)
+    lens = torch.zeros(n, dtype=torch.int32)
+    spk = torch.zeros(n, 1, dtype=torch.int64)
+    for i in range(n):
+        e = g[f"expanded{i}"][0]
+        seq[i, :len(e)] = torch.from_numpy(e)
+        lens[i] = len(e)
+        spk[i, 0] = int(g[f"spk{i}"])
+    fn = pm.infer_freq(seq, spk, True, lengths=lens).cpu().numpy()
+    fh = pm.infer_freq(seq, spk, False, lengths=lens).cpu().numpy()
+    for i in range(n):
+        k = int(lens[i])
+        want = g[f"f0_{kind}_norm{i}"][0]
+        # voiced/unvoiced decision identical except where the class logit is within rounding of 0
+        flips = (fn[i, :k] == 0) != (want == 0)
+        assert flips.sum() <= 1, (i, flips.sum())
+        ok = ~flips
+        assert np.abs(fn[i, :k][ok] - want[ok]).max() <= 2e-5
+        assert np.abs(fh[i, :k][ok] - g[f"f0_{kind}_hz{i}"][0][ok]).max() <= 2e-3
+        assert not fn[i, k:].any()
+        one = pm.infer_freq(seq[i:i + 1, :k], spk[i:i + 1], True).cpu().numpy()
+        np.testing.assert_array_equal(one[0], fn[i, :k])  # batching does not change a sample
+
+
+def test_infer_samples_matches_reference_infer_wild(env, golden_dir):
+    P, synth, g = env["P"], env["synth"], env["g"]
+    lm = P.LenPredictor(n_tokens=100, n_speakers=10).to("cuda:0")
+    lm.load_state_dict(synth.synth_len_state_dict(100, 10))
+    lm.norm_mean, lm.norm_std = synth.synth_len_norm_stats()
+    pm = P.PitchPredictorBase(100, 10).to("cuda:0")
+    pm.load_state_dict(synth.synth_pitch_state_dict("base", 100, 10))
+    names = pickle.load(open(os.path.join(golden_dir, "esd_id_to_spkr.pkl"), "rb"))
+    seqs, spks, keys = [], [], []
+    for t in g["wild/targets"]:
+        for i in range(3):
+            seqs.append(g[f"wild/in{i}"])
+            spks.append(names.index(str(t)))
+            keys.append(f"wild/{t}/{i}")
+    res = P.infer_samples(seqs, spks, lm, pm, norm_pitch=True)
+    for (units, f0), k in zip(res, keys):
+        np.testing.assert_array_equal(units, g[k + "/units"])
+        want = g[k + "/f0"]
+        flips = (np.array(f0) == 0) != (want == 0)
+        assert flips.sum() <= 1
+        assert np.abs(np.array(f0)[~flips] - want[~flips]).max() <= 2e-5
