@@ -293,7 +293,9 @@ def infer_samples(unit_seqs, spk_ids, len_model=None, pitch_model=None, norm_pit
     """Batched ``_infer_sample`` for the --pred_len/--pred_pitch modes.
 
     unit_seqs: list of 1-D int sequences (pad token n_tokens is dropped like infer.py:25);
-    spk_ids: list of target speaker ids.  Returns a list of (units list[int], f0 list[float]|None)."""
+    spk_ids: list of target speaker ids.  Returns a list of
+    (units list[int], f0 list[float]|None, lens list[int]|None) -- lens = corrected frames per
+    dedup'd unit when a length model is given."""
     dev = torch.device(device)
     seqs = [torch.as_tensor(s).long().reshape(-1) for s in unit_seqs]
     seqs = [s[s != n_tokens] for s in seqs]
@@ -317,12 +319,16 @@ def infer_samples(unit_seqs, spk_ids, len_model=None, pitch_model=None, norm_pit
         out_len = totals
     else:
         out_seq, out_len, tot = units, lengths, lengths.cpu()
+        lens_int = n = None
     f0 = None
     if pitch_model is not None and int(tot.max()) > 0:
         f0 = pitch_model.infer_freq(out_seq, spk, norm_pitch, lengths=out_len).cpu()
     out_seq_c = out_seq.cpu()
+    lens_c = lens_int.cpu() if lens_int is not None else None
+    n_c = n.cpu() if n is not None else None
     res = []
     for i in range(B):
         k = int(tot[i])
-        res.append((out_seq_c[i, :k].tolist(), f0[i, :k].tolist() if f0 is not None else None))
+        res.append((out_seq_c[i, :k].tolist(), f0[i, :k].tolist() if f0 is not None else None,
+                    lens_c[i, :int(n_c[i])].tolist() if lens_c is not None else None))
     return res

@@ -192,12 +192,127 @@ def make_predictors():
         out["wild/targets"] = np.array(a.target_speakers)
         for i, s in enumerate(wild):
             out[f"wild/in{i}"] = s
+    # end-to-end reference infer() (reconstruction + 2 targets, "new" pitch model, VCTK speakers)
+    import shutil
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(f"{td}/len"); os.makedirs(f"{td}/pitch"); os.makedirs(f"{td}/out"); os.makedirs(f"{td}/in")
+        torch.save(len_sd, f"{td}/len/best_model.pth")
+        torch.save((mean, std), f"{td}/len/len_norm_stats.pth")
+        torch.save(synth.synth_pitch_state_dict("new", 100, n_spk), f"{td}/pitch/best_model.pth")
+        shutil.copy(os.path.join(REF, "data/VCTK/hubert100/id_to_spkr.pkl"), f"{td}/in/id_to_spkr.pkl")
+        val = synth.synth_unit_sequences(3, 40, 260, seed=11)
+        vnames = ["p226_001.wav", "p300_014.wav", "p231_100.wav"]
+        rs2 = np.random.RandomState(12)
+        with open(f"{td}/in/val.txt", "w") as f:
+            for s_, nm in zip(val, vnames):
+                f0 = (rs2.rand(len(s_)) > 0.3) * (120 + 80 * rs2.rand(len(s_)))
+                f.write(_json.dumps({"units": s_.tolist(), "f0": f0.tolist(), "audio": nm}) + "\n")
+        out["val/manifest"] = np.array(open(f"{td}/in/val.txt").read())
+        a = argparse.Namespace(input_path=f"{td}/in/val.txt", n=3, out_path=f"{td}/out", pred_len=True,
+                               pred_pitch=True, len_model=f"{td}/len/", f0_model=f"{td}/pitch/",
+                               f0_model_type="new", n_tokens=100, device="cpu", seed=42,
+                               f0_path=os.path.join(REF, "data/VCTK/hubert100/f0_stats.pkl"), vc=True,
+                               norm_pitch=True, target_speakers=["p231", "p225"], sample_df=None,
+                               wild_sample=False, id_to_spkr=None)
+        ref_infer.args = a
+        ref_infer.infer(a.input_path, "cpu", a)
+        for fn in sorted(os.listdir(f"{td}/out")):
+            for i, ln in enumerate(open(f"{td}/out/{fn}").read().strip().split("\n")):
+                d = _json.loads(ln)
+                out[f"val/{fn}/{i}/units"] = np.array(d["units"], dtype=np.int64)
+                out[f"val/{fn}/{i}/f0"] = np.array(d["f0"], dtype=np.float64)
+                out[f"val/{fn}/{i}/audio"] = np.array(d["audio"])
     np.savez_compressed(os.path.join(HERE, "pred.npz"), **out)
     print("pred.npz", len(out), "arrays")
 
 
+def make_sr_inference():
+    """Run the reference's sr/inference.py worker code (init_worker + inference) on CPU.
+
+    librosa / soundfile / amfm_decompy are not installed: tiny stand-in modules provide
+    librosa.util.normalize (x / max|x| unless the peak is below float tiny -- its documented
+    norm=inf behaviour), librosa.filters.mel (unused result) and soundfile.read (scipy)."""
+    import json as _json
+    import pickle
+    import queue
+    import shutil
+    import tempfile
+    from scipy.io import wavfile
+
+    for m in list(sys.modules):
+        if m in ("utils", "models", "dataset", "inference", "infer") or m.startswith(("model.", "modules")):
+            sys.modules.pop(m, None)
+    if REF in sys.path:
+        sys.path.remove(REF)
+    sys.path.insert(0, os.path.join(REF, "sr"))
+
+    def _normalize(S, **kw):
+        S = np.asarray(S)
+        mag = np.abs(S).astype(float)
+        length = np.max(mag, axis=0, keepdims=True)
+        tiny = np.finfo(S.dtype).tiny if S.dtype.kind == "f" else np.finfo(np.float32).tiny
+        length = np.where(length < tiny, 1.0, length)
+        return (S / length).astype(S.dtype if S.dtype.kind == "f" else float)
+
+    librosa = types.ModuleType("librosa")
+    librosa.util = types.ModuleType("librosa.util")
+    librosa.util.normalize = _normalize
+    librosa.filters = types.ModuleType("librosa.filters")
+    librosa.filters.mel = lambda sr, n_fft, n_mels, fmin, fmax: np.zeros((n_mels, n_fft // 2 + 1), np.float32)
+    sf = types.ModuleType("soundfile")
+    sf.read = lambda path, dtype="int16": (lambda r: (r[1], r[0]))(wavfile.read(str(path)))
+    amfm = types.ModuleType("amfm_decompy")
+    sys.modules.update({"librosa": librosa, "librosa.util": librosa.util, "librosa.filters": librosa.filters,
+                        "soundfile": sf, "amfm_decompy": amfm,
+                        "amfm_decompy.basic_tools": types.ModuleType("amfm_decompy.basic_tools"),
+                        "amfm_decompy.pYAAPT": types.ModuleType("amfm_decompy.pYAAPT")})
+    import inference as ref_inf  # reference sr/inference.py
+
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(f"{td}/ckpt"); os.makedirs(f"{td}/wav"); os.makedirs(f"{td}/out"); os.makedirs(f"{td}/meta")
+        cfg = _json.load(open(os.path.join(REF, "sr/configs/VCTK/hubert100_lut.json")))
+        cfg.update({"input_training_file": f"{td}/meta/train.txt", "f0_normalize": False, "f0_stats": None})
+        _json.dump(cfg, open(f"{td}/ckpt/config.json", "w"))
+        torch.save({"generator": synth.synth_generator_state_dict(seed=0)}, f"{td}/ckpt/g_00000001")
+        shutil.copy(os.path.join(REF, "data/VCTK/hubert100/id_to_spkr.pkl"), f"{td}/meta/id_to_spkr.pkl")
+        names = ["p226_001.wav", "p300_002.wav"]
+        srcs = ["s1_1.wav", "s1_2.wav"]
+        lens = [90, 71]
+        man = f"{td}/man.txt"
+        with open(man, "w") as f:
+            for i, (nm, sr_, T) in enumerate(zip(names, srcs, lens)):
+                shutil.copy(os.path.join(REF, "data/unseen/wav_orig", sr_), f"{td}/wav/{nm}")
+                code, f0, _, _ = synth.synth_generator_inputs(1, T, seed=900 + i)
+                f.write(_json.dumps({"units": code[0].tolist(), "f0": f0[0, 0].tolist(), "audio": nm}) + "\n")
+                out[f"sr/units{i}"], out[f"sr/f0{i}"] = code[0], f0[0, 0]
+        import argparse
+        a = argparse.Namespace(code_file=None, input_code_file=man, data_path=f"{td}/wav", output_dir=f"{td}/out",
+                               checkpoint_file=f"{td}/ckpt/", f0_stats=None, vc=True,
+                               target_speakers=["p231", "p225"], pad=None, debug=True, eval_mode=True,
+                               parts=False, unseen_f0=None, unseen_speaker=False, id_to_spkr=None,
+                               sample_df=None, n=-1)
+        q = queue.Queue()
+        q.put("cpu")
+        try:
+            ref_inf.init_worker(q, a)
+        except TypeError:
+            pass  # `seed = 52 + idx` with idx='cpu' (reference sr/inference.py:166): all globals are set by then
+        for i in range(2):
+            ref_inf.inference(i)
+        for fn in sorted(os.listdir(f"{td}/out")):
+            rate, data = wavfile.read(f"{td}/out/{fn}")
+            assert rate == 16000
+            out[f"sr/out/{fn}"] = data
+        out["sr/names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "sr_inference.npz"), **out)
+    print("sr_inference.npz", sorted(k for k in out if k.startswith("sr/out")))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["generator", "predictors"]
+    which = sys.argv[1:] or ["generator", "predictors", "sr_inference"]
+    if "sr_inference" in which:
+        make_sr_inference()
     if "generator" in which:
         make_generator()
     if "predictors" in which:

@@ -1,0 +1,96 @@
+"""End-to-end entry points on the GPU vs outputs of the reference's own CLI code
+(tests/golden/pred.npz 'val/*' = reference infer.infer(); sr_inference.npz = reference
+sr/inference.py init_worker + inference)."""
+import importlib.util
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+from scipy.io import wavfile
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, rel))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def test_infer_cli_matches_reference(gpu, golden_dir, tmp_path):
+    from oracle import synth
+    g = np.load(os.path.join(golden_dir, "pred.npz"))
+    td = str(tmp_path)
+    for d in ("len", "pitch", "out", "in"):
+        os.makedirs(f"{td}/{d}")
+    torch.save(synth.synth_len_state_dict(100, 108), f"{td}/len/best_model.pth")
+    torch.save(synth.synth_len_norm_stats(), f"{td}/len/len_norm_stats.pth")
+    torch.save(synth.synth_pitch_state_dict("new", 100, 108), f"{td}/pitch/best_model.pth")
+    shutil.copy(os.path.join(golden_dir, "vctk_id_to_spkr.pkl"), f"{td}/in/id_to_spkr.pkl")
+    open(f"{td}/in/val.txt", "w").write(str(g["val/manifest"]))
+    infer = _load("dissc_infer_cli", "infer.py")
+    infer.main(["--input_path", f"{td}/in/val.txt", "-n", "1000", "--out_path", f"{td}/out", "--pred_len",
+                "--pred_pitch", "--len_model", f"{td}/len/", "--f0_model", f"{td}/pitch/", "--f0_model_type",
+                "new", "--f0_path", os.path.join(golden_dir, "vctk_f0_stats.pkl"), "--vc",
+                "--target_speakers", "p231", "p225", "--device", "cuda:0"])
+    assert sorted(os.listdir(f"{td}/out")) == ["p225_val.txt", "p231_val.txt", "val.txt"]
+    for fn in os.listdir(f"{td}/out"):
+        lines = open(f"{td}/out/{fn}").read().strip().split("\n")
+        assert len(lines) == 3
+        for i, ln in enumerate(lines):
+            d = json.loads(ln)
+            assert d["audio"] == str(g[f"val/{fn}/{i}/audio"])
+            np.testing.assert_array_equal(d["units"], g[f"val/{fn}/{i}/units"])  # exact
+            want = g[f"val/{fn}/{i}/f0"]
+            got = np.array(d["f0"])
+            flips = (got == 0) != (want == 0)
+            assert flips.sum() <= 1
+            assert np.abs(got[~flips] - want[~flips]).max() <= 2e-5
+
+
+def test_sr_inference_cli_matches_reference(gpu, golden_dir, tmp_path):
+    from oracle import synth
+    g = np.load(os.path.join(golden_dir, "sr_inference.npz"))
+    td = str(tmp_path)
+    for d in ("ckpt", "wav", "out", "meta"):
+        os.makedirs(f"{td}/{d}")
+    cfg = dict(synth.VCTK_CONFIG, input_training_file=f"{td}/meta/train.txt", f0_normalize=False,
+               f0_stats=None, test_base_path=f"{td}/wav")
+    json.dump(cfg, open(f"{td}/ckpt/config.json", "w"))
+    torch.save({"generator": synth.synth_generator_state_dict(seed=0)}, f"{td}/ckpt/g_00000001")
+    shutil.copy(os.path.join(golden_dir, "vctk_id_to_spkr.pkl"), f"{td}/meta/id_to_spkr.pkl")
+    names = [str(x) for x in g["sr/names"]]
+    with open(f"{td}/man.txt", "w") as f:
+        for i, nm in enumerate(names):
+            shutil.copy(os.path.join(golden_dir, f"s1_{i + 1}.wav"), f"{td}/wav/{nm}")
+            f.write(json.dumps({"units": g[f"sr/units{i}"].tolist(), "f0": g[f"sr/f0{i}"].tolist(),
+                                "audio": nm}) + "\n")
+    cli = _load("dissc_sr_inference_cli", "sr/inference.py")
+    cli.main(["--input_code_file", f"{td}/man.txt", "--data_path", f"{td}/wav", "--output_dir", f"{td}/out",
+              "--checkpoint_file", f"{td}/ckpt/", "--vc", "--target-speakers", "p231", "p225", "-n", "-1"])
+    want_files = sorted(k[len("sr/out/"):] for k in g.files if k.startswith("sr/out/"))
+    assert sorted(os.listdir(f"{td}/out")) == want_files
+    for fn in want_files:
+        rate, data = wavfile.read(f"{td}/out/{fn}")
+        ref = g["sr/out/" + fn]
+        assert rate == 16000 and data.dtype == np.float32 and data.shape == ref.shape, fn
+        if fn.endswith("_gt.wav"):
+            np.testing.assert_array_equal(data, ref)
+        else:
+            # int16 truncation of a ~1e-6-different waveform can move a sample by one LSB
+            # (1/peak ~ 3e-5); everything else is bit-identical
+            d = np.abs(data - ref)
+            assert d.max() <= 1e-4, (fn, d.max())
+            assert np.sqrt(np.mean(d ** 2)) <= 1e-5
+            assert (d > 1e-6).mean() <= 0.02

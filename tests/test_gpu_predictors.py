@@ -133,7 +133,7 @@ def test_infer_samples_matches_reference_infer_wild(env, golden_dir):
             spks.append(names.index(str(t)))
             keys.append(f"wild/{t}/{i}")
     res = P.infer_samples(seqs, spks, lm, pm, norm_pitch=True)
-    for (units, f0), k in zip(res, keys):
+    for (units, f0, _lens), k in zip(res, keys):
         np.testing.assert_array_equal(units, g[k + "/units"])
         want = g[k + "/f0"]
         flips = (np.array(f0) == 0) != (want == 0)
