@@ -1,0 +1,119 @@
+"""CPU restatement of the HuBERT-base unit encoder (TEST INFRASTRUCTURE).
+
+PARITY UNPINNED against the reference's actual dependency: the arithmetic lives in
+fairseq (pinned at commit dd106d9534b22e7db859a6b87ffd7780c38341f8, reference README.md:34) and
+textlesslib (unpinned HEAD, README.md:31-33), reached from data/encode.py:21-22,32 -- neither
+library nor the hubert-base-ls960 / k-means-100 weights exist offline.  What IS pinned
+(tests/golden/hubert.npz, made by tests/golden/make_golden.py):
+  * this restatement == HuggingFace ``transformers.HubertModel`` (architecture-equivalent to
+    fairseq HuBERT-base per its conversion script; hidden_states[6] == extract_features(
+    output_layer=6)) on seeded random weights,
+  * kmeans_assign == sklearn.cluster.KMeans.predict with the same centroids.
+
+Published algorithm restated (fairseq hubert.py / wav2vec2.py, HuBERT-base config):
+  conv_feature_extractor  7 x Conv1d(no bias) k=(10,3,3,3,3,2,2) s=(5,2,2,2,2,2,2), 512 ch;
+                          GroupNorm(512 groups) after conv 0; exact GELU after every conv
+  project                 LayerNorm(512) -> Linear(512,768)
+  encoder                 x += GELU(Conv1d(768,768,k=128,pad=64,groups=16, weight_norm dim=2)[..., :-1]);
+                          LayerNorm; 6 x post-LN block {MHA 12x64 (q scaled by 1/8), FFN 768-3072-768 GELU}
+  kmeans_assign           argmin_k ||x - c_k||^2 (lowest index on ties)
+
+Weight names follow the fairseq checkpoint (``model`` dict of hubert_base_ls960.pt).
+"""
+import torch
+import torch.nn.functional as F
+
+CONV_LAYERS = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2
+EPS = 1e-5
+
+
+def num_frames(n_samples):
+    n = n_samples
+    for _, k, s in CONV_LAYERS:
+        n = (n - k) // s + 1 if n >= k else 0
+    return n
+
+
+def conv_feature_extractor(sd, wav):
+    """wav f32 [B,N] -> [B,512,T]"""
+    x = wav.unsqueeze(1)
+    for i, (_, k, s) in enumerate(CONV_LAYERS):
+        x = F.conv1d(x, sd[f"feature_extractor.conv_layers.{i}.0.weight"], None, stride=s)
+        if i == 0:
+            x = F.group_norm(x, x.shape[1], sd["feature_extractor.conv_layers.0.2.weight"],
+                             sd["feature_extractor.conv_layers.0.2.bias"], EPS)
+        x = F.gelu(x)
+    return x
+
+
+def pos_conv_weight(sd):
+    # weight_norm(dim=2): norm over dims (0,1) for every kernel position
+    return torch._weight_norm(sd["encoder.pos_conv.0.weight_v"], sd["encoder.pos_conv.0.weight_g"], 2)
+
+
+def encoder(sd, feats, n_layers=6, n_heads=12):
+    """feats [B,512,T] -> layer-``n_layers`` output [B,T,768]"""
+    x = feats.transpose(1, 2)
+    x = F.layer_norm(x, (x.shape[-1],), sd["layer_norm.weight"], sd["layer_norm.bias"], EPS)
+    x = F.linear(x, sd["post_extract_proj.weight"], sd["post_extract_proj.bias"])
+    pc = F.conv1d(x.transpose(1, 2), pos_conv_weight(sd), sd["encoder.pos_conv.0.bias"], padding=64, groups=16)
+    pc = F.gelu(pc[:, :, :-1])
+    x = x + pc.transpose(1, 2)
+    x = F.layer_norm(x, (768,), sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"], EPS)
+    B, T, D = x.shape
+    hd = D // n_heads
+    for i in range(n_layers):
+        p = f"encoder.layers.{i}."
+        q = F.linear(x, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]) * hd ** -0.5
+        k = F.linear(x, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"])
+        v = F.linear(x, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"])
+        q, k, v = (t.view(B, T, n_heads, hd).transpose(1, 2) for t in (q, k, v))
+        a = torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v
+        a = a.transpose(1, 2).reshape(B, T, D)
+        a = F.linear(a, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+        x = F.layer_norm(x + a, (D,), sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"], EPS)
+        h = F.gelu(F.linear(x, sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
+        h = F.linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+        x = F.layer_norm(x + h, (D,), sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"], EPS)
+    return x
+
+
+def kmeans_assign(x, centers):
+    """x [T,D], centers [K,D] -> int64 [T]: argmin ||x-c||^2 = argmin (||c||^2 - 2 x.c)"""
+    d = (centers * centers).sum(1)[None, :] - 2.0 * (x @ centers.t())
+    return torch.argmin(d, dim=1)
+
+
+@torch.no_grad()
+def encode(sd, centers, wav, n_layers=6):
+    """One utterance like the reference (B=1, data/encode.py:32): wav [1,N] -> (units [T], dense [T,768])"""
+    dense = encoder(sd, conv_feature_extractor(sd, wav), n_layers)[0]
+    return kmeans_assign(dense, centers), dense
+
+
+def fairseq_to_hf(sd):
+    """fairseq key names -> transformers.HubertModel names (its conversion script's mapping)."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("feature_extractor.conv_layers."):
+            i, sub = k.split(".")[2], k.split(".")[3]
+            rest = k.split(".")[4]
+            name = "conv" if sub == "0" else "layer_norm"
+            out[f"feature_extractor.conv_layers.{i}.{name}.{rest}"] = v
+        elif k.startswith("post_extract_proj."):
+            out["feature_projection.projection." + k.split(".")[-1]] = v
+        elif k.startswith("layer_norm."):
+            out["feature_projection.layer_norm." + k.split(".")[-1]] = v
+        elif k == "encoder.pos_conv.0.weight_g":
+            out["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = v
+        elif k == "encoder.pos_conv.0.weight_v":
+            out["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = v
+        elif k == "encoder.pos_conv.0.bias":
+            out["encoder.pos_conv_embed.conv.bias"] = v
+        elif k.startswith("encoder.layer_norm."):
+            out[k] = v
+        elif k.startswith("encoder.layers."):
+            k2 = (k.replace("self_attn_layer_norm", "layer_norm").replace("self_attn.", "attention.")
+                   .replace("fc1.", "feed_forward.intermediate_dense.").replace("fc2.", "feed_forward.output_dense."))
+            out[k2] = v
+    return out

@@ -199,3 +199,55 @@ def synth_unit_sequences(n, T_lo=60, T_hi=500, seed=99, n_codes=100):
             t += run
         out.append(seq)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# HuBERT-base (fairseq checkpoint key names) + k-means centroids
+# ----------------------------------------------------------------------------------------------
+def synth_hubert_state_dict(n_layers=6, seed=3):
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    convs = [(512, 1, 10)] + [(512, 512, 3)] * 4 + [(512, 512, 2)] * 2
+    for i, (co, ci, k) in enumerate(convs):
+        sd[f"feature_extractor.conv_layers.{i}.0.weight"] = _t(rs.standard_normal((co, ci, k)) * 1.6 / np.sqrt(ci * k))
+    sd["feature_extractor.conv_layers.0.2.weight"] = _t(1.0 + 0.2 * rs.standard_normal(512))
+    sd["feature_extractor.conv_layers.0.2.bias"] = _t(0.1 * rs.standard_normal(512))
+
+    def ln(name, c):
+        sd[name + ".weight"] = _t(1.0 + 0.1 * rs.standard_normal(c))
+        sd[name + ".bias"] = _t(0.05 * rs.standard_normal(c))
+
+    def lin(name, co, ci, gain=1.0):
+        sd[name + ".weight"] = _t(rs.standard_normal((co, ci)) * gain / np.sqrt(ci))
+        sd[name + ".bias"] = _t(0.05 * rs.standard_normal(co))
+
+    ln("layer_norm", 512)
+    lin("post_extract_proj", 768, 512)
+    v = rs.standard_normal((768, 48, 128))
+    sd["encoder.pos_conv.0.weight_v"] = _t(v)
+    sd["encoder.pos_conv.0.weight_g"] = _t((np.sqrt((v ** 2).sum((0, 1), keepdims=True))
+                                            * 1.2 / np.sqrt(48 * 128)) * (1 + 0.1 * rs.standard_normal((1, 1, 128))))
+    sd["encoder.pos_conv.0.bias"] = _t(0.05 * rs.standard_normal(768))
+    ln("encoder.layer_norm", 768)
+    for i in range(n_layers):
+        p = f"encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            lin(p + "self_attn." + n, 768, 768, 1.5 if n in ("q_proj", "k_proj") else 1.0)
+        ln(p + "self_attn_layer_norm", 768)
+        lin(p + "fc1", 3072, 768)
+        lin(p + "fc2", 768, 3072)
+        ln(p + "final_layer_norm", 768)
+    return sd
+
+
+def synth_kmeans_centers(k=100, dim=768, seed=4):
+    return _t(np.random.RandomState(seed).standard_normal((k, dim)) * 0.7)
+
+
+def synth_waveform(n, seed=0):
+    """N(0,0.1) noise + a few tones, clipped to [-1,1]"""
+    rs = np.random.RandomState(seed)
+    t = np.arange(n) / 16000.0
+    x = 0.1 * rs.standard_normal(n) + 0.2 * np.sin(2 * np.pi * (110 + 40 * rs.rand()) * t) \
+        + 0.1 * np.sin(2 * np.pi * (900 + 300 * rs.rand()) * t)
+    return np.clip(x, -1, 1).astype(np.float32)

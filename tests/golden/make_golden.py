@@ -309,8 +309,40 @@ def make_sr_inference():
     print("sr_inference.npz", sorted(k for k in out if k.startswith("sr/out")))
 
 
+def make_hubert():
+    """HF transformers.HubertModel (architecture oracle) + sklearn KMeans."""
+    from sklearn.cluster import KMeans
+    from transformers import HubertConfig, HubertModel
+    from oracle import hubert_ref
+    sd = synth.synth_hubert_state_dict(6)
+    m = HubertModel(HubertConfig(num_hidden_layers=6)).eval()
+    missing, unexpected = m.load_state_dict(hubert_ref.fairseq_to_hf(sd), strict=False)
+    assert not unexpected and all("masked_spec_embed" in k for k in missing), (missing, unexpected)
+    centers = synth.synth_kmeans_centers()
+    km = KMeans(n_clusters=100, n_init=1)
+    km.cluster_centers_ = centers.numpy().astype(np.float32)
+    km._n_threads = 1
+    km.n_features_in_ = 768
+    out = {}
+    for n in (400, 719, 4000, 16000, 32000):
+        wav = torch.from_numpy(synth.synth_waveform(n, seed=n))[None]
+        with torch.no_grad():
+            o = m(wav, output_hidden_states=True)
+            feats = m.feature_extractor(wav)
+        dense = o.hidden_states[6][0].numpy()
+        out[f"n{n}/dense"] = dense
+        out[f"n{n}/units"] = km.predict(dense.astype(np.float32)).astype(np.int64)
+        if n <= 4000:
+            out[f"n{n}/cnn"] = feats.numpy()
+            out[f"n{n}/h0"] = o.hidden_states[0][0].numpy()
+    np.savez_compressed(os.path.join(HERE, "hubert.npz"), **out)
+    print("hubert.npz", {k: v.shape for k, v in out.items() if k.endswith("units")})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["generator", "predictors", "sr_inference"]
+    which = sys.argv[1:] or ["generator", "predictors", "sr_inference", "hubert"]
+    if "hubert" in which:
+        make_hubert()
     if "sr_inference" in which:
         make_sr_inference()
     if "generator" in which:

@@ -144,3 +144,39 @@ def test_infer_sample_matches_reference_infer_wild(pgold):
             units, f0 = pr.infer_sample(pgold[f"wild/in{i}"], spk, len_sd, stats, pitch_sd, "base", True)
             np.testing.assert_array_equal(units, pgold[f"wild/{t}/{i}/units"])
             assert np.abs(np.array(f0) - pgold[f"wild/{t}/{i}/f0"]).max() <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------
+# HuBERT unit encoder (golden: HF transformers.HubertModel + sklearn KMeans.predict;
+# parity vs fairseq/textless itself is UNPINNED -- see oracle/hubert_ref.py header)
+# ------------------------------------------------------------------------------------------
+from oracle import hubert_ref as hr  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hgold(golden_dir):
+    return np.load(os.path.join(golden_dir, "hubert.npz"))
+
+
+def test_hubert_frame_count():
+    assert [hr.num_frames(n) for n in (399, 400, 719, 720, 32000, 160000)] == [0, 1, 1, 2, 99, 499]
+
+
+@pytest.mark.parametrize("n", [400, 719, 4000, 16000, 32000])
+def test_hubert_oracle_matches_hf_and_sklearn(hgold, n):
+    sd = synth.synth_hubert_state_dict(6)
+    centers = synth.synth_kmeans_centers()
+    wav = torch.from_numpy(synth.synth_waveform(n, seed=n))[None]
+    units, dense = hr.encode(sd, centers, wav)
+    want = hgold[f"n{n}/dense"]
+    assert dense.shape == want.shape
+    assert np.abs(dense.numpy() - want).max() <= 2e-4 * max(1.0, np.abs(want).max())
+    # unit indices: equal wherever the top-2 centroid margin is above rounding noise
+    d = ((torch.from_numpy(want)[:, None, :] - centers[None]) ** 2).sum(-1)
+    top2 = torch.topk(d, 2, largest=False).values
+    safe = ((top2[:, 1] - top2[:, 0]) > 0.02).numpy()  # distances are O(1e3); fp32 noise ~1e-3
+    np.testing.assert_array_equal(units.numpy()[safe], hgold[f"n{n}/units"][safe])
+    assert safe.mean() > 0.9
+    if n <= 4000:
+        cnn = hr.conv_feature_extractor(sd, wav)
+        assert np.abs(cnn.numpy() - hgold[f"n{n}/cnn"]).max() <= 1e-4
