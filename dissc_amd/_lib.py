@@ -79,6 +79,14 @@ def _load():
     L.dissc_dedup.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     L.dissc_len_carryover.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.dissc_expand.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp]
+    L.dissc_hubert_create.argtypes = [i32, ctypes.POINTER(DisscTensor), ctypes.c_size_t, vp, i32,
+                                      ctypes.POINTER(vp)]
+    L.dissc_hubert_destroy.argtypes = [vp]
+    L.dissc_hubert_destroy.restype = None
+    L.dissc_hubert_frames.argtypes = [i32]
+    L.dissc_hubert_workspace_bytes.argtypes = [vp, i32, i32]
+    L.dissc_hubert_workspace_bytes.restype = ctypes.c_size_t
+    L.dissc_hubert_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, ctypes.c_size_t, vp]
     L.dissc_mfma_peak.argtypes = [i32, ctypes.POINTER(ctypes.c_float)]
     L.dissc_set_option.argtypes = [ctypes.c_char_p, i32]
     L.dissc_conv_bench.argtypes = [i32] * 9 + [ctypes.POINTER(ctypes.c_float)]

@@ -48,9 +48,16 @@ struct ConvArgs {
   const float* res;     // residual, same layout as out (EPI_RES / EPI_MRF_*)
   float* out;           // [B][M/up][ldo]
   float* acc;           // MRF accumulator (EPI_MRF_*), same layout as out
-  const int32_t* lengths;  // [B] valid frames, or nullptr
+  const int32_t* lengths;  // [B] valid input frames, or nullptr
   int len_default;      // used when lengths == nullptr (already in this layer's units)
   int len_mul;          // layer length = lengths[b] * len_mul
+  const int32_t* lengths_out;  // [B] valid OUTPUT positions (strided / valid convs); nullptr = same as input
+  int olen_default;     // used when lengths_out == nullptr and >= 0
+  int pad_left;         // input index = t*stride + j*dil - pad_left
+  int groups;           // grouped conv: CIN and M are PER GROUP
+  int mt_per_group;     // M tiles (blockIdx.y) per group
+  int nsub_group;       // 16-row subtiles per group in the packed weights / bias arrays
+  int act;              // 0 none, 1 exact GELU on (conv + bias) before any residual
   int CIN, M, KS, dil, nchunk;
   int XW;               // LDS row stride (floats), XW % 32 == 16
   int ldx, ldo;
@@ -61,20 +68,21 @@ struct ConvArgs {
   int up;               // 1 = conv; s = ConvTranspose stride (rows are co*s+p)
 };
 
-constexpr int MAX_TAP_SPAN = 60;  // (KS-1)*dil supported by the staging register budget
+constexpr int MAX_TAP_SPAN = 60;    // (KS-1)*dil of the default instances (staging register budget)
+constexpr int WIDE_TAP_SPAN = 128;  // wide instance (HuBERT positional conv, k=128)
 
 // Pick a tile shape for M rows / Lmax columns and launch.  Returns a DISSC_* code.
-int launch_conv(const ConvArgs& a, int B, int Lmax, hipStream_t stream);
+int launch_conv(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t stream);
 // LDS row stride for a (KS, dil) conv with time tile BN.
 int conv_tile_bn(int M);
 int conv_cfg(int M);
 void conv_set_cfg(int bm_class, int cfg);  // tuning hook (dissc_conv_bench / dissc_set_option)
-int conv_xw(int M, int KS, int dil);
+int conv_xw(int M, int KS, int dil, int stride = 1);
 
 // Host-side weight packing.  w: [Cout][Cin][KS] (Conv1d layout).  Returns the packed
 // buffer (Mpad/16 * nchunk * KS * 64 float4) and Mpad (M rounded up to 16).
 void pack_conv_weights(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
-                       int& Mpad, int& nchunk);
+                       int& Mpad, int& nchunk, int groups = 1);
 // ConvTranspose1d [Cin][Cout][k], stride s, padding (k-s)/2  ->  3-tap conv with
 // M = Cout*s rows (row = co*s + p), taps delta = -1,0,+1.
 void convT_to_conv(const float* w, int Cin, int Cout, int k, int s, std::vector<float>& w3);
@@ -85,17 +93,33 @@ struct DevConv {
   float* bias = nullptr;
   float* scale = nullptr;  // optional per-row affine applied after bias: v*scale + shift
   float* shift = nullptr;  // (eval-mode BatchNorm1d / label de-normalisation)
-  int CIN = 0, M = 0, KS = 0, dil = 1, nchunk = 0, up = 1;
+  int CIN = 0, M = 0, KS = 0, dil = 1, nchunk = 0, up = 1;  // CIN, M per group
+  int groups = 1, Mpad = 0, stride = 1, pad_left = -1;      // pad_left -1 = "same" ((KS-1)*dil/2)
+  int act = 0;
   double macs_per_t = 0;  // MACs per input time step (algorithmic, zero taps excluded)
 };
+// Per-call extras of run_conv_ex (strided / valid convolutions with their own output lengths).
+struct ConvIO {
+  const int32_t* lengths_in = nullptr;
+  const int32_t* lengths_out = nullptr;
+  int len_default = 0, olen_default = -1, len_mul = 1;
+};
 int upload(const std::vector<float>& h, float** d);
-int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int dil, DevConv& dc);
+int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int dil, DevConv& dc,
+              int groups = 1, int stride = 1, int pad_left = -1);
 int make_convT(const float* w, const float* bias, int Cin, int Cout, int k, int s, DevConv& dc);
 int set_affine(DevConv& dc, const float* scale, const float* shift, int n);  // host pointers
 void free_conv(DevConv& dc);
 int run_conv(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
              const int32_t* lengths, int len_default, int len_mul, int B, int C_x, int ldx, int ldo,
              int Lmax, float slope, int epi, float mrf_div, hipStream_t stream);
+
+int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res, const ConvIO& io,
+                int B, int C_x_total, int ldx, int ldo, int Lmax_out, float slope, int epi,
+                hipStream_t stream);
+int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
+                const ConvIO& io, int B, int C_x_total, int ldx, int ldo, int Lmax_out, float slope,
+                int epi, float mrf_div, hipStream_t stream);
 
 // misc kernels (gen_misc.hip)
 void launch_embed_concat(const int64_t* code, const float* f0, const int64_t* spkr,

@@ -12,15 +12,19 @@ int upload(const std::vector<float>& h, float** d) {
   return DISSC_OK;
 }
 
-int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int dil,
-                     DevConv& dc) {
+// w: [Cout][Cin/groups][KS] (PyTorch layout); Cout, Cin are the TOTAL channel counts.
+int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int dil, DevConv& dc,
+              int groups, int stride, int pad_left) {
   std::vector<float> packed;
   int Mpad, nchunk;
-  pack_conv_weights(w, Cout, Cin, KS, packed, Mpad, nchunk);
-  std::vector<float> b(Mpad, 0.f);
-  if (bias) memcpy(b.data(), bias, Cout * sizeof(float));
-  dc.CIN = Cin; dc.M = Cout; dc.KS = KS; dc.dil = dil; dc.nchunk = nchunk; dc.up = 1;
-  dc.macs_per_t = (double)Cout * Cin * KS;
+  const int Mg = Cout / groups, Cg = Cin / groups;
+  pack_conv_weights(w, Cout, Cg, KS, packed, Mpad, nchunk, groups);
+  std::vector<float> b((size_t)Mpad * groups, 0.f);
+  if (bias)
+    for (int g = 0; g < groups; ++g) memcpy(b.data() + (size_t)g * Mpad, bias + (size_t)g * Mg, Mg * sizeof(float));
+  dc.CIN = Cg; dc.M = Mg; dc.KS = KS; dc.dil = dil; dc.nchunk = nchunk; dc.up = 1;
+  dc.groups = groups; dc.Mpad = Mpad; dc.stride = stride; dc.pad_left = pad_left;
+  dc.macs_per_t = (double)Cout * Cg * KS;
   int rc = upload(packed, &dc.wpack);
   if (rc) return rc;
   return upload(b, &dc.bias);
@@ -40,11 +44,12 @@ int make_convT(const float* w, const float* bias, int Cin, int Cout, int k, int 
 }
 
 int set_affine(DevConv& dc, const float* scale, const float* shift, int n) {
-  const int bm_pad = 256;  // generous: rows beyond M are never stored
-  std::vector<float> sc((size_t)(dc.M + bm_pad), 1.f), sh((size_t)(dc.M + bm_pad), 0.f);
-  for (int i = 0; i < n && i < dc.M; ++i) {
-    sc[i] = scale ? scale[i] : 1.f;
-    sh[i] = shift ? shift[i] : 0.f;
+  // same [groups][Mpad] indexing as the bias
+  std::vector<float> sc((size_t)dc.Mpad * dc.groups, 1.f), sh((size_t)dc.Mpad * dc.groups, 0.f);
+  for (int i = 0; i < n && i < dc.M * dc.groups; ++i) {
+    const size_t k = (size_t)(i / dc.M) * dc.Mpad + (i % dc.M);
+    sc[k] = scale ? scale[i] : 1.f;
+    sh[k] = shift ? shift[i] : 0.f;
   }
   int rc = upload(sc, &dc.scale);
   if (rc) return rc;
@@ -60,20 +65,38 @@ void free_conv(DevConv& dc) {
 }
 
 
-int run_conv(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
-                    const int32_t* lengths, int len_default, int len_mul, int B, int C_x, int ldx,
-                    int ldo, int Lmax, float slope, int epi, float mrf_div, hipStream_t stream) {
+int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
+                const ConvIO& io, int B, int C_x_total, int ldx, int ldo, int Lmax_out, float slope,
+                int epi, float mrf_div, hipStream_t stream) {
   ConvArgs a;
-  a.x = x; a.wpack = dc.wpack; a.bias = dc.bias; a.scale = dc.scale; a.shift = dc.shift; a.res = res; a.out = out; a.acc = acc;
-  a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul;
+  a.x = x; a.wpack = dc.wpack; a.bias = dc.bias; a.scale = dc.scale; a.shift = dc.shift; a.res = res;
+  a.out = out; a.acc = acc;
+  a.lengths = io.lengths_in; a.len_default = io.len_default; a.len_mul = io.len_mul;
+  a.lengths_out = io.lengths_out; a.olen_default = io.olen_default;
   a.CIN = dc.CIN; a.M = dc.M; a.KS = dc.KS; a.dil = dc.dil; a.nchunk = dc.nchunk;
-  a.XW = conv_xw(dc.M, dc.KS, dc.dil);
+  a.pad_left = dc.pad_left >= 0 ? dc.pad_left : ((dc.KS - 1) * dc.dil) / 2;
+  a.groups = dc.groups; a.nsub_group = dc.Mpad / 16; a.act = dc.act;
+  a.XW = conv_xw(dc.M, dc.KS, dc.dil, dc.stride);
   a.ldx = ldx; a.ldo = ldo;
-  a.x_bstride = (long long)C_x * ldx;
-  a.o_bstride = (long long)(dc.M / dc.up) * ldo;
+  a.x_bstride = (long long)C_x_total * ldx;
+  a.o_bstride = (long long)(dc.M * dc.groups / dc.up) * ldo;
   a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.up = dc.up;
-  return launch_conv(a, B, Lmax, stream);
+  return launch_conv(a, B, Lmax_out, dc.stride, stream);
 }
 
+int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res, const ConvIO& io,
+                int B, int C_x_total, int ldx, int ldo, int Lmax_out, float slope, int epi,
+                hipStream_t stream) {
+  return run_conv_ex(dc, x, out, res, nullptr, io, B, C_x_total, ldx, ldo, Lmax_out, slope, epi, 1.f,
+                     stream);
+}
+
+int run_conv(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
+             const int32_t* lengths, int len_default, int len_mul, int B, int C_x, int ldx, int ldo,
+             int Lmax, float slope, int epi, float mrf_div, hipStream_t stream) {
+  ConvIO io;
+  io.lengths_in = lengths; io.len_default = len_default; io.len_mul = len_mul;
+  return run_conv_ex(dc, x, out, res, acc, io, B, C_x, ldx, ldo, Lmax, slope, epi, mrf_div, stream);
+}
 
 }  // namespace dissc

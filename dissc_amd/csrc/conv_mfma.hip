@@ -24,19 +24,26 @@ namespace dissc {
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-template <int MI, int NI, int WM, int WN>
+__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+// STRIDE: input step per output position (1; 2 for HuBERT's strided feature convs).
+// SPAN: largest (KS-1)*dil the staging registers are sized for.
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BN = 16 * NI * WN;
-  constexpr int XW_MAX = (BN + MAX_TAP_SPAN + 3 + 31) / 32 * 32 + 16;
+  constexpr int XW_MAX = ((BN - 1) * STRIDE + 1 + SPAN + 3 + 31) / 32 * 32 + 16;
   constexpr int SV = (KC * (XW_MAX / 4) + NT - 1) / NT;  // float4 staging slots per thread
   constexpr int CW = 16 * NI + 4;                        // epilogue patch row stride
   extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x [KC][XW] | NW x [16][CW]
 
   const int b = blockIdx.z;
-  const int len = (a.lengths ? a.lengths[b] * a.len_mul : a.len_default);
+  const int len = (a.lengths ? a.lengths[b] * a.len_mul : a.len_default);  // valid INPUT positions
+  const int olen = a.lengths_out ? a.lengths_out[b] : (a.olen_default >= 0 ? a.olen_default : len);
   const int t0 = blockIdx.x * BN;
-  if (t0 >= len) return;
+  if (t0 >= olen) return;
+  const int grp = blockIdx.y / a.mt_per_group;
+  const int mt = blockIdx.y - grp * a.mt_per_group;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -45,13 +52,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
   const int l15 = lane & 15, g = lane >> 4;
   const int XW = a.XW;
   const int NV = XW >> 2;
-  const int halo = ((a.KS - 1) * a.dil) >> 1;
-  const int tb = (t0 - halo) & ~3;   // 16-byte aligned window start (may be negative)
-  const int sh = t0 - halo - tb;     // 0..3
+  const int tin0 = t0 * STRIDE - a.pad_left;
+  const int tb = tin0 & ~3;   // 16-byte aligned window start (may be negative)
+  const int sh = tin0 - tb;   // 0..3
   const int nq = a.nchunk * a.KS;
-  const int ms0 = blockIdx.y * (MI * WM) + wm * MI;
+  const int ms0 = mt * (MI * WM) + wm * MI;  // 16-row subtile within the group
   const float slope = a.slope;
-  const float* xb = a.x + (size_t)b * a.x_bstride;
+  const float* xb = a.x + (size_t)b * a.x_bstride + (size_t)grp * a.CIN * a.ldx;
 
   // this thread's float4 staging slots: slot i = tid + i*NT -> (row r, vec v)
   const int r0 = tid / NV, v0 = tid - r0 * NV;
@@ -106,7 +113,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
   f32x4 av[MI], avn[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)(ms0 + mi) * nq * 64 + lane;
+    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) +
+             ((size_t)grp * a.nsub_group + ms0 + mi) * nq * 64 + lane;
     av[mi] = wp[mi][0];
   }
 
@@ -119,7 +127,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
   _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                          \
       acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][CQ], BV[ni], acc[mi][ni], 0, 0, 0);
 
-  const int boff = g * XW + sh + wn * (16 * NI) + l15;
+  const int boff = g * XW + sh + (wn * (16 * NI) + l15) * STRIDE;
   const int XW4 = 4 * XW;
   int q = 0;
   for (int c = 0; c < a.nchunk; ++c) {
@@ -127,7 +135,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
     const bool more = c + 1 < a.nchunk;
     float b0[NI], b1[NI], b2[NI], b3[NI], b0n[NI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) b0[ni] = bj[ni * 16];
+    for (int ni = 0; ni < NI; ++ni) b0[ni] = bj[ni * 16 * STRIDE];
     for (int j = 0; j < a.KS; ++j, ++q) {
       const int qn = (q + 1 < nq) ? q + 1 : q;
 #pragma unroll
@@ -136,14 +144,14 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
       __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of the MFMAs
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        b1[ni] = bj[XW4 + ni * 16];
-        b2[ni] = bj[2 * XW4 + ni * 16];
-        b3[ni] = bj[3 * XW4 + ni * 16];
+        b1[ni] = bj[XW4 + ni * 16 * STRIDE];
+        b2[ni] = bj[2 * XW4 + ni * 16 * STRIDE];
+        b3[ni] = bj[3 * XW4 + ni * 16 * STRIDE];
       }
       DISSC_MFMA_STEP(0, b0)
       bj += a.dil;
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b0n[ni] = bj[ni * 16];  // next tap's first k-step
+      for (int ni = 0; ni < NI; ++ni) b0n[ni] = bj[ni * 16 * STRIDE];  // next tap's first k-step
       DISSC_MFMA_STEP(1, b1)
       DISSC_MFMA_STEP(2, b2)
       DISSC_MFMA_STEP(3, b3)
@@ -170,14 +178,14 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
       for (int r = 0; r < 4; ++r) {
         const int row = (ms0 + mi) * 16 + g * 4 + r;
         if (row >= a.M) continue;
-        const float bz = a.bias[row];
+        const float bz = a.bias[row];  // ConvTranspose path: groups == 1
         const int co = row / a.up;
         const int p = row - co * a.up;
         const size_t rowoff = ob + (size_t)co * a.ldo + p;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int t = tbase + ni * 16;
-          if (t < len) a.out[rowoff + (size_t)t * a.up] = acc[mi][ni][r] + bz;
+          if (t < olen) a.out[rowoff + (size_t)t * a.up] = acc[mi][ni][r] + bz;
         }
       }
     }
@@ -201,17 +209,21 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
 #pragma unroll
     for (int p = 0; p < NI; ++p) {
       const int rl = p * RPP + prow;
-      const int row = (ms0 + mi) * 16 + rl;
+      const int row = (ms0 + mi) * 16 + rl;  // within the group
       f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * CW + 4 * pc4);
-      if (row >= a.M || tcol >= len) continue;
-      const float bz = a.bias[row];
+      if (row >= a.M || tcol >= olen) continue;
+      const int prow_idx = grp * a.nsub_group * 16 + row;  // bias/scale/shift are [groups][Mpad]
+      const float bz = a.bias[prow_idx];
       v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
       if (a.scale) {  // eval-mode BatchNorm1d as PyTorch evaluates it: x * alpha + beta
-        const float sc = a.scale[row], sf = a.shift[row];
+        const float sc = a.scale[prow_idx], sf = a.shift[prow_idx];
         v[0] = v[0] * sc + sf; v[1] = v[1] * sc + sf; v[2] = v[2] * sc + sf; v[3] = v[3] * sc + sf;
       }
-      const size_t idx = ob + (size_t)row * a.ldo + tcol;
-      const int nv = len - tcol;  // >= 1
+      if (a.act == 1) {
+        v[0] = gelu_exact(v[0]); v[1] = gelu_exact(v[1]); v[2] = gelu_exact(v[2]); v[3] = gelu_exact(v[3]);
+      }
+      const size_t idx = ob + (size_t)(grp * a.M + row) * a.ldo + tcol;
+      const int nv = olen - tcol;  // >= 1
       if (nv >= 4) {
         if (epi == EPI_STORE) {
           *reinterpret_cast<f32x4*>(a.out + idx) = v;
@@ -301,31 +313,35 @@ int conv_tile_bn(int M) {
   return 16 * c.NI * c.WN;
 }
 
-int conv_xw(int M, int KS, int dil) {
-  const int need = conv_tile_bn(M) + (KS - 1) * dil + 3;  // +3: 16-byte aligned window start
+int conv_xw(int M, int KS, int dil, int stride) {
+  const int need = (conv_tile_bn(M) - 1) * stride + 1 + (KS - 1) * dil + 3;  // +3: aligned window start
   int xw = (need + 31) / 32 * 32 + 16;
   if (xw - 32 >= need) xw -= 32;
   return xw;
 }
 
+// w: [Cout][Cin][KS] with Cin = input channels PER GROUP; rows of group g are
+// [g*Cout/groups, (g+1)*Cout/groups).  Mpad = padded rows PER GROUP.
 void pack_conv_weights(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
-                       int& Mpad, int& nchunk) {
-  const int bm = pick_bm(Cout);
-  Mpad = (Cout + bm - 1) / bm * bm;
+                       int& Mpad, int& nchunk, int groups) {
+  const int Mg = Cout / groups;
+  const int bm = pick_bm(Mg);
+  Mpad = (Mg + bm - 1) / bm * bm;
   nchunk = (Cin + KC - 1) / KC;
   const int nsub = Mpad / 16;
-  packed.assign((size_t)nsub * nchunk * KS * 64 * 4, 0.f);
-  for (int ms = 0; ms < nsub; ++ms)
-    for (int c = 0; c < nchunk; ++c)
-      for (int j = 0; j < KS; ++j)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int cq = 0; cq < 4; ++cq) {
-            const int co = ms * 16 + (lane & 15);
-            const int ci = c * KC + cq * 4 + (lane >> 4);
-            if (co < Cout && ci < Cin)
-              packed[((((size_t)ms * nchunk + c) * KS + j) * 64 + lane) * 4 + cq] =
-                  w[((size_t)co * Cin + ci) * KS + j];
-          }
+  packed.assign((size_t)groups * nsub * nchunk * KS * 64 * 4, 0.f);
+  for (int gi = 0; gi < groups; ++gi)
+    for (int ms = 0; ms < nsub; ++ms)
+      for (int c = 0; c < nchunk; ++c)
+        for (int j = 0; j < KS; ++j)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int cq = 0; cq < 4; ++cq) {
+              const int co = ms * 16 + (lane & 15);
+              const int ci = c * KC + cq * 4 + (lane >> 4);
+              if (co < Mg && ci < Cin)
+                packed[(((((size_t)gi * nsub + ms) * nchunk + c) * KS + j) * 64 + lane) * 4 + cq] =
+                    w[((size_t)(gi * Mg + co) * Cin + ci) * KS + j];
+            }
 }
 
 void convT_to_conv(const float* w, int Cin, int Cout, int k, int s, std::vector<float>& w3) {
@@ -342,54 +358,68 @@ void convT_to_conv(const float* w, int Cin, int Cout, int k, int s, std::vector<
         }
 }
 
-template <int MI, int NI, int WM, int WN>
-static int launch_t(const ConvArgs& a, int B, int Lmax, hipStream_t stream) {
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN>
+static int launch_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, NW = WM * WN;
   constexpr int CW = 16 * NI + 4;
-  const int Mpad = (a.M + BM - 1) / BM * BM;
-  dim3 grid((Lmax + BN - 1) / BN, Mpad / BM, B);
+  a.mt_per_group = (a.M + BM - 1) / BM;
+  dim3 grid((Lmax_out + BN - 1) / BN, a.mt_per_group * a.groups, B);
   size_t lds_f = (size_t)2 * KC * a.XW;
   if (lds_f < (size_t)NW * 16 * CW) lds_f = (size_t)NW * 16 * CW;
   const size_t lds = lds_f * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_mfma_kernel<MI, NI, WM, WN>),
+        reinterpret_cast<const void*>(&conv_mfma_kernel<MI, NI, WM, WN, STRIDE, SPAN>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<MI, NI, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<MI, NI, WM, WN, STRIDE, SPAN>), grid, dim3(64 * WM * WN), lds,
+                     stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
 
-int launch_conv(const ConvArgs& a, int B, int Lmax, hipStream_t stream) {
-  if (B <= 0 || Lmax <= 0) return DISSC_OK;
+int launch_conv(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t stream) {
+  if (B <= 0 || Lmax_out <= 0) return DISSC_OK;
   if (B > 65535) {
     set_error("launch_conv: batch %d exceeds grid.z limit", B);
     return DISSC_EINVAL;
   }
-  if ((a.KS - 1) * a.dil > MAX_TAP_SPAN || (a.KS & 1) == 0) {
-    set_error("launch_conv: kernel %d x dilation %d unsupported (odd k, (k-1)*d <= %d)", a.KS, a.dil,
-              MAX_TAP_SPAN);
-    return DISSC_EINVAL;
-  }
+  const int span = (a.KS - 1) * a.dil;
   if ((a.ldx & 3) || (a.ldo & 3) || ((uintptr_t)a.x & 15) || ((uintptr_t)a.out & 15 && a.out) ||
       ((uintptr_t)a.res & 15) || ((uintptr_t)a.acc & 15)) {
     set_error("launch_conv: activations must be 16-byte aligned with row strides %% 4 == 0");
     return DISSC_EINVAL;
   }
-  switch (conv_cfg(a.M)) {
-    case 0: return launch_t<4, 4, 4, 1>(a, B, Lmax, stream);
-    case 1: return launch_t<4, 4, 2, 2>(a, B, Lmax, stream);
-    case 2: return launch_t<4, 4, 1, 4>(a, B, Lmax, stream);
-    case 3: return launch_t<2, 8, 1, 4>(a, B, Lmax, stream);
-    case 4: return launch_t<1, 8, 1, 4>(a, B, Lmax, stream);
-    case 5: return launch_t<2, 4, 1, 4>(a, B, Lmax, stream);
-    case 6: return launch_t<1, 4, 1, 4>(a, B, Lmax, stream);
-    case 7: return launch_t<2, 4, 2, 2>(a, B, Lmax, stream);
-    case 8: return launch_t<2, 4, 4, 1>(a, B, Lmax, stream);
-    default: return launch_t<4, 2, 4, 2>(a, B, Lmax, stream);
+  const int cfg = conv_cfg(a.M);
+  if (stride == 2 && span <= MAX_TAP_SPAN && a.up == 1) {
+    // HuBERT feature convs (512 -> 512, k3/k2 s2): only the 256x64 tile is instantiated
+    if (cfg == 0) return launch_t<4, 4, 4, 1, 2, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    set_error("launch_conv: stride 2 needs >= 256 output rows (got %d)", a.M);
+    return DISSC_EINVAL;
+  }
+  if (stride != 1) {
+    set_error("launch_conv: stride %d unsupported", stride);
+    return DISSC_EINVAL;
+  }
+  if (span > MAX_TAP_SPAN) {
+    // wide taps (HuBERT positional conv k=128, 48 rows per group): 32x256 tile only
+    if (span <= WIDE_TAP_SPAN && cfg == 5) return launch_t<2, 4, 1, 4, 1, WIDE_TAP_SPAN>(a, B, Lmax_out, stream);
+    set_error("launch_conv: kernel %d x dilation %d unsupported for %d rows", a.KS, a.dil, a.M);
+    return DISSC_EINVAL;
+  }
+  switch (cfg) {
+    case 0: return launch_t<4, 4, 4, 1, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 1: return launch_t<4, 4, 2, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 2: return launch_t<4, 4, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 3: return launch_t<2, 8, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 4: return launch_t<1, 8, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 5: return launch_t<2, 4, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 6: return launch_t<1, 4, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 7: return launch_t<2, 4, 2, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 8: return launch_t<2, 4, 4, 1, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    default: return launch_t<4, 2, 4, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
   }
 }
 

@@ -1,0 +1,615 @@
+// dissc_hubert_*: HuBERT-base unit encoder (CNN feature extractor -> projection -> positional
+// conv -> N post-LN transformer layers -> k-means assignment) on one MI355X.
+//
+// Replaces what data/encode.py:21-22,32 reaches through textless' SpeechEncoder: fairseq
+// HubertModel.extract_features(output_layer=6) and the k-means quantiser's predict()
+// (third-party code that is absent from the reference tree; algorithm restated in
+// oracle/hubert_ref.py, pinned to HF HubertModel + sklearn KMeans).
+//
+// Everything stays channels-first [B][C][ld] fp32 with time contiguous, so every dense layer
+// (strided feature convs, 1x1 projections, QKV/out/FFN linears, the grouped k=128 positional
+// conv, the centroid dot products) is the same fp32-MFMA implicit GEMM as the vocoder
+// (conv_mfma_kernel) with GELU / residual fused in its epilogue.  Attention is exact:
+// S = Q^T K (batched MFMA GEMM) -> row softmax -> O = V P^T (batched MFMA GEMM).
+// Ragged batches are per-utterance exact: GroupNorm statistics over valid frames only, zero
+// padding of the positional conv at each utterance's end, keys masked to T_b.
+#include <string.h>
+
+#include <map>
+#include <string>
+
+#include "common.h"
+
+namespace dissc {
+
+constexpr int NCONV = 7;
+__constant__ int c_k[NCONV] = {10, 3, 3, 3, 3, 2, 2};
+__constant__ int c_s[NCONV] = {5, 2, 2, 2, 2, 2, 2};
+
+// lens[l][b] = frames after conv layer l (0 when the utterance is too short)
+__global__ void hubert_lengths_kernel(const int32_t* __restrict__ n_samples, int B, int n_default,
+                                      int32_t* __restrict__ lens) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = n_samples ? n_samples[b] : n_default;
+  for (int l = 0; l < NCONV; ++l) {
+    n = n >= c_k[l] ? (n - c_k[l]) / c_s[l] + 1 : 0;
+    lens[l * B + b] = n;
+  }
+}
+
+// ---- conv0 (1 -> 512, k10, s5, no bias) + GroupNorm(512 groups) + GELU -----------------------
+constexpr int C0_TILE = 1024;  // outputs per block: 256 threads x 4
+constexpr int C0_CH = 512;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// pass 1: partial sums of x and x^2 per (b, tile, c) -> part[b][tile][c][2] (double)
+__global__ void __launch_bounds__(256) conv0_stats_kernel(const float* __restrict__ wav, int ldw,
+                                                          const float* __restrict__ w,
+                                                          const int32_t* __restrict__ len0, int ntile,
+                                                          double* __restrict__ part) {
+  __shared__ float red[4][2];
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const int T0 = len0[b];
+  const int t = tile * C0_TILE + threadIdx.x * 4;
+  double* pb = part + ((size_t)b * ntile + tile) * C0_CH * 2;
+  float s[25];
+  const float* wb = wav + (size_t)b * ldw;
+  const bool any = t < T0;
+#pragma unroll
+  for (int i = 0; i < 25; ++i) s[i] = (any && (5 * t + i) < 5 * (T0 - 1) + 10) ? wb[5 * t + i] : 0.f;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c = 0; c < C0_CH; ++c) {
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = 0.f;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) x = fmaf(w[c * 10 + j], s[5 * e + j], x);
+      if (t + e < T0) {
+        sum += x;
+        sq = fmaf(x, x, sq);
+      }
+    }
+    sum = wave_sum(sum);
+    sq = wave_sum(sq);
+    if (lane == 0) {
+      red[wv][0] = sum;
+      red[wv][1] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      pb[c * 2] = (double)red[0][0] + red[1][0] + red[2][0] + red[3][0];
+      pb[c * 2 + 1] = (double)red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    }
+    __syncthreads();
+  }
+}
+
+// reduce the tile partials in a fixed order -> mean / rstd per (b, c)
+__global__ void conv0_finalize_kernel(const double* __restrict__ part, const int32_t* __restrict__ len0,
+                                      int ntile, float eps, float* __restrict__ stats) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C0_CH) return;
+  const int T0 = len0[b];
+  const int nt = (T0 + C0_TILE - 1) / C0_TILE;
+  double s = 0, q = 0;
+  for (int i = 0; i < nt; ++i) {
+    s += part[(((size_t)b * ntile + i) * C0_CH + c) * 2];
+    q += part[(((size_t)b * ntile + i) * C0_CH + c) * 2 + 1];
+  }
+  const double n = T0 > 0 ? (double)T0 : 1.0;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0) var = 0;
+  stats[((size_t)b * C0_CH + c) * 2] = (float)mean;
+  stats[((size_t)b * C0_CH + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// pass 2: recompute conv0, normalise, affine, GELU, store [B][512][ld0]
+__global__ void __launch_bounds__(256) conv0_apply_kernel(const float* __restrict__ wav, int ldw,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ stats,
+                                                          const int32_t* __restrict__ len0,
+                                                          float* __restrict__ out, int ld0) {
+  const int b = blockIdx.y;
+  const int T0 = len0[b];
+  const int t = blockIdx.x * C0_TILE + threadIdx.x * 4;
+  if (t >= T0) return;
+  const float* wb = wav + (size_t)b * ldw;
+  float s[25];
+#pragma unroll
+  for (int i = 0; i < 25; ++i) s[i] = (5 * t + i) < 5 * (T0 - 1) + 10 ? wb[5 * t + i] : 0.f;
+  const float* st = stats + (size_t)b * C0_CH * 2;
+  float* ob = out + (size_t)b * C0_CH * ld0 + t;
+  for (int c = 0; c < C0_CH; ++c) {
+    const float mean = st[c * 2], rstd = st[c * 2 + 1], ga = gamma[c], be = beta[c];
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = 0.f;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) x = fmaf(w[c * 10 + j], s[5 * e + j], x);
+      x = (x - mean) * rstd * ga + be;
+      y[e] = 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    }
+    if (t + 3 < T0) {
+      *reinterpret_cast<f32x4*>(ob + (size_t)c * ld0) = y;
+    } else {
+      for (int e = 0; e < 4 && t + e < T0; ++e) ob[(size_t)c * ld0 + e] = y[e];
+    }
+  }
+}
+
+// ---- LayerNorm over channels of a channels-first tensor (optionally of x + r) ----------------
+__global__ void __launch_bounds__(128) ln_cf_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta,
+                                                    const int32_t* __restrict__ lens, int C, int ld,
+                                                    float eps, float* __restrict__ y) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lens[b]) return;
+  const size_t base = (size_t)b * C * ld + t;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += x[base + (size_t)c * ld] + (r ? r[base + (size_t)c * ld] : 0.f);
+  const float mean = s / (float)C;
+  float q = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float d = x[base + (size_t)c * ld] + (r ? r[base + (size_t)c * ld] : 0.f) - mean;
+    q = fmaf(d, d, q);
+  }
+  const float rstd = 1.f / sqrtf(q / (float)C + eps);
+  for (int c = 0; c < C; ++c) {
+    const float v = x[base + (size_t)c * ld] + (r ? r[base + (size_t)c * ld] : 0.f);
+    y[base + (size_t)c * ld] = (v - mean) * rstd * gamma[c] + beta[c];
+  }
+}
+
+// ---- batched fp32 MFMA GEMM for attention: C[z] = alpha * A[z] (MxK) * B[z] (KxN) ------------
+struct BGemmArgs {
+  const float* A; const float* B; float* C;
+  long long a_bs, a_hs, b_bs, b_hs, c_bs, c_hs;  // per-utterance / per-head offsets (floats)
+  long long sam, sak, sbk, sbn, scm;             // element strides; C is n-contiguous
+  const int32_t* lens;                           // T_b
+  int m_is_t, n_is_t, k_is_t, fixed;             // dims: T_b where the flag is set, else `fixed`
+  int H;
+  float alpha;
+};
+constexpr int BG_LD = 80;  // LDS row stride: 80 % 32 == 16 -> conflict-free fragment reads
+
+__global__ void __launch_bounds__(256) bgemm_kernel(const BGemmArgs a) {
+  __shared__ float As[16 * BG_LD];
+  __shared__ float Bs[16 * BG_LD];
+  const int z = blockIdx.z, b = z / a.H, h = z - b * a.H;
+  const int T = a.lens[b];
+  const int M = a.m_is_t ? T : a.fixed, N = a.n_is_t ? T : a.fixed, K = a.k_is_t ? T : a.fixed;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  if (m0 >= M || n0 >= N) return;
+  const float* A = a.A + b * a.a_bs + h * a.a_hs;
+  const float* B = a.B + b * a.b_bs + h * a.b_hs;
+  float* C = a.C + b * a.c_bs + h * a.c_hs;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool a_mfast = a.sam == 1, b_nfast = a.sbn == 1;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      int kk, mm;
+      if (a_mfast) { kk = e >> 6; mm = e & 63; } else { mm = e >> 4; kk = e & 15; }
+      float v = 0.f;
+      if (m0 + mm < M && k0 + kk < K) v = A[(long long)(m0 + mm) * a.sam + (long long)(k0 + kk) * a.sak];
+      As[kk * BG_LD + mm] = v;
+      int nn;
+      if (b_nfast) { kk = e >> 6; nn = e & 63; } else { nn = e >> 4; kk = e & 15; }
+      v = 0.f;
+      if (n0 + nn < N && k0 + kk < K) v = B[(long long)(k0 + kk) * a.sbk + (long long)(n0 + nn) * a.sbn];
+      Bs[kk * BG_LD + nn] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[i] = As[(g + 4 * cq) * BG_LD + wm * 32 + i * 16 + l15];
+        bv[i] = Bs[(g + 4 * cq) * BG_LD + wn * 32 + i * 16 + l15];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 32 + i * 16 + 4 * g + r;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 32 + j * 16 + l15;
+        if (n < N) C[(long long)m * a.scm + n] = a.alpha * acc[i][j][r];
+      }
+    }
+}
+
+// in-place softmax over the first T_b entries of every row of S[b][h][i][:]
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S,
+                                                           const int32_t* __restrict__ lens, int H,
+                                                           int Tmax, int ldS) {
+  const int b = blockIdx.z;
+  const int T = lens[b];
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per row
+  const int h = blockIdx.y;
+  if (row >= T) return;
+  float* p = S + (((size_t)b * H + h) * Tmax + row) * ldS;
+  const int lane = threadIdx.x & 63;
+  float mx = -INFINITY;
+  for (int j = lane; j < T; j += 64) mx = fmaxf(mx, p[j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float sum = 0.f;
+  for (int j = lane; j < T; j += 64) {
+    const float e = expf(p[j] - mx);
+    p[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  for (int j = lane; j < T; j += 64) p[j] = __fdiv_rn(p[j], sum);
+}
+
+// units[b][t] = argmin_k (cnorm[k] - 2 * xc[b][k][t]), lowest index on ties
+__global__ void kmeans_argmin_kernel(const float* __restrict__ xc, const float* __restrict__ cnorm,
+                                     const int32_t* __restrict__ lens, int K, int Kld, int ld, int T,
+                                     int64_t* __restrict__ units) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  int64_t best = 0;
+  if (t < lens[b]) {
+    float bv = INFINITY;
+    const float* p = xc + (size_t)b * Kld * ld + t;
+    for (int k = 0; k < K; ++k) {
+      const float d = cnorm[k] - 2.f * p[(size_t)k * ld];
+      if (d < bv) {
+        bv = d;
+        best = k;
+      }
+    }
+  }
+  units[(size_t)b * T + t] = best;
+}
+
+}  // namespace dissc
+
+using namespace dissc;
+
+struct dissc_hubert {
+  int n_layers = 6, H = 12, D = 768, F = 3072, CF = 512, K = 0;
+  float* w0 = nullptr;   // conv0 [512][10]
+  float* gn_g = nullptr; // GroupNorm affine
+  float* gn_b = nullptr;
+  std::vector<DevConv> fconv;  // feature convs 1..6 (stride 2, GELU)
+  float *ln0_g = nullptr, *ln0_b = nullptr;  // feature LayerNorm(512)
+  DevConv proj, pos, kmeans;
+  float *eln_g = nullptr, *eln_b = nullptr;  // encoder.layer_norm
+  struct Layer {
+    DevConv qkv, out, fc1, fc2;
+    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+  };
+  std::vector<Layer> layers;
+  float* cnorm = nullptr;
+  ~dissc_hubert() {
+    for (float* p : {w0, gn_g, gn_b, ln0_g, ln0_b, eln_g, eln_b, cnorm})
+      if (p) (void)hipFree(p);
+    for (auto& c : fconv) free_conv(c);
+    free_conv(proj); free_conv(pos); free_conv(kmeans);
+    for (auto& l : layers) {
+      free_conv(l.qkv); free_conv(l.out); free_conv(l.fc1); free_conv(l.fc2);
+      for (float* p : {l.ln1_g, l.ln1_b, l.ln2_g, l.ln2_b})
+        if (p) (void)hipFree(p);
+    }
+  }
+};
+
+static inline size_t rup(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+static int frames_of(int n) {
+  static const int k[NCONV] = {10, 3, 3, 3, 3, 2, 2}, s[NCONV] = {5, 2, 2, 2, 2, 2, 2};
+  for (int l = 0; l < NCONV; ++l) n = n >= k[l] ? (n - k[l]) / s[l] + 1 : 0;
+  return n;
+}
+static int frames_after(int n, int upto) {
+  static const int k[NCONV] = {10, 3, 3, 3, 3, 2, 2}, s[NCONV] = {5, 2, 2, 2, 2, 2, 2};
+  for (int l = 0; l <= upto; ++l) n = n >= k[l] ? (n - k[l]) / s[l] + 1 : 0;
+  return n;
+}
+
+extern "C" {
+
+int dissc_hubert_frames(int n_samples) { return frames_of(n_samples); }
+
+int dissc_hubert_create(int n_layers, const DisscTensor* weights, size_t n_weights,
+                        const float* centers, int n_centers, dissc_hubert_t* out) {
+  if (!weights || !out || n_layers < 1 || n_layers > 12) {
+    set_error("dissc_hubert_create: bad argument");
+    return DISSC_EINVAL;
+  }
+  std::map<std::string, const DisscTensor*> by;
+  for (size_t i = 0; i < n_weights; ++i) by[weights[i].name] = &weights[i];
+  dissc_hubert* m = new dissc_hubert();
+  m->n_layers = n_layers;
+  int rc = DISSC_OK;
+  auto fail = [&](int code) {
+    delete m;
+    return code;
+  };
+  auto get = [&](const std::string& name, size_t numel, const float** p) -> int {
+    auto it = by.find(name);
+    if (it == by.end()) {
+      set_error("dissc_hubert_create: missing tensor '%s'", name.c_str());
+      return DISSC_ENOTFOUND;
+    }
+    size_t n = 1;
+    for (int d = 0; d < it->second->ndim; ++d) n *= (size_t)it->second->shape[d];
+    if (n != numel) {
+      set_error("dissc_hubert_create: tensor '%s' has %zu elements, expected %zu", name.c_str(), n, numel);
+      return DISSC_EINVAL;
+    }
+    *p = it->second->data;
+    return DISSC_OK;
+  };
+  auto up = [&](const std::string& name, size_t numel, float** d) -> int {
+    const float* p;
+    int r = get(name, numel, &p);
+    if (r) return r;
+    return upload(std::vector<float>(p, p + numel), d);
+  };
+  const int D = m->D, F = m->F, CF = m->CF;
+  const float *w, *b;
+  if ((rc = up("feature_extractor.conv_layers.0.0.weight", (size_t)CF * 10, &m->w0))) return fail(rc);
+  if ((rc = up("feature_extractor.conv_layers.0.2.weight", CF, &m->gn_g))) return fail(rc);
+  if ((rc = up("feature_extractor.conv_layers.0.2.bias", CF, &m->gn_b))) return fail(rc);
+  static const int ks[NCONV] = {10, 3, 3, 3, 3, 2, 2};
+  m->fconv.resize(NCONV - 1);
+  for (int l = 1; l < NCONV; ++l) {
+    char name[96];
+    snprintf(name, sizeof(name), "feature_extractor.conv_layers.%d.0.weight", l);
+    if ((rc = get(name, (size_t)CF * CF * ks[l], &w))) return fail(rc);
+    if ((rc = make_conv(w, nullptr, CF, CF, ks[l], 1, m->fconv[l - 1], 1, 2, 0))) return fail(rc);
+    m->fconv[l - 1].act = 1;
+  }
+  if ((rc = up("layer_norm.weight", CF, &m->ln0_g)) || (rc = up("layer_norm.bias", CF, &m->ln0_b)))
+    return fail(rc);
+  if ((rc = get("post_extract_proj.weight", (size_t)D * CF, &w)) || (rc = get("post_extract_proj.bias", D, &b)))
+    return fail(rc);
+  if ((rc = make_conv(w, b, D, CF, 1, 1, m->proj, 1, 1, 0))) return fail(rc);
+  // positional conv: weight already folded (weight_norm dim=2) by the caller: [768][48][128]
+  if ((rc = get("encoder.pos_conv.0.weight", (size_t)D * 48 * 128, &w)) ||
+      (rc = get("encoder.pos_conv.0.bias", D, &b)))
+    return fail(rc);
+  if ((rc = make_conv(w, b, D, D, 128, 1, m->pos, 16, 1, 64))) return fail(rc);
+  m->pos.act = 1;
+  if ((rc = up("encoder.layer_norm.weight", D, &m->eln_g)) || (rc = up("encoder.layer_norm.bias", D, &m->eln_b)))
+    return fail(rc);
+  m->layers.resize(n_layers);
+  for (int i = 0; i < n_layers; ++i) {
+    char pre[64];
+    snprintf(pre, sizeof(pre), "encoder.layers.%d.", i);
+    std::string p(pre);
+    auto& L = m->layers[i];
+    const float *wq, *wk, *wv, *bq, *bk, *bv;
+    if ((rc = get(p + "self_attn.q_proj.weight", (size_t)D * D, &wq)) || (rc = get(p + "self_attn.q_proj.bias", D, &bq)) ||
+        (rc = get(p + "self_attn.k_proj.weight", (size_t)D * D, &wk)) || (rc = get(p + "self_attn.k_proj.bias", D, &bk)) ||
+        (rc = get(p + "self_attn.v_proj.weight", (size_t)D * D, &wv)) || (rc = get(p + "self_attn.v_proj.bias", D, &bv)))
+      return fail(rc);
+    std::vector<float> wqkv((size_t)3 * D * D), bqkv(3 * D);
+    const float scale = 1.f / sqrtf((float)(D / m->H));  // 0.125: exact in fp32
+    for (size_t e = 0; e < (size_t)D * D; ++e) wqkv[e] = wq[e] * scale;
+    memcpy(wqkv.data() + (size_t)D * D, wk, (size_t)D * D * 4);
+    memcpy(wqkv.data() + (size_t)2 * D * D, wv, (size_t)D * D * 4);
+    for (int e = 0; e < D; ++e) bqkv[e] = bq[e] * scale;
+    memcpy(bqkv.data() + D, bk, D * 4);
+    memcpy(bqkv.data() + 2 * D, bv, D * 4);
+    if ((rc = make_conv(wqkv.data(), bqkv.data(), 3 * D, D, 1, 1, L.qkv, 1, 1, 0))) return fail(rc);
+    if ((rc = get(p + "self_attn.out_proj.weight", (size_t)D * D, &w)) || (rc = get(p + "self_attn.out_proj.bias", D, &b)))
+      return fail(rc);
+    if ((rc = make_conv(w, b, D, D, 1, 1, L.out, 1, 1, 0))) return fail(rc);
+    if ((rc = get(p + "fc1.weight", (size_t)F * D, &w)) || (rc = get(p + "fc1.bias", F, &b))) return fail(rc);
+    if ((rc = make_conv(w, b, F, D, 1, 1, L.fc1, 1, 1, 0))) return fail(rc);
+    L.fc1.act = 1;
+    if ((rc = get(p + "fc2.weight", (size_t)D * F, &w)) || (rc = get(p + "fc2.bias", D, &b))) return fail(rc);
+    if ((rc = make_conv(w, b, D, F, 1, 1, L.fc2, 1, 1, 0))) return fail(rc);
+    if ((rc = up(p + "self_attn_layer_norm.weight", D, &L.ln1_g)) || (rc = up(p + "self_attn_layer_norm.bias", D, &L.ln1_b)) ||
+        (rc = up(p + "final_layer_norm.weight", D, &L.ln2_g)) || (rc = up(p + "final_layer_norm.bias", D, &L.ln2_b)))
+      return fail(rc);
+  }
+  if (centers && n_centers > 0) {
+    m->K = n_centers;
+    if ((rc = make_conv(centers, nullptr, n_centers, D, 1, 1, m->kmeans, 1, 1, 0))) return fail(rc);
+    std::vector<float> cn(n_centers);
+    for (int k = 0; k < n_centers; ++k) {
+      float s = 0.f;
+      for (int d = 0; d < D; ++d) s += centers[(size_t)k * D + d] * centers[(size_t)k * D + d];
+      cn[k] = s;
+    }
+    if ((rc = upload(cn, &m->cnorm))) return fail(rc);
+  }
+  *out = m;
+  return DISSC_OK;
+}
+
+void dissc_hubert_destroy(dissc_hubert_t m) { delete m; }
+
+// workspace carve-up (floats unless noted)
+struct HubertWs {
+  int32_t* lens;     // [7][B]
+  double* part;      // [B][ntile][512][2]
+  float* stats;      // [B][512][2]
+  float* f[2];       // ping-pong feature buffers, each B*512*ld0 floats
+  float *x, *y, *t1; // [B][768][ldT]
+  float* qkv;        // [B][2304][ldT]
+  float* ffn;        // [B][3072][ldT]
+  float* S;          // [B][H][T][ldS]
+  float* xc;         // [B][Kpad][ldT]
+  size_t bytes;
+};
+
+static HubertWs carve(const dissc_hubert* m, int B, int Nmax, void* base_) {
+  HubertWs w;
+  char* p = (char*)rup((size_t)base_, 256);
+  char* p0 = p;
+  const int T0 = frames_after(Nmax, 0), T = frames_of(Nmax);
+  const size_t ld0 = rup(T0 > 0 ? T0 : 1, 4), ldT = rup(T > 0 ? T : 1, 4);
+  const int ntile = (T0 + C0_TILE - 1) / C0_TILE + 1;
+  auto take = [&](size_t bytes) {
+    char* r = p;
+    p += rup(bytes, 256);
+    return r;
+  };
+  w.lens = (int32_t*)take((size_t)NCONV * B * 4);
+  w.part = (double*)take((size_t)B * ntile * C0_CH * 2 * 8);
+  w.stats = (float*)take((size_t)B * C0_CH * 2 * 4);
+  w.f[0] = (float*)take((size_t)B * 512 * ld0 * 4);
+  const size_t ld1 = rup(frames_after(Nmax, 1) > 0 ? frames_after(Nmax, 1) : 1, 4);
+  w.f[1] = (float*)take((size_t)B * 512 * ld1 * 4);
+  w.x = (float*)take((size_t)B * m->D * ldT * 4);
+  w.y = (float*)take((size_t)B * m->D * ldT * 4);
+  w.t1 = (float*)take((size_t)B * m->D * ldT * 4);
+  w.qkv = (float*)take((size_t)B * 3 * m->D * ldT * 4);
+  w.ffn = (float*)take((size_t)B * m->F * ldT * 4);
+  w.S = (float*)take((size_t)B * m->H * (size_t)(T > 0 ? T : 1) * ldT * 4);
+  w.xc = (float*)take((size_t)B * rup(m->K > 0 ? m->K : 1, 128) * ldT * 4);
+  w.bytes = (size_t)(p - p0) + 256;
+  return w;
+}
+
+size_t dissc_hubert_workspace_bytes(dissc_hubert_t m, int B, int Nmax) {
+  if (!m || B <= 0 || Nmax <= 0) return 0;
+  return carve(m, B, Nmax, nullptr).bytes;
+}
+
+int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_samples, int B, int Nmax,
+                         float* dense_out, int64_t* units_out, void* workspace, size_t ws_bytes,
+                         void* stream_) {
+  if (!m || !wav || !workspace || B <= 0 || Nmax <= 0 || (units_out && m->K <= 0)) {
+    set_error("dissc_hubert_forward: bad argument");
+    return DISSC_EINVAL;
+  }
+  if (ws_bytes < dissc_hubert_workspace_bytes(m, B, Nmax)) {
+    set_error("dissc_hubert_forward: workspace %zu < %zu bytes", ws_bytes,
+              dissc_hubert_workspace_bytes(m, B, Nmax));
+    return DISSC_ENOMEM;
+  }
+  hipStream_t st = (hipStream_t)stream_;
+  HubertWs w = carve(m, B, Nmax, workspace);
+  const int T0 = frames_after(Nmax, 0), T = frames_of(Nmax);
+  if (T <= 0) {
+    set_error("dissc_hubert_forward: %d samples give no frame (need >= 400)", Nmax);
+    return DISSC_EINVAL;
+  }
+  const int ld0 = (int)rup(T0, 4), ldT = (int)rup(T, 4);
+  const int ntile = (T0 + C0_TILE - 1) / C0_TILE + 1;
+  const int D = m->D, H = m->H, hd = D / H;
+  int rc;
+  hipLaunchKernelGGL(hubert_lengths_kernel, dim3((B + 63) / 64), dim3(64), 0, st, n_samples, B, Nmax, w.lens);
+  // conv0 + GroupNorm + GELU
+  dim3 g0((T0 + C0_TILE - 1) / C0_TILE, B);
+  hipLaunchKernelGGL(conv0_stats_kernel, g0, dim3(256), 0, st, wav, Nmax, m->w0, w.lens, ntile, w.part);
+  hipLaunchKernelGGL(conv0_finalize_kernel, dim3(C0_CH / 128, B), dim3(128), 0, st, w.part, w.lens, ntile,
+                     1e-5f, w.stats);
+  hipLaunchKernelGGL(conv0_apply_kernel, g0, dim3(256), 0, st, wav, Nmax, m->w0, m->gn_g, m->gn_b, w.stats,
+                     w.lens, w.f[0], ld0);
+  // strided feature convs (GELU fused), ping-pong
+  int cur = 0, ld_in = ld0, n_in = Nmax;
+  n_in = T0;
+  for (int l = 1; l < NCONV; ++l) {
+    const int n_out = frames_after(Nmax, l);
+    const int ld_out = (int)rup(n_out > 0 ? n_out : 1, 4);
+    ConvIO io;
+    io.lengths_in = w.lens + (size_t)(l - 1) * B;
+    io.lengths_out = w.lens + (size_t)l * B;
+    if ((rc = run_conv_ex(m->fconv[l - 1], w.f[cur], w.f[cur ^ 1], nullptr, io, B, 512, ld_in, ld_out, n_out,
+                          1.0f, EPI_STORE, st)))
+      return rc;
+    cur ^= 1;
+    ld_in = ld_out;
+    n_in = n_out;
+  }
+  (void)n_in;
+  const int32_t* lensT = w.lens + (size_t)(NCONV - 1) * B;
+  ConvIO ioT;
+  ioT.lengths_in = lensT;
+  dim3 gln((T + 127) / 128, B);
+  // LayerNorm(512) -> Linear(512,768)
+  float* fn = w.f[cur ^ 1];  // free buffer, [B][512][ldT] fits (ldT <= ld of that buffer)
+  hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(128), 0, st, w.f[cur], (const float*)nullptr, m->ln0_g, m->ln0_b,
+                     lensT, 512, ldT, 1e-5f, fn);
+  if ((rc = run_conv_ex(m->proj, fn, w.x, nullptr, ioT, B, 512, ldT, ldT, T, 1.0f, EPI_STORE, st))) return rc;
+  // x = LN(x + GELU(pos_conv(x)))
+  if ((rc = run_conv_ex(m->pos, w.x, w.y, w.x, ioT, B, D, ldT, ldT, T, 1.0f, EPI_RES, st))) return rc;
+  hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(128), 0, st, w.y, (const float*)nullptr, m->eln_g, m->eln_b, lensT,
+                     D, ldT, 1e-5f, w.x);
+  for (int i = 0; i < m->n_layers; ++i) {
+    auto& L = m->layers[i];
+    if ((rc = run_conv_ex(L.qkv, w.x, w.qkv, nullptr, ioT, B, D, ldT, ldT, T, 1.0f, EPI_STORE, st))) return rc;
+    BGemmArgs a;
+    // S[b,h][i][j] = sum_d Q[d][i] K[d][j]      (Q already scaled by 1/sqrt(hd))
+    a.A = w.qkv; a.B = w.qkv + (size_t)D * ldT; a.C = w.S;
+    a.a_bs = (long long)3 * D * ldT; a.a_hs = (long long)hd * ldT; a.b_bs = a.a_bs; a.b_hs = a.a_hs;
+    a.c_bs = (long long)H * T * ldT; a.c_hs = (long long)T * ldT;
+    a.sam = 1; a.sak = ldT; a.sbk = ldT; a.sbn = 1; a.scm = ldT;
+    a.lens = lensT; a.m_is_t = 1; a.n_is_t = 1; a.k_is_t = 0; a.fixed = hd; a.H = H; a.alpha = 1.f;
+    dim3 gs((T + 63) / 64, (T + 63) / 64, B * H);
+    hipLaunchKernelGGL(bgemm_kernel, gs, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((T + 3) / 4, H, B), dim3(256), 0, st, w.S, lensT, H, T, ldT);
+    // O[h*hd + d][i] = sum_j V[d][j] P[i][j]  -> t1 (channels-first)
+    a.A = w.qkv + (size_t)2 * D * ldT; a.B = w.S; a.C = w.t1;
+    a.a_bs = (long long)3 * D * ldT; a.a_hs = (long long)hd * ldT;
+    a.b_bs = (long long)H * T * ldT; a.b_hs = (long long)T * ldT;
+    a.c_bs = (long long)D * ldT; a.c_hs = (long long)hd * ldT;
+    a.sam = ldT; a.sak = 1; a.sbk = 1; a.sbn = ldT; a.scm = ldT;
+    a.m_is_t = 0; a.n_is_t = 1; a.k_is_t = 1; a.fixed = hd;
+    dim3 go((T + 63) / 64, (hd + 63) / 64, B * H);
+    hipLaunchKernelGGL(bgemm_kernel, go, dim3(256), 0, st, a);
+    // x = LN(x + out_proj(O))
+    if ((rc = run_conv_ex(L.out, w.t1, w.y, w.x, ioT, B, D, ldT, ldT, T, 1.0f, EPI_RES, st))) return rc;
+    hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(128), 0, st, w.y, (const float*)nullptr, L.ln1_g, L.ln1_b, lensT, D,
+                       ldT, 1e-5f, w.x);
+    // x = LN(x + fc2(GELU(fc1(x))))
+    if ((rc = run_conv_ex(L.fc1, w.x, w.ffn, nullptr, ioT, B, D, ldT, ldT, T, 1.0f, EPI_STORE, st))) return rc;
+    if ((rc = run_conv_ex(L.fc2, w.ffn, w.y, w.x, ioT, B, m->F, ldT, ldT, T, 1.0f, EPI_RES, st))) return rc;
+    hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(128), 0, st, w.y, (const float*)nullptr, L.ln2_g, L.ln2_b, lensT, D,
+                       ldT, 1e-5f, w.x);
+  }
+  if (dense_out)  // [B][768][ldT] channels-first
+    DISSC_HIP_CHECK(hipMemcpyAsync(dense_out, w.x, (size_t)B * D * ldT * 4, hipMemcpyDeviceToDevice, st));
+  if (units_out) {
+    if ((rc = run_conv_ex(m->kmeans, w.x, w.xc, nullptr, ioT, B, D, ldT, ldT, T, 1.0f, EPI_STORE, st))) return rc;
+    hipLaunchKernelGGL(kmeans_argmin_kernel, dim3((T + 127) / 128, B), dim3(128), 0, st, w.xc, m->cnorm, lensT,
+                       m->K, m->K, ldT, T, units_out);
+  }
+  DISSC_HIP_CHECK(hipGetLastError());
+  return DISSC_OK;
+}
+
+}  // extern "C"

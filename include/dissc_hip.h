@@ -166,6 +166,34 @@ int dissc_len_carryover(const float* lens, const int32_t* n, int B, int ld, int3
 int dissc_expand(const int64_t* vals, const int32_t* lens_int, const int32_t* n, int B, int ld_in,
                  int64_t* out, int ld_out, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * HuBERT-base unit encoder + k-means quantiser.
+ * Replaces: textless SpeechEncoder.__call__ as used at reference data/encode.py:21-22,32
+ *   = fairseq HubertModel.extract_features(source, mask=False, output_layer=n_layers)
+ *   + KMeansQuantizer.predict.  Those libraries are un-vendored third parties (fairseq @
+ *   dd106d95, textlesslib HEAD; reference README.md:31-34); the algorithm is restated in
+ *   oracle/hubert_ref.py and pinned to HF transformers.HubertModel + sklearn KMeans.
+ * weights: fairseq checkpoint names ("feature_extractor.conv_layers.{i}.0.weight",
+ *   "feature_extractor.conv_layers.0.2.weight/bias", "layer_norm.*", "post_extract_proj.*",
+ *   "encoder.pos_conv.0.weight" (weight-norm already folded, [768,48,128]) / ".bias",
+ *   "encoder.layer_norm.*", "encoder.layers.{i}.self_attn.{q,k,v,out}_proj.*",
+ *   ".self_attn_layer_norm.*", ".fc1.*", ".fc2.*", ".final_layer_norm.*").
+ * centers: host f32 [n_centers,768] k-means centroids (NULL = dense features only).
+ * ------------------------------------------------------------------------- */
+typedef struct dissc_hubert* dissc_hubert_t;
+int dissc_hubert_create(int n_layers, const DisscTensor* weights, size_t n_weights,
+                        const float* centers, int n_centers, dissc_hubert_t* out);
+void dissc_hubert_destroy(dissc_hubert_t m);
+/* frames produced for n_samples input samples: floor((n-400)/320)+1 for n >= 400 */
+int dissc_hubert_frames(int n_samples);
+size_t dissc_hubert_workspace_bytes(dissc_hubert_t m, int B, int Nmax);
+/* wav f32 [B,Nmax] (16 kHz, un-normalised like hubert-base), n_samples i32 [B] (NULL = Nmax)
+ * -> dense_out f32 [B,768,ldT] channels-first, ldT = frames(Nmax) rounded up to 4 (may be NULL)
+ *    units_out i64 [B,frames(Nmax)] (may be NULL).  Each utterance is exact w.r.t. a B=1 run. */
+int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_samples, int B, int Nmax,
+                         float* dense_out, int64_t* units_out, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* Diagnostics: sustained fp32 v_mfma_f32_16x16x4_f32 rate (TFLOP/s) of this GPU at its
  * real clocks -- the practical ceiling the conv kernels are compared with. */
 int dissc_mfma_peak(int iters, float* tflops);
