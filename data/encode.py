@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""wav directory -> units JSONL with the HuBERT-base + k-means-100 encoder on MI355X.
+
+Same command line and output format as the reference's data/encode.py (reference
+data/encode.py:11-41): one line ``{"units": [...], "f0": [...], "durations": [...],
+"audio": file}`` per wav in ``--base_dir`` (os.listdir order), appended to ``--out_file``.
+
+Differences in execution: files are encoded in length-sorted batches through the HIP encoder
+(per-utterance exact) instead of one B=1 call each, and written in listdir order afterwards.
+Checkpoints are not downloaded (no network): ``--checkpoint_dir`` / $DISSC_CHECKPOINT_DIR must
+hold ``<model_name>.pt`` and ``<quantizer_name>_<vocab_size>.{npy,bin,pt}``.
+``f0`` is written as zeros: the YAAPT tracker is off the --pred_pitch path,
+where infer.py never reads it (reference infer.py:36-39,149-155).
+"""
+import argparse
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+from scipy.io import wavfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def load_wav(path):
+    """torchaudio.load semantics for 16-bit PCM: float32 in [-1, 1), [1, N] (first channel)."""
+    sr, x = wavfile.read(path)
+    if x.ndim > 1:
+        x = x[:, 0]
+    if x.dtype == np.int16:
+        x = x.astype(np.float32) / 32768.0
+    elif x.dtype == np.int32:
+        x = x.astype(np.float32) / 2147483648.0
+    elif x.dtype == np.uint8:
+        x = (x.astype(np.float32) - 128.0) / 128.0
+    else:
+        x = x.astype(np.float32)
+    return x, sr
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--model_name', default='hubert-base-ls960', help='Name for pretrained dense model name')
+    parser.add_argument('--quantizer_name', default='kmeans', help='Name for quantising the hidden units')
+    parser.add_argument('--vocab_size', default=100, type=int, help='number of unique HuBERT clusters to used')
+    parser.add_argument('--base_dir', default='ESD/wav/train', help='Input audio file path')
+    parser.add_argument('--out_file', default='ESD/hubert100/train.txt', help='Output path')
+    parser.add_argument('--device', default='cuda:0', help='Device to run on')
+    parser.add_argument('--checkpoint_dir', default=None, help='local directory with the HuBERT / k-means files')
+    parser.add_argument('--batch_seconds', default=640.0, type=float, help='audio seconds per GPU batch')
+    args = parser.parse_args(argv)
+
+    from dissc_amd.hubert import SpeechEncoder
+    encoder = SpeechEncoder.by_name(dense_model_name=args.model_name, quantizer_model_name=args.quantizer_name,
+                                    vocab_size=args.vocab_size, deduplicate=False,
+                                    checkpoint_dir=args.checkpoint_dir).to(args.device)
+    os.makedirs(Path(args.out_file).parent.absolute(), exist_ok=True)
+    files = os.listdir(args.base_dir)
+    waves = {}
+    for f in files:
+        x, sr = load_wav(os.path.join(args.base_dir, f))
+        if len(x) < 400:
+            print(f"\nProblem encoding sample {f}: shorter than one HuBERT frame")
+            continue
+        waves[f] = x
+    order = sorted(waves, key=lambda f: -len(waves[f]))
+    results = {}
+    i = 0
+    while i < len(order):
+        n0 = len(waves[order[i]])
+        bsz = max(1, int(args.batch_seconds * 16000 // n0))
+        batch = order[i:i + bsz]
+        i += len(batch)
+        wav = np.zeros((len(batch), n0), dtype=np.float32)
+        ns = np.zeros(len(batch), dtype=np.int32)
+        for k, f in enumerate(batch):
+            wav[k, :len(waves[f])] = waves[f]
+            ns[k] = len(waves[f])
+        out = encoder.model(torch.from_numpy(wav), n_samples=torch.from_numpy(ns), want_dense=False)
+        units = out["units"].cpu()
+        for k, f in enumerate(batch):
+            T = int(out["frames"][k])
+            results[f] = units[k, :T].tolist()
+    with open(args.out_file, 'a+') as fo:
+        for f in files:
+            if f not in results:
+                continue
+            u = results[f]
+            fo.write(json.dumps({"units": u, "f0": [0.0] * len(u), "durations": [1] * len(u), "audio": f}) + "\n")
+
+
+if __name__ == '__main__':
+    main()

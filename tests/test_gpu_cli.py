@@ -94,3 +94,31 @@ def test_sr_inference_cli_matches_reference(gpu, golden_dir, tmp_path):
             assert d.max() <= 1e-4, (fn, d.max())
             assert np.sqrt(np.mean(d ** 2)) <= 1e-5
             assert (d > 1e-6).mean() <= 0.02
+
+
+def test_encode_cli_roundtrip(gpu, golden_dir, tmp_path):
+    """data/encode.py on the reference's two fixture wavs: units equal the CPU oracle's."""
+    from oracle import hubert_ref as hr
+    from oracle import synth
+    td = str(tmp_path)
+    os.makedirs(f"{td}/ckpt")
+    os.makedirs(f"{td}/wav")
+    sd = synth.synth_hubert_state_dict(6)
+    centers = synth.synth_kmeans_centers()
+    torch.save({"model": sd}, f"{td}/ckpt/hubert-base-ls960.pt")
+    np.save(f"{td}/ckpt/kmeans_100.npy", centers.numpy())
+    for i in (1, 2):
+        shutil.copy(os.path.join(golden_dir, f"s1_{i}.wav"), f"{td}/wav/s1_{i}.wav")
+    cli = _load("dissc_encode_cli", "data/encode.py")
+    cli.main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/out/enc.txt", "--checkpoint_dir", f"{td}/ckpt"])
+    lines = [json.loads(x) for x in open(f"{td}/out/enc.txt").read().strip().split("\n")]
+    assert sorted(d["audio"] for d in lines) == ["s1_1.wav", "s1_2.wav"]
+    for d in lines:
+        x, sr = cli.load_wav(f"{td}/wav/{d['audio']}")
+        assert sr == 16000 and len(x) == 32000
+        units, dense = hr.encode(sd, centers, torch.from_numpy(x)[None])
+        assert len(d["units"]) == 99 == len(d["f0"]) == len(d["durations"])
+        dist = ((dense[:, None, :] - centers[None]) ** 2).sum(-1)
+        top2 = torch.topk(dist, 2, largest=False).values
+        safe = ((top2[:, 1] - top2[:, 0]) > 0.02).numpy()
+        np.testing.assert_array_equal(np.array(d["units"])[safe], units.numpy()[safe])
