@@ -28,14 +28,16 @@ __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + 
 
 // STRIDE: input step per output position (1; 2 for HuBERT's strided feature convs).
 // SPAN: largest (KS-1)*dil the staging registers are sized for.
-template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN>
+// CPB: 16-channel chunks staged per barrier (4 for 1x1 convs, whose chunk is a single tap).
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BN = 16 * NI * WN;
+  constexpr int KCB = KC * CPB;  // channels staged per barrier
   constexpr int XW_MAX = ((BN - 1) * STRIDE + 1 + SPAN + 3 + 31) / 32 * 32 + 16;
-  constexpr int SV = (KC * (XW_MAX / 4) + NT - 1) / NT;  // float4 staging slots per thread
+  constexpr int SV = (KCB * (XW_MAX / 4) + NT - 1) / NT;  // float4 staging slots per thread
   constexpr int CW = 16 * NI + 4;                        // epilogue patch row stride
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x [KC][XW] | NW x [16][CW]
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x [KCB][XW] | NW x [16][CW]
 
   const int b = blockIdx.z;
   const int len = (a.lengths ? a.lengths[b] * a.len_mul : a.len_default);  // valid INPUT positions
@@ -72,7 +74,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
     int r = r0, v = v0;
 #pragma unroll
     for (int i = 0; i < SV; ++i) {
-      int ci = c * KC + (r < KC ? r : KC - 1);
+      int ci = c * KCB + (r < KCB ? r : KCB - 1);
       ci = ci < a.CIN ? ci : a.CIN - 1;
       int t = tb + 4 * v;
       t = t < 0 ? 0 : (t > a.ldx - 4 ? a.ldx - 4 : t);
@@ -86,9 +88,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
     int r = r0, v = v0;
 #pragma unroll
     for (int i = 0; i < SV; ++i) {
-      if (r < KC) {
+      if (r < KCB) {
         const int t = tb + 4 * v;
-        const bool rowok = (c * KC + r) < a.CIN;
+        const bool rowok = (c * KCB + r) < a.CIN;
         f32x4 val = sv[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -130,38 +132,44 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
   const int boff = g * XW + sh + (wn * (16 * NI) + l15) * STRIDE;
   const int XW4 = 4 * XW;
   int q = 0;
-  for (int c = 0; c < a.nchunk; ++c) {
-    const float* bj = xs + (c & 1) * (KC * XW) + boff;
-    const bool more = c + 1 < a.nchunk;
-    float b0[NI], b1[NI], b2[NI], b3[NI], b0n[NI];
+  const int nblk = (a.nchunk + CPB - 1) / CPB;
+  for (int cb = 0; cb < nblk; ++cb) {
+    const float* blk = xs + (cb & 1) * (KCB * XW) + boff;
+    const bool more = cb + 1 < nblk;
+#pragma unroll 1
+    for (int sc = 0; sc < CPB; ++sc) {
+      if (cb * CPB + sc >= a.nchunk) break;
+      const float* bj = blk + sc * (KC * XW);
+      float b0[NI], b1[NI], b2[NI], b3[NI], b0n[NI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) b0[ni] = bj[ni * 16 * STRIDE];
-    for (int j = 0; j < a.KS; ++j, ++q) {
-      const int qn = (q + 1 < nq) ? q + 1 : q;
+      for (int ni = 0; ni < NI; ++ni) b0[ni] = bj[ni * 16 * STRIDE];
+      for (int j = 0; j < a.KS; ++j, ++q) {
+        const int qn = (q + 1 < nq) ? q + 1 : q;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][(size_t)qn * 64];
-      if (j == 0 && more) stage_load(c + 1);  // in flight behind this chunk's MFMAs
-      __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of the MFMAs
+        for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][(size_t)qn * 64];
+        if (j == 0 && sc == 0 && more) stage_load(cb + 1);  // in flight behind this block's MFMAs
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of the MFMAs
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        b1[ni] = bj[XW4 + ni * 16 * STRIDE];
-        b2[ni] = bj[2 * XW4 + ni * 16 * STRIDE];
-        b3[ni] = bj[3 * XW4 + ni * 16 * STRIDE];
+        for (int ni = 0; ni < NI; ++ni) {
+          b1[ni] = bj[XW4 + ni * 16 * STRIDE];
+          b2[ni] = bj[2 * XW4 + ni * 16 * STRIDE];
+          b3[ni] = bj[3 * XW4 + ni * 16 * STRIDE];
+        }
+        DISSC_MFMA_STEP(0, b0)
+        bj += a.dil;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b0n[ni] = bj[ni * 16 * STRIDE];  // next tap's first k-step
+        DISSC_MFMA_STEP(1, b1)
+        DISSC_MFMA_STEP(2, b2)
+        DISSC_MFMA_STEP(3, b3)
+        __builtin_amdgcn_sched_barrier(0);  // the register rotation below must not creep upwards
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b0[ni] = b0n[ni];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) av[mi] = avn[mi];
       }
-      DISSC_MFMA_STEP(0, b0)
-      bj += a.dil;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b0n[ni] = bj[ni * 16 * STRIDE];  // next tap's first k-step
-      DISSC_MFMA_STEP(1, b1)
-      DISSC_MFMA_STEP(2, b2)
-      DISSC_MFMA_STEP(3, b3)
-      __builtin_amdgcn_sched_barrier(0);  // the register rotation below must not creep upwards
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b0[ni] = b0n[ni];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) av[mi] = avn[mi];
     }
-    if (more) stage_store(xs + ((c + 1) & 1) * (KC * XW), c + 1);
+    if (more) stage_store(xs + ((cb + 1) & 1) * (KCB * XW), cb + 1);
     __syncthreads();
   }
 #undef DISSC_MFMA_STEP
@@ -358,23 +366,23 @@ void convT_to_conv(const float* w, int Cin, int Cout, int k, int s, std::vector<
         }
 }
 
-template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN>
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1>
 static int launch_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, NW = WM * WN;
   constexpr int CW = 16 * NI + 4;
   a.mt_per_group = (a.M + BM - 1) / BM;
   dim3 grid((Lmax_out + BN - 1) / BN, a.mt_per_group * a.groups, B);
-  size_t lds_f = (size_t)2 * KC * a.XW;
+  size_t lds_f = (size_t)2 * KC * CPB * a.XW;
   if (lds_f < (size_t)NW * 16 * CW) lds_f = (size_t)NW * 16 * CW;
   const size_t lds = lds_f * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_mfma_kernel<MI, NI, WM, WN, STRIDE, SPAN>),
+        reinterpret_cast<const void*>(&conv_mfma_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<MI, NI, WM, WN, STRIDE, SPAN>), grid, dim3(64 * WM * WN), lds,
+  hipLaunchKernelGGL((conv_mfma_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>), grid, dim3(64 * WM * WN), lds,
                      stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
@@ -409,6 +417,8 @@ int launch_conv(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t 
     set_error("launch_conv: kernel %d x dilation %d unsupported for %d rows", a.KS, a.dil, a.M);
     return DISSC_EINVAL;
   }
+  if (span == 0 && cfg == 0 && a.nchunk >= 8)  // 1x1 convs (HuBERT linears): 64 channels per barrier
+    return launch_t<4, 4, 4, 1, 1, 0, 4>(a, B, Lmax_out, stream);
   switch (cfg) {
     case 0: return launch_t<4, 4, 4, 1, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     case 1: return launch_t<4, 4, 2, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);

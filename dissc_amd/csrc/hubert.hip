@@ -150,28 +150,61 @@ __global__ void __launch_bounds__(256) conv0_apply_kernel(const float* __restric
 }
 
 // ---- LayerNorm over channels of a channels-first tensor (optionally of x + r) ----------------
-__global__ void __launch_bounds__(128) ln_cf_kernel(const float* __restrict__ x, const float* __restrict__ r,
-                                                    const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta,
-                                                    const int32_t* __restrict__ lens, int C, int ld,
-                                                    float eps, float* __restrict__ y) {
+// One block = 64 time steps x all C channels; 16 waves each keep C/16 channels of their 64
+// columns in registers (single pass over HBM), partial moments are combined through LDS.
+constexpr int LN_WAVES = 16;
+constexpr int LN_MAXC = 48;  // channels per wave held in registers (C <= 768)
+__global__ void __launch_bounds__(64 * LN_WAVES) ln_cf_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ r,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const int32_t* __restrict__ lens, int C,
+                                                              int ld, float eps, float* __restrict__ y) {
+  __shared__ float red[LN_WAVES][64];
   const int b = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= lens[b]) return;
-  const size_t base = (size_t)b * C * ld + t;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  const bool ok = t < lens[b];
+  const int cpw = C / LN_WAVES;  // host guarantees C % 16 == 0 and cpw <= LN_MAXC
+  const size_t base = (size_t)b * C * ld + (size_t)(wv * cpw) * ld + t;
+  float v[LN_MAXC];
   float s = 0.f;
-  for (int c = 0; c < C; ++c) s += x[base + (size_t)c * ld] + (r ? r[base + (size_t)c * ld] : 0.f);
-  const float mean = s / (float)C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    v[i] = 0.f;
+    if (i < cpw && ok) {
+      v[i] = x[base + (size_t)i * ld];
+      if (r) v[i] += r[base + (size_t)i * ld];
+    }
+    s += v[i];
+  }
+  red[wv][lane] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < LN_WAVES; ++w) tot += red[w][lane];
+  const float mean = tot / (float)C;
   float q = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float d = x[base + (size_t)c * ld] + (r ? r[base + (size_t)c * ld] : 0.f) - mean;
-    q = fmaf(d, d, q);
-  }
-  const float rstd = 1.f / sqrtf(q / (float)C + eps);
-  for (int c = 0; c < C; ++c) {
-    const float v = x[base + (size_t)c * ld] + (r ? r[base + (size_t)c * ld] : 0.f);
-    y[base + (size_t)c * ld] = (v - mean) * rstd * gamma[c] + beta[c];
-  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i)
+    if (i < cpw) {
+      const float d = v[i] - mean;
+      q = fmaf(d, d, q);
+    }
+  __syncthreads();
+  red[wv][lane] = q;
+  __syncthreads();
+  tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < LN_WAVES; ++w) tot += red[w][lane];
+  const float rstd = 1.f / sqrtf(tot / (float)C + eps);
+  if (!ok) return;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i)
+    if (i < cpw) {
+      const int c = wv * cpw + i;
+      y[base + (size_t)i * ld] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    }
 }
 
 // ---- batched fp32 MFMA GEMM for attention: C[z] = alpha * A[z] (MxK) * B[z] (KxN) ------------
@@ -559,15 +592,15 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
   const int32_t* lensT = w.lens + (size_t)(NCONV - 1) * B;
   ConvIO ioT;
   ioT.lengths_in = lensT;
-  dim3 gln((T + 127) / 128, B);
+  dim3 gln((T + 63) / 64, B);
   // LayerNorm(512) -> Linear(512,768)
   float* fn = w.f[cur ^ 1];  // free buffer, [B][512][ldT] fits (ldT <= ld of that buffer)
-  hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(128), 0, st, w.f[cur], (const float*)nullptr, m->ln0_g, m->ln0_b,
+  hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(64 * LN_WAVES), 0, st, w.f[cur], (const float*)nullptr, m->ln0_g, m->ln0_b,
                      lensT, 512, ldT, 1e-5f, fn);
   if ((rc = run_conv_ex(m->proj, fn, w.x, nullptr, ioT, B, 512, ldT, ldT, T, 1.0f, EPI_STORE, st))) return rc;
   // x = LN(x + GELU(pos_conv(x)))
   if ((rc = run_conv_ex(m->pos, w.x, w.y, w.x, ioT, B, D, ldT, ldT, T, 1.0f, EPI_RES, st))) return rc;
-  hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(128), 0, st, w.y, (const float*)nullptr, m->eln_g, m->eln_b, lensT,
+  hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(64 * LN_WAVES), 0, st, w.y, (const float*)nullptr, m->eln_g, m->eln_b, lensT,
                      D, ldT, 1e-5f, w.x);
   for (int i = 0; i < m->n_layers; ++i) {
     auto& L = m->layers[i];
@@ -593,12 +626,12 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
     hipLaunchKernelGGL(bgemm_kernel, go, dim3(256), 0, st, a);
     // x = LN(x + out_proj(O))
     if ((rc = run_conv_ex(L.out, w.t1, w.y, w.x, ioT, B, D, ldT, ldT, T, 1.0f, EPI_RES, st))) return rc;
-    hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(128), 0, st, w.y, (const float*)nullptr, L.ln1_g, L.ln1_b, lensT, D,
+    hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(64 * LN_WAVES), 0, st, w.y, (const float*)nullptr, L.ln1_g, L.ln1_b, lensT, D,
                        ldT, 1e-5f, w.x);
     // x = LN(x + fc2(GELU(fc1(x))))
     if ((rc = run_conv_ex(L.fc1, w.x, w.ffn, nullptr, ioT, B, D, ldT, ldT, T, 1.0f, EPI_STORE, st))) return rc;
     if ((rc = run_conv_ex(L.fc2, w.ffn, w.y, w.x, ioT, B, m->F, ldT, ldT, T, 1.0f, EPI_RES, st))) return rc;
-    hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(128), 0, st, w.y, (const float*)nullptr, L.ln2_g, L.ln2_b, lensT, D,
+    hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(64 * LN_WAVES), 0, st, w.y, (const float*)nullptr, L.ln2_g, L.ln2_b, lensT, D,
                        ldT, 1e-5f, w.x);
   }
   if (dense_out)  // [B][768][ldT] channels-first
