@@ -180,3 +180,53 @@ def test_hubert_oracle_matches_hf_and_sklearn(hgold, n):
     if n <= 4000:
         cnn = hr.conv_feature_extractor(sd, wav)
         assert np.abs(cnn.numpy() - hgold[f"n{n}/cnn"]).max() <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------
+# the C restatement (oracle/host_ref.c) of the integer host logic
+# ------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def coracle():
+    import ctypes
+    import __graft_entry__ as ge
+    path = ge.build_oracle()
+    L = ctypes.CDLL(path)
+    L.oracle_dedup.restype = ctypes.c_int
+    return L
+
+
+def test_c_oracle_matches_reference_goldens(coracle, pgold):
+    import ctypes
+    for i in range(int(pgold["n_seqs"])):
+        seq = np.ascontiguousarray(pgold[f"seq{i}"], dtype=np.int64)
+        vals = np.zeros(len(seq), np.int64)
+        counts = np.zeros(len(seq), np.int32)
+        m = coracle.oracle_dedup(seq.ctypes.data_as(ctypes.c_void_p), len(seq),
+                                 vals.ctypes.data_as(ctypes.c_void_p), counts.ctypes.data_as(ctypes.c_void_p))
+        np.testing.assert_array_equal(vals[:m], pgold[f"dd_vals{i}"])
+        np.testing.assert_array_equal(counts[:m], pgold[f"dd_counts{i}"])
+        lens = np.ascontiguousarray(pgold[f"lens{i}"][0], dtype=np.float32)
+        out = np.zeros(len(lens), np.int32)
+        coracle.oracle_len_carryover(lens.ctypes.data_as(ctypes.c_void_p), len(lens), out.ctypes.data_as(ctypes.c_void_p))
+        np.testing.assert_array_equal(out, pgold[f"lens_int{i}"])
+    for j in range(4):
+        x = np.ascontiguousarray(pgold[f"carry_in{j}"][0], dtype=np.float32)
+        out = np.zeros(len(x), np.int32)
+        coracle.oracle_len_carryover(x.ctypes.data_as(ctypes.c_void_p), len(x), out.ctypes.data_as(ctypes.c_void_p))
+        np.testing.assert_array_equal(out, pgold[f"carry_out{j}"])
+
+
+def test_c_oracle_postprocess_and_kmeans(coracle, hgold):
+    import ctypes
+    rs = np.random.RandomState(1)
+    y = np.tanh(rs.standard_normal(4000).astype(np.float32) * 2)
+    y[:3] = [1.0, -1.0, 0.999999]
+    out = np.zeros_like(y)
+    coracle.oracle_wav_postprocess(y.ctypes.data_as(ctypes.c_void_p), len(y), out.ctypes.data_as(ctypes.c_void_p))
+    np.testing.assert_array_equal(out, gr.wav_postprocess(y))
+    dense = np.ascontiguousarray(hgold["n16000/dense"], dtype=np.float32)
+    centers = np.ascontiguousarray(synth.synth_kmeans_centers().numpy())
+    units = np.zeros(len(dense), np.int64)
+    coracle.oracle_kmeans_assign(dense.ctypes.data_as(ctypes.c_void_p), len(dense), 768,
+                                 centers.ctypes.data_as(ctypes.c_void_p), 100, units.ctypes.data_as(ctypes.c_void_p))
+    np.testing.assert_array_equal(units, hgold["n16000/units"])  # == sklearn KMeans.predict
