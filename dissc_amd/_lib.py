@@ -96,6 +96,12 @@ def _load():
 
 lib = _load()
 
+# tuning hook: DISSC_OPTIONS="key=value,key=value" -> dissc_set_option (see include/dissc_hip.h)
+for _kv in filter(None, os.environ.get("DISSC_OPTIONS", "").split(",")):
+    _k, _v = _kv.split("=")
+    if lib.dissc_set_option(_k.strip().encode(), int(_v)) != 0:
+        raise DisscError(f"DISSC_OPTIONS: unknown option {_k}")
+
 
 def check(rc, what=""):
     if rc != 0:

@@ -121,6 +121,14 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
                 const ConvIO& io, int B, int C_x_total, int ldx, int ldo, int Lmax_out, float slope,
                 int epi, float mrf_div, hipStream_t stream);
 
+// fused ResBlock1 for narrow stages (resblock_fused.hip)
+bool resblock_fused_supported(int C, int KS, const int* dil);
+void fused_set_option(int which, int value);  // 0: BN for C=16, 1: BN for C=32, 2: max C (0 = off)
+int launch_resblock_fused(int C, const float* x, float* acc, const float* wpack, const float* bias,
+                          const int32_t* lengths, int len_default, int len_mul, int KS, const int* dil,
+                          int B, int Lmax, int ld, float slope, int epi, float mrf_div,
+                          hipStream_t stream);
+
 // misc kernels (gen_misc.hip)
 void launch_embed_concat(const int64_t* code, const float* f0, const int64_t* spkr,
                          const float* dict_w, const float* spkr_w, const int32_t* lengths, int B,

@@ -37,6 +37,7 @@ struct dissc_gen {
   DevConv conv_pre;
   std::vector<DevConv> ups;
   std::vector<DevConv> rb1, rb2;  // [stage*nk*3 + j*3 + m]
+  std::vector<float*> fused_w, fused_b;  // [stage*nk + j]: 6 packed convs / biases of a fused ResBlock
   float* post_w = nullptr;
   float* post_b = nullptr;
   int post_C = 0, post_KS = 0;
@@ -48,6 +49,8 @@ struct dissc_gen {
     for (auto& c : ups) free_conv(c);
     for (auto& c : rb1) free_conv(c);
     for (auto& c : rb2) free_conv(c);
+    for (float* p : fused_w) if (p) (void)hipFree(p);
+    for (float* p : fused_b) if (p) (void)hipFree(p);
     if (post_w) (void)hipFree(post_w);
     if (post_b) (void)hipFree(post_b);
     if (dict_w) (void)hipFree(dict_w);
@@ -135,6 +138,8 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
   const int nk = cfg->num_kernels;
   g->rb1.resize((size_t)cfg->num_upsamples * nk * 3);
   g->rb2.resize((size_t)cfg->num_upsamples * nk * 3);
+  g->fused_w.assign((size_t)cfg->num_upsamples * nk, nullptr);
+  g->fused_b.assign((size_t)cfg->num_upsamples * nk, nullptr);
   for (int i = 0; i < cfg->num_upsamples; ++i) {
     const int s = cfg->upsample_rates[i], k = cfg->upsample_kernel_sizes[i];
     if (s < 1 || k < s || (k - s) % 2 != 0) {  // L_out = s * L_in needs k - s even
@@ -171,6 +176,8 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
         set_error("dissc_gen_create: even resblock kernel size %d unsupported", rk);
         return fail(DISSC_EINVAL);
       }
+      const bool fuse = resblock_fused_supported(ch, rk, cfg->resblock_dilations[j]);
+      std::vector<float> fw, fb;
       for (int m = 0; m < 3; ++m) {
         const int d = cfg->resblock_dilations[j][m];
         const size_t idx = ((size_t)i * nk + j) * 3 + m;
@@ -179,11 +186,29 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
         snprintf(name, sizeof(name), "resblocks.%d.convs1.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
         if ((rc = make_conv(w, b, ch, ch, rk, d, g->rb1[idx]))) return fail(rc);
+        if (fuse) {
+          std::vector<float> pk;
+          int mp, nc;
+          pack_conv_weights(w, ch, ch, rk, pk, mp, nc);
+          fw.insert(fw.end(), pk.begin(), pk.end());
+          fb.insert(fb.end(), b, b + ch);
+        }
         snprintf(name, sizeof(name), "resblocks.%d.convs2.%d.weight", i * nk + j, m);
         if ((rc = get(name, {ch, ch, rk}, &w))) return fail(rc);
         snprintf(name, sizeof(name), "resblocks.%d.convs2.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
         if ((rc = make_conv(w, b, ch, ch, rk, 1, g->rb2[idx]))) return fail(rc);
+        if (fuse) {
+          std::vector<float> pk;
+          int mp, nc;
+          pack_conv_weights(w, ch, ch, rk, pk, mp, nc);
+          fw.insert(fw.end(), pk.begin(), pk.end());
+          fb.insert(fb.end(), b, b + ch);
+        }
+      }
+      if (fuse) {
+        if ((rc = upload(fw, &g->fused_w[(size_t)i * nk + j]))) return fail(rc);
+        if ((rc = upload(fb, &g->fused_b[(size_t)i * nk + j]))) return fail(rc);
       }
     }
   }
@@ -290,6 +315,16 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
     ch = ch_out; mul = mul_out; ld = ld_out;
     const int L = Tmax * mul;
     for (int j = 0; j < nk; ++j) {
+      if (g->fused_w[(size_t)i * nk + j]) {  // narrow stage: the whole ResBlock in one launch
+        const int epi = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET)
+                                 : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
+        if ((rc = launch_resblock_fused(ch, X, ACC, g->fused_w[(size_t)i * nk + j],
+                                        g->fused_b[(size_t)i * nk + j], lengths, L, mul,
+                                        c.resblock_kernel_sizes[j], c.resblock_dilations[j], B, L, ld,
+                                        0.1f, epi, (float)nk, stream)))
+          return rc;
+        continue;
+      }
       for (int m = 0; m < 3; ++m) {
         const size_t idx = ((size_t)i * nk + j) * 3 + m;
         const float* xin = (m == 0) ? X : XK;
@@ -369,6 +404,10 @@ int dissc_set_option(const char* key, int value) {
     conv_set_cfg(cls, value);
     return DISSC_OK;
   }
+  if (strcmp(key, "fused_bn16") == 0) { fused_set_option(0, value); return DISSC_OK; }
+  if (strcmp(key, "fused_bn32") == 0) { fused_set_option(1, value); return DISSC_OK; }
+  if (strcmp(key, "fused_max_c") == 0) { fused_set_option(2, value); return DISSC_OK; }
+  if (strcmp(key, "fused_variant") == 0) { fused_set_option(3, value); return DISSC_OK; }
   set_error("dissc_set_option: unknown key %s", key);
   return DISSC_EINVAL;
 }

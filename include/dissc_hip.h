@@ -116,7 +116,9 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
                            int ldx, int ldo, int Lmax, float in_slope, void* stream);
 
 /* Tuning hook: "conv_cfg_bm{16,32,64,128,256}" = tile-shape id used for convs whose GEMM
- * M falls in that class (see kCfgs in conv_mfma.hip).  Process-wide; set before create. */
+ * M falls in that class (see kCfgs in conv_mfma.hip); "fused_max_c" = widest ResBlock that
+ * runs as one fused launch (0 = never), "fused_bn16/32" = its time tile.  Process-wide; set
+ * before dissc_gen_create. */
 int dissc_set_option(const char* key, int value);
 
 /* Diagnostics (not on the product path): average milliseconds of `iters` launches of
