@@ -401,6 +401,14 @@ int launch_resblock_fused(int C, const float* x, float* acc, const float* wpack,
       if (KS == 11) return launch_fused<16, 16, 3>(&resblock16_kernel<11, 16, 3>, a, B, Lmax, stream);
     } else if (g_fused_var == 2) {
       return launch_fused<16, 16, 2>(&resblock_fused_kernel<16, 16, 2>, a, B, Lmax, stream);
+    } else if (g_fused_var == 3) {  // 8 waves x 4 tiles: 2 workgroups per CU overlap their memory phases
+      if (KS == 3) return launch_fused<16, 8, 4>(&resblock16_kernel<3, 8, 4>, a, B, Lmax, stream);
+      if (KS == 7) return launch_fused<16, 8, 4>(&resblock16_kernel<7, 8, 4>, a, B, Lmax, stream);
+      if (KS == 11) return launch_fused<16, 8, 4>(&resblock16_kernel<11, 8, 4>, a, B, Lmax, stream);
+    } else if (g_fused_var == 4) {  // 4 waves x 8 tiles: up to 2-3 workgroups per CU
+      if (KS == 3) return launch_fused<16, 4, 8>(&resblock16_kernel<3, 4, 8>, a, B, Lmax, stream);
+      if (KS == 7) return launch_fused<16, 4, 8>(&resblock16_kernel<7, 4, 8>, a, B, Lmax, stream);
+      if (KS == 11) return launch_fused<16, 4, 8>(&resblock16_kernel<11, 4, 8>, a, B, Lmax, stream);
     } else {
       if (KS == 3) return launch_fused<16, 16, 2>(&resblock16_kernel<3, 16, 2>, a, B, Lmax, stream);
       if (KS == 7) return launch_fused<16, 16, 2>(&resblock16_kernel<7, 16, 2>, a, B, Lmax, stream);
