@@ -65,7 +65,8 @@ struct ConvArgs {
   float slope;          // leaky-ReLU slope applied to x on load (1 = identity)
   float mrf_div;
   int epi;
-  int up;               // 1 = conv; s = ConvTranspose stride (rows are co*s+p)
+  int up;               // 1 = conv; s = ConvTranspose stride
+  int up_np, up_p0;     // ConvTranspose phase group: row = co*up_np + pi, phase = up_p0 + pi
 };
 
 constexpr int MAX_TAP_SPAN = 60;    // (KS-1)*dil of the default instances (staging register budget)
@@ -83,9 +84,11 @@ int conv_xw(int M, int KS, int dil, int stride = 1);
 // buffer (Mpad/16 * nchunk * KS * 64 float4) and Mpad (M rounded up to 16).
 void pack_conv_weights(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
                        int& Mpad, int& nchunk, int groups = 1);
-// ConvTranspose1d [Cin][Cout][k], stride s, padding (k-s)/2  ->  3-tap conv with
-// M = Cout*s rows (row = co*s + p), taps delta = -1,0,+1.
-void convT_to_conv(const float* w, int Cin, int Cout, int k, int s, std::vector<float>& w3);
+// ConvTranspose1d [Cin][Cout][k], stride s, padding (k-s)/2, phases [p0, p0+np): conv weights
+// [Cout*np][Cin][ntap] (row = co*np + pi) over input taps delta = dlo .. dlo+ntap-1
+// (out[s*q + p] = sum_delta x[q + delta] * w[kk = p + pad - s*delta]).
+void convT_phase_weights(const float* w, int Cin, int Cout, int k, int s, int p0, int np, int dlo,
+                         int ntap, std::vector<float>& wc);
 
 // Device-resident conv layer (conv_host.hip).
 struct DevConv {
@@ -95,6 +98,7 @@ struct DevConv {
   float* shift = nullptr;  // (eval-mode BatchNorm1d / label de-normalisation)
   int CIN = 0, M = 0, KS = 0, dil = 1, nchunk = 0, up = 1;  // CIN, M per group
   int groups = 1, Mpad = 0, stride = 1, pad_left = -1;      // pad_left -1 = "same" ((KS-1)*dil/2)
+  int up_np = 1, up_p0 = 0;                                 // ConvTranspose phase group (see ConvArgs)
   int act = 0;
   double macs_per_t = 0;  // MACs per input time step (algorithmic, zero taps excluded)
 };
@@ -107,7 +111,9 @@ struct ConvIO {
 int upload(const std::vector<float>& h, float** d);
 int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int dil, DevConv& dc,
               int groups = 1, int stride = 1, int pad_left = -1);
-int make_convT(const float* w, const float* bias, int Cin, int Cout, int k, int s, DevConv& dc);
+// ConvTranspose1d = one conv per group of output phases sharing the same input taps.
+int make_convT(const float* w, const float* bias, int Cin, int Cout, int k, int s,
+               std::vector<DevConv>& groups);
 int set_affine(DevConv& dc, const float* scale, const float* shift, int n);  // host pointers
 void free_conv(DevConv& dc);
 int run_conv(const DevConv& dc, const float* x, float* out, const float* res, float* acc,

@@ -31,16 +31,55 @@ int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int 
 }
 
 int make_convT(const float* w, const float* bias, int Cin, int Cout, int k, int s,
-                      DevConv& dc) {
-  std::vector<float> w3;
-  convT_to_conv(w, Cin, Cout, k, s, w3);
-  std::vector<float> b3((size_t)Cout * s);
-  for (int co = 0; co < Cout; ++co)
-    for (int p = 0; p < s; ++p) b3[co * s + p] = bias ? bias[co] : 0.f;
-  int rc = make_conv(w3.data(), b3.data(), Cout * s, Cin, 3, 1, dc);
-  dc.up = s;
-  dc.macs_per_t = (double)Cin * Cout * k;  // per INPUT step: every (ci,co,kk) used once
-  return rc;
+               std::vector<DevConv>& groups) {
+  const int pad = (k - s) / 2;
+  groups.clear();
+  // input taps of phase p: delta in [dlo, dhi] with 0 <= p + pad - s*delta < k
+  auto taps = [&](int p, int& dlo, int& dhi) {
+    dlo = 1 << 30;
+    dhi = -(1 << 30);
+    for (int kk = (p + pad) % s; kk < k; kk += s) {
+      const int delta = (p + pad - kk) / s;  // exact
+      dlo = delta < dlo ? delta : dlo;
+      dhi = delta > dhi ? delta : dhi;
+    }
+  };
+  // Narrow layers (few output rows) are store/latency bound: one launch over the union of the
+  // taps (some zero weights) beats several small ones; wide layers skip the zero taps instead.
+  const bool single = Cout < 64;
+  int p0 = 0;
+  while (p0 < s) {
+    int dlo, dhi;
+    taps(p0, dlo, dhi);
+    int np = 1;
+    while (p0 + np < s) {
+      int l2, h2;
+      taps(p0 + np, l2, h2);
+      if (single) {
+        dlo = l2 < dlo ? l2 : dlo;
+        dhi = h2 > dhi ? h2 : dhi;
+      } else if (l2 != dlo || h2 != dhi) {
+        break;
+      }
+      ++np;
+    }
+    const int ntap = dhi - dlo + 1;
+    std::vector<float> wc;
+    convT_phase_weights(w, Cin, Cout, k, s, p0, np, dlo, ntap, wc);
+    std::vector<float> bc((size_t)Cout * np);
+    for (int co = 0; co < Cout; ++co)
+      for (int pi = 0; pi < np; ++pi) bc[co * np + pi] = bias ? bias[co] : 0.f;
+    groups.emplace_back();
+    DevConv& dc = groups.back();
+    int rc = make_conv(wc.data(), bc.data(), Cout * np, Cin, ntap, 1, dc, 1, 1, -dlo);
+    if (rc) return rc;
+    dc.up = s;
+    dc.up_np = np;
+    dc.up_p0 = p0;
+    dc.macs_per_t = groups.size() == 1 ? (double)Cin * Cout * k : 0.0;  // algorithmic MACs counted once
+    p0 += np;
+  }
+  return DISSC_OK;
 }
 
 int set_affine(DevConv& dc, const float* scale, const float* shift, int n) {
@@ -79,8 +118,8 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
   a.XW = conv_xw(dc.M, dc.KS, dc.dil, dc.stride);
   a.ldx = ldx; a.ldo = ldo;
   a.x_bstride = (long long)C_x_total * ldx;
-  a.o_bstride = (long long)(dc.M * dc.groups / dc.up) * ldo;
-  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.up = dc.up;
+  a.o_bstride = (long long)(dc.M * dc.groups / dc.up_np) * ldo;
+  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.up = dc.up; a.up_np = dc.up_np; a.up_p0 = dc.up_p0;
   return launch_conv(a, B, Lmax_out, dc.stride, stream);
 }
 

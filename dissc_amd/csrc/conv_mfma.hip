@@ -187,8 +187,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
         const int row = (ms0 + mi) * 16 + g * 4 + r;
         if (row >= a.M) continue;
         const float bz = a.bias[row];  // ConvTranspose path: groups == 1
-        const int co = row / a.up;
-        const int p = row - co * a.up;
+        const int co = row / a.up_np;
+        const int p = a.up_p0 + row - co * a.up_np;
         const size_t rowoff = ob + (size_t)co * a.ldo + p;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -352,17 +352,17 @@ void pack_conv_weights(const float* w, int Cout, int Cin, int KS, std::vector<fl
             }
 }
 
-void convT_to_conv(const float* w, int Cin, int Cout, int k, int s, std::vector<float>& w3) {
+void convT_phase_weights(const float* w, int Cin, int Cout, int k, int s, int p0, int np, int dlo,
+                         int ntap, std::vector<float>& wc) {
   const int pad = (k - s) / 2;
-  const int M = Cout * s;
-  w3.assign((size_t)M * Cin * 3, 0.f);
+  wc.assign((size_t)Cout * np * Cin * ntap, 0.f);
   for (int co = 0; co < Cout; ++co)
-    for (int p = 0; p < s; ++p)
+    for (int pi = 0; pi < np; ++pi)
       for (int ci = 0; ci < Cin; ++ci)
-        for (int j = 0; j < 3; ++j) {
-          const int kk = p + pad - s * (j - 1);
+        for (int j = 0; j < ntap; ++j) {
+          const int kk = (p0 + pi) + pad - s * (dlo + j);
           if (kk >= 0 && kk < k)
-            w3[((size_t)(co * s + p) * Cin + ci) * 3 + j] = w[((size_t)ci * Cout + co) * k + kk];
+            wc[((size_t)(co * np + pi) * Cin + ci) * ntap + j] = w[((size_t)ci * Cout + co) * k + kk];
         }
 }
 

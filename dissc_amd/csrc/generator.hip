@@ -35,7 +35,7 @@ struct dissc_gen {
   DisscGenConfig cfg;
   int hop = 1;
   DevConv conv_pre;
-  std::vector<DevConv> ups;
+  std::vector<std::vector<DevConv>> ups;  // per stage: one conv per phase group
   std::vector<DevConv> rb1, rb2;  // [stage*nk*3 + j*3 + m]
   std::vector<float*> fused_w, fused_b;  // [stage*nk + j]: 6 packed convs / biases of a fused ResBlock
   float* post_w = nullptr;
@@ -46,7 +46,7 @@ struct dissc_gen {
   std::vector<int> stage_C, stage_mul;  // channels / length multiplier after ups[i]
   ~dissc_gen() {
     free_conv(conv_pre);
-    for (auto& c : ups) free_conv(c);
+    for (auto& v : ups) for (auto& c : v) free_conv(c);
     for (auto& c : rb1) free_conv(c);
     for (auto& c : rb2) free_conv(c);
     for (float* p : fused_w) if (p) (void)hipFree(p);
@@ -146,19 +146,6 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
       set_error("dissc_gen_create: upsample k=%d s=%d unsupported", k, s);
       return fail(DISSC_EINVAL);
     }
-    {  // every tap kk must map to delta in {-1,0,1}: kk = p + pad - s*delta
-      const int pad = (k - s) / 2;
-      bool ok = true;
-      for (int p = 0; p < s && ok; ++p)
-        for (int kk = (p + pad) % s; kk < k; kk += s) {
-          const int delta = (p + pad - kk) / s;  // exact
-          if (delta < -1 || delta > 1) ok = false;
-        }
-      if (!ok) {
-        set_error("dissc_gen_create: upsample k=%d s=%d needs more than 3 phase taps", k, s);
-        return fail(DISSC_EINVAL);
-      }
-    }
     const int cout = ch / 2;
     char name[96];
     snprintf(name, sizeof(name), "ups.%d.weight", i);
@@ -254,7 +241,7 @@ double dissc_gen_flops(dissc_gen_t g, int64_t frames) {
   int mul = 1;
   const int nk = g->cfg.num_kernels;
   for (int i = 0; i < g->cfg.num_upsamples; ++i) {
-    macs += g->ups[i].macs_per_t * mul;
+    for (auto& c : g->ups[i]) macs += c.macs_per_t * mul;
     mul = g->stage_mul[i];
     for (int j = 0; j < nk * 3; ++j)
       macs += (g->rb1[(size_t)i * nk * 3 + j].macs_per_t + g->rb2[(size_t)i * nk * 3 + j].macs_per_t) * mul;
@@ -309,9 +296,10 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
     const int ch_out = ch / 2, mul_out = mul * s;
     const int ld_out = (int)round_up((size_t)Tmax * mul_out, 4);
     // lrelu(0.1) -> ConvTranspose: ACC [B,ch,ld] -> X [B,ch_out,ld_out]
-    if ((rc = run_conv(g->ups[i], ACC, X, nullptr, nullptr, lengths, Tmax * mul, mul, B, ch, ld,
-                       ld_out, Tmax * mul, 0.1f, EPI_STORE, 1.f, stream)))
-      return rc;
+    for (auto& grp : g->ups[i])
+      if ((rc = run_conv(grp, ACC, X, nullptr, nullptr, lengths, Tmax * mul, mul, B, ch, ld, ld_out,
+                         Tmax * mul, 0.1f, EPI_STORE, 1.f, stream)))
+        return rc;
     ch = ch_out; mul = mul_out; ld = ld_out;
     const int L = Tmax * mul;
     for (int j = 0; j < nk; ++j) {
@@ -389,10 +377,14 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
     set_error("dissc_conv_transpose1d: bad argument");
     return DISSC_EINVAL;
   }
-  DevConv dc;
-  int rc = make_convT(w_host, bias_host, Cin, Cout, k, stride, dc);
-  if (rc) return rc;
-  return conv_once(dc, x, y, lengths, B, ldx, ldo, Lmax, in_slope, (hipStream_t)stream);
+  std::vector<DevConv> grp;
+  int rc = make_convT(w_host, bias_host, Cin, Cout, k, stride, grp);
+  for (auto& dc : grp) {
+    int r2 = rc ? rc : conv_once(dc, x, y, lengths, B, ldx, ldo, Lmax, in_slope, (hipStream_t)stream);
+    if (rc) free_conv(dc);
+    rc = rc ? rc : r2;
+  }
+  return rc;
 }
 
 int dissc_set_option(const char* key, int value) {

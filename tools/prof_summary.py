@@ -18,7 +18,9 @@ def layer_list(B=32, T=500):
     out = [("conv_pre 257->512 k7", 2.0 * 512 * 257 * 7 * T * B)]
     ch, L = 512, T
     for i, (s, k) in enumerate(UPS):
-        out.append((f"up{i} convT {ch}->{ch//2} k{k} s{s}", 2.0 * ch * (ch // 2) * k * L * B))
+        ngrp = {5: 3, 4: 2, 2: 2}[s] if ch // 2 >= 64 else 1  # ConvTranspose = one launch per phase group
+        for gi in range(ngrp):
+            out.append((f"up{i} convT {ch}->{ch//2} k{k} s{s} g{gi}", 2.0 * ch * (ch // 2) * k * L * B / ngrp))
         ch //= 2
         L *= s
         for rk in RK:
