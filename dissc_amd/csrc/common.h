@@ -58,6 +58,7 @@ struct ConvArgs {
   int mt_per_group;     // M tiles (blockIdx.y) per group
   int nsub_group;       // 16-row subtiles per group in the packed weights / bias arrays
   int act;              // 0 none, 1 exact GELU on (conv + bias) before any residual
+  int m32;              // 1: weights packed for / launched on the 32x32x2 kernel (conv_mfma32.hip)
   int CIN, M, KS, dil, nchunk;
   int XW;               // LDS row stride (floats), XW % 32 == 16
   int ldx, ldo;
@@ -78,7 +79,15 @@ int launch_conv(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t 
 int conv_tile_bn(int M);
 int conv_cfg(int M);
 void conv_set_cfg(int bm_class, int cfg);  // tuning hook (dissc_conv_bench / dissc_set_option)
-int conv_xw(int M, int KS, int dil, int stride = 1);
+int conv_xw(int M, int KS, int dil, int stride = 1, int m32 = 0);
+// 32x32x2 form (conv_mfma32.hip)
+int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t stream);
+int conv32_tile_bn(int M);
+int conv32_cfg(int M);
+void conv32_set_cfg(int bm_class, int cfg);
+void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
+                         int& Mpad, int& nchunk, int groups);
+extern int g_use_mfma32;  // tuning: 0 forces the 16x16x4 kernel everywhere
 
 // Host-side weight packing.  w: [Cout][Cin][KS] (Conv1d layout).  Returns the packed
 // buffer (Mpad/16 * nchunk * KS * 64 float4) and Mpad (M rounded up to 16).
@@ -100,6 +109,7 @@ struct DevConv {
   int groups = 1, Mpad = 0, stride = 1, pad_left = -1;      // pad_left -1 = "same" ((KS-1)*dil/2)
   int up_np = 1, up_p0 = 0;                                 // ConvTranspose phase group (see ConvArgs)
   int act = 0;
+  int m32 = 0;              // packed for the 32x32x2 kernel
   double macs_per_t = 0;  // MACs per input time step (algorithmic, zero taps excluded)
 };
 // Per-call extras of run_conv_ex (strided / valid convolutions with their own output lengths).

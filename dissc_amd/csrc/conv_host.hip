@@ -6,6 +6,8 @@
 
 namespace dissc {
 
+int g_use_mfma32 = 1;
+
 int upload(const std::vector<float>& h, float** d) {
   DISSC_HIP_CHECK(hipMalloc((void**)d, h.size() * sizeof(float)));
   DISSC_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -18,7 +20,9 @@ int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int 
   std::vector<float> packed;
   int Mpad, nchunk;
   const int Mg = Cout / groups, Cg = Cin / groups;
-  pack_conv_weights(w, Cout, Cg, KS, packed, Mpad, nchunk, groups);
+  dc.m32 = (g_use_mfma32 && Mg >= 32) ? 1 : 0;  // 64-cycle MFMAs wherever a 32-row tile is not mostly padding
+  if (dc.m32) pack_conv_weights32(w, Cout, Cg, KS, packed, Mpad, nchunk, groups);
+  else pack_conv_weights(w, Cout, Cg, KS, packed, Mpad, nchunk, groups);
   std::vector<float> b((size_t)Mpad * groups, 0.f);
   if (bias)
     for (int g = 0; g < groups; ++g) memcpy(b.data() + (size_t)g * Mpad, bias + (size_t)g * Mg, Mg * sizeof(float));
@@ -114,8 +118,8 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
   a.lengths_out = io.lengths_out; a.olen_default = io.olen_default;
   a.CIN = dc.CIN; a.M = dc.M; a.KS = dc.KS; a.dil = dc.dil; a.nchunk = dc.nchunk;
   a.pad_left = dc.pad_left >= 0 ? dc.pad_left : ((dc.KS - 1) * dc.dil) / 2;
-  a.groups = dc.groups; a.nsub_group = dc.Mpad / 16; a.act = dc.act;
-  a.XW = conv_xw(dc.M, dc.KS, dc.dil, dc.stride);
+  a.groups = dc.groups; a.nsub_group = dc.Mpad / (dc.m32 ? 32 : 16); a.act = dc.act; a.m32 = dc.m32;
+  a.XW = conv_xw(dc.M, dc.KS, dc.dil, dc.stride, dc.m32);
   a.ldx = ldx; a.ldo = ldo;
   a.x_bstride = (long long)C_x_total * ldx;
   a.o_bstride = (long long)(dc.M * dc.groups / dc.up_np) * ldo;

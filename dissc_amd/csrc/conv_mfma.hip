@@ -321,8 +321,9 @@ int conv_tile_bn(int M) {
   return 16 * c.NI * c.WN;
 }
 
-int conv_xw(int M, int KS, int dil, int stride) {
-  const int need = (conv_tile_bn(M) - 1) * stride + 1 + (KS - 1) * dil + 3;  // +3: aligned window start
+int conv_xw(int M, int KS, int dil, int stride, int m32) {
+  const int bn = m32 ? conv32_tile_bn(M) : conv_tile_bn(M);
+  const int need = (bn - 1) * stride + 1 + (KS - 1) * dil + 3;  // +3: aligned window start
   int xw = (need + 31) / 32 * 32 + 16;
   if (xw - 32 >= need) xw -= 32;
   return xw;
@@ -400,6 +401,7 @@ int launch_conv(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t 
     set_error("launch_conv: activations must be 16-byte aligned with row strides %% 4 == 0");
     return DISSC_EINVAL;
   }
+  if (a.m32) return launch_conv32(a, B, Lmax_out, stride, stream);
   const int cfg = conv_cfg(a.M);
   if (stride == 2 && span <= MAX_TAP_SPAN && a.up == 1) {
     // HuBERT feature convs (512 -> 512, k3/k2 s2): only the 256x64 tile is instantiated

@@ -1,0 +1,394 @@
+// conv_mfma32_kernel: the 32x32x2 (64-cycle) MFMA form of the implicit-GEMM conv, used for every
+// layer with >= 32 output rows.  Staging, prefetching and epilogue semantics are those of
+// conv_mfma_kernel (conv_mfma.hip); only the fragment geometry differs:
+//   A: lane l holds W[row = l & 31][k = l >> 5], B: lane l holds X[k = l >> 5][col = l & 31],
+//   D: 16 registers, col = l & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
+#include "common.h"
+
+namespace dissc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+// 32x32x2 form of the kernel in conv_mfma.hip (64-cycle MFMAs sustain ~155 TFLOP/s on this part,
+// the 16x16x4 form ~130-139): tile units are 32 rows x 32 columns, a k-step is 2 channels.
+// STRIDE: input step per output position (1; 2 for HuBERT's strided feature convs).
+// SPAN: largest (KS-1)*dil the staging registers are sized for.
+// CPB: 16-channel chunks staged per barrier (4 for 1x1 convs, whose chunk is a single tap).
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1>
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const ConvArgs a) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BN = 32 * NI * WN;
+  constexpr int KCB = KC * CPB;  // channels staged per barrier
+  constexpr int XW_MAX = ((BN - 1) * STRIDE + 1 + SPAN + 3 + 31) / 32 * 32 + 16;
+  constexpr int SV = (KCB * (XW_MAX / 4) + NT - 1) / NT;  // float4 staging slots per thread
+  constexpr int CW = 32 * NI + 4;                        // epilogue patch row stride
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x [KCB][XW] | NW x [8][CW]
+
+  const int b = blockIdx.z;
+  const int len = (a.lengths ? a.lengths[b] * a.len_mul : a.len_default);  // valid INPUT positions
+  const int olen = a.lengths_out ? a.lengths_out[b] : (a.olen_default >= 0 ? a.olen_default : len);
+  const int t0 = blockIdx.x * BN;
+  if (t0 >= olen) return;
+  const int grp = blockIdx.y / a.mt_per_group;
+  const int mt = blockIdx.y - grp * a.mt_per_group;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int XW = a.XW;
+  const int NV = XW >> 2;
+  const int tin0 = t0 * STRIDE - a.pad_left;
+  const int tb = tin0 & ~3;   // 16-byte aligned window start (may be negative)
+  const int sh = tin0 - tb;   // 0..3
+  const int nq = a.nchunk * a.KS;
+  const int ms0 = mt * (MI * WM) + wm * MI;  // 32-row subtile within the group
+  const float slope = a.slope;
+  const float* xb = a.x + (size_t)b * a.x_bstride + (size_t)grp * a.CIN * a.ldx;
+
+  // this thread's float4 staging slots: slot i = tid + i*NT -> (row r, vec v)
+  const int r0 = tid / NV, v0 = tid - r0 * NV;
+  const int dr = NT / NV, dv = NT - dr * NV;
+
+  // Staging: every slot issues an unconditional, in-bounds 16-byte load (addresses are
+  // clamped, never predicated, so nothing waits at the load site); zero padding, the
+  // ragged tail and leaky-ReLU are applied when the registers are written to LDS.
+  f32x4 sv[SV];
+  auto stage_load = [&](int c) {
+    int r = r0, v = v0;
+#pragma unroll
+    for (int i = 0; i < SV; ++i) {
+      int ci = c * KCB + (r < KCB ? r : KCB - 1);
+      ci = ci < a.CIN ? ci : a.CIN - 1;
+      int t = tb + 4 * v;
+      t = t < 0 ? 0 : (t > a.ldx - 4 ? a.ldx - 4 : t);
+      sv[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)ci * a.ldx + t);
+      v += dv;
+      r += dr;
+      if (v >= NV) { v -= NV; ++r; }
+    }
+  };
+  auto stage_store = [&](float* buf, int c) {
+    int r = r0, v = v0;
+#pragma unroll
+    for (int i = 0; i < SV; ++i) {
+      if (r < KCB) {
+        const int t = tb + 4 * v;
+        const bool rowok = (c * KCB + r) < a.CIN;
+        f32x4 val = sv[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = rowok && (t + e) >= 0 && (t + e) < len;
+          val[e] = ok ? lrelu(val[e], slope) : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(buf + r * XW + 4 * v) = val;
+      }
+      v += dv;
+      r += dr;
+      if (v >= NV) { v -= NV; ++r; }
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  // A fragments: 8 k-steps (16 channels) of one tap = two float4 per lane: [q][half][lane]
+  const f32x4* wp[MI];
+  f32x4 av[MI][2], avn[MI][2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) +
+             ((size_t)grp * a.nsub_group + ms0 + mi) * nq * 128 + lane;
+    av[mi][0] = wp[mi][0];
+    av[mi][1] = wp[mi][64];
+  }
+
+  stage_load(0);
+  stage_store(xs, 0);
+  __syncthreads();
+
+#define DISSC_MFMA_STEP(KS_, BV)                                                             \
+  _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                          \
+  _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                          \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][(KS_) >> 2][(KS_) & 3], BV[ni], acc[mi][ni], 0, 0, 0);
+
+  const int boff = h * XW + sh + (wn * (32 * NI) + l31) * STRIDE;
+  const int XW2 = 2 * XW;
+  int q = 0;
+  const int nblk = (a.nchunk + CPB - 1) / CPB;
+  for (int cb = 0; cb < nblk; ++cb) {
+    const float* blk = xs + (cb & 1) * (KCB * XW) + boff;
+    const bool more = cb + 1 < nblk;
+#pragma unroll 1
+    for (int sc = 0; sc < CPB; ++sc) {
+      if (cb * CPB + sc >= a.nchunk) break;
+      const float* bj = blk + sc * (KC * XW);
+      float b0[NI], bk[7][NI], b0n[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b0[ni] = bj[ni * 32 * STRIDE];
+      for (int j = 0; j < a.KS; ++j, ++q) {
+        const int qn = (q + 1 < nq) ? q + 1 : q;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          avn[mi][0] = wp[mi][(size_t)qn * 128];
+          avn[mi][1] = wp[mi][(size_t)qn * 128 + 64];
+        }
+        if (j == 0 && sc == 0 && more) stage_load(cb + 1);  // in flight behind this block's MFMAs
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of the MFMAs
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) bk[s][ni] = bj[(s + 1) * XW2 + ni * 32 * STRIDE];
+        DISSC_MFMA_STEP(0, b0)
+        bj += a.dil;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b0n[ni] = bj[ni * 32 * STRIDE];  // next tap's first k-step
+        DISSC_MFMA_STEP(1, bk[0])
+        DISSC_MFMA_STEP(2, bk[1])
+        DISSC_MFMA_STEP(3, bk[2])
+        DISSC_MFMA_STEP(4, bk[3])
+        DISSC_MFMA_STEP(5, bk[4])
+        DISSC_MFMA_STEP(6, bk[5])
+        DISSC_MFMA_STEP(7, bk[6])
+        __builtin_amdgcn_sched_barrier(0);  // the register rotation below must not creep upwards
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b0[ni] = b0n[ni];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          av[mi][0] = avn[mi][0];
+          av[mi][1] = avn[mi][1];
+        }
+      }
+    }
+    if (more) stage_store(xs + ((cb + 1) & 1) * (KCB * XW), cb + 1);
+    __syncthreads();
+  }
+#undef DISSC_MFMA_STEP
+
+  const int epi = a.epi;
+  const size_t ob = (size_t)b * a.o_bstride;
+  // C/D layout of 32x32x2: col = lane & 31 (time), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+  if (a.up != 1) {
+    // ConvTranspose pixel shuffle straight from registers: row = co*np + pi -> out[co][t*up + p0 + pi]
+    const int tbase = t0 + wn * (32 * NI) + l31;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (ms0 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= a.M) continue;
+        const float bz = a.bias[row];  // ConvTranspose path: groups == 1
+        const int co = row / a.up_np;
+        const int p = a.up_p0 + row - co * a.up_np;
+        const size_t rowoff = ob + (size_t)co * a.ldo + p;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int t = tbase + ni * 32;
+          if (t < olen) a.out[rowoff + (size_t)t * a.up] = acc[mi][ni][r] + bz;
+        }
+      }
+    }
+    return;
+  }
+
+  // Transposed epilogue: 8 rows at a time through a wave-private LDS patch [8][CW] -> 16 B per lane.
+  float* ep = xs + wave * (8 * CW);
+  constexpr int LPR = 8 * NI;        // float4 lanes per output row (32*NI columns)
+  constexpr int RPP = 64 / LPR;      // rows per pass
+  constexpr int NPASS = 8 / RPP;
+  const int prow = lane / LPR, pc4 = lane % LPR;
+  const int tcol = t0 + wn * (32 * NI) + 4 * pc4;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {  // rows 8*qd .. 8*qd+7 of the 32-row subtile
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ep[(4 * h + r) * CW + ni * 32 + l31] = acc[mi][ni][qd * 4 + r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int rl = p * RPP + prow;
+        const int row = (ms0 + mi) * 32 + qd * 8 + rl;  // within the group
+        f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * CW + 4 * pc4);
+        if (row >= a.M || tcol >= olen) continue;
+        const int prow_idx = grp * a.nsub_group * 32 + row;  // bias/scale/shift are [groups][Mpad]
+        const float bz = a.bias[prow_idx];
+        v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
+        if (a.scale) {  // eval-mode BatchNorm1d as PyTorch evaluates it: x * alpha + beta
+          const float sc = a.scale[prow_idx], sf = a.shift[prow_idx];
+          v[0] = v[0] * sc + sf; v[1] = v[1] * sc + sf; v[2] = v[2] * sc + sf; v[3] = v[3] * sc + sf;
+        }
+        if (a.act == 1) {
+          v[0] = gelu_exact(v[0]); v[1] = gelu_exact(v[1]); v[2] = gelu_exact(v[2]); v[3] = gelu_exact(v[3]);
+        }
+        const size_t idx = ob + (size_t)(grp * a.M + row) * a.ldo + tcol;
+        const int nv = olen - tcol;  // >= 1
+        if (nv >= 4) {
+          if (epi == EPI_STORE) {
+            *reinterpret_cast<f32x4*>(a.out + idx) = v;
+          } else {
+            const f32x4 rs = *reinterpret_cast<const f32x4*>(a.res + idx);
+            v[0] += rs[0]; v[1] += rs[1]; v[2] += rs[2]; v[3] += rs[3];
+            if (epi == EPI_RES) {
+              *reinterpret_cast<f32x4*>(a.out + idx) = v;
+            } else if (epi == EPI_MRF_SET) {
+              *reinterpret_cast<f32x4*>(a.acc + idx) = v;
+            } else {
+              const f32x4 ac = *reinterpret_cast<const f32x4*>(a.acc + idx);
+              v[0] = ac[0] + v[0]; v[1] = ac[1] + v[1]; v[2] = ac[2] + v[2]; v[3] = ac[3] + v[3];
+              if (epi == EPI_MRF_DIV) {
+                v[0] = __fdiv_rn(v[0], a.mrf_div); v[1] = __fdiv_rn(v[1], a.mrf_div);
+                v[2] = __fdiv_rn(v[2], a.mrf_div); v[3] = __fdiv_rn(v[3], a.mrf_div);
+              }
+              *reinterpret_cast<f32x4*>(a.acc + idx) = v;
+            }
+          }
+        } else {
+          for (int e = 0; e < nv; ++e) {
+            float x = v[e];
+            if (epi == EPI_STORE) {
+              a.out[idx + e] = x;
+            } else {
+              x += a.res[idx + e];
+              if (epi == EPI_RES) {
+                a.out[idx + e] = x;
+              } else if (epi == EPI_MRF_SET) {
+                a.acc[idx + e] = x;
+              } else {
+                x = a.acc[idx + e] + x;
+                if (epi == EPI_MRF_DIV) x = __fdiv_rn(x, a.mrf_div);
+                a.acc[idx + e] = x;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+// Tile shapes (32-unit wave tiles): BM = 32*MI*WM, BN = 32*NI*WN.
+struct TileCfg32 { int MI, NI, WM, WN; };
+static const TileCfg32 kCfgs32[] = {
+    {2, 2, 4, 1},  // 0: 256 x 64
+    {2, 2, 2, 2},  // 1: 128 x 128
+    {1, 2, 2, 2},  // 2:  64 x 128
+    {1, 2, 1, 4},  // 3:  32 x 256
+    {1, 4, 1, 4},  // 4:  32 x 512
+    {2, 2, 1, 4},  // 5:  64 x 256
+};
+static int g_cfg32_for_bm[4] = {3, 2, 1, 0};  // BM class 32, 64, 128, 256 -> cfg id
+
+void conv32_set_cfg(int bm_class, int cfg) {
+  if (bm_class >= 0 && bm_class < 4 && cfg >= 0 && cfg < 6) g_cfg32_for_bm[bm_class] = cfg;
+}
+
+static int bm32_of(int M) { return M >= 256 ? 256 : (M >= 128 ? 128 : (M >= 64 ? 64 : 32)); }
+
+int conv32_cfg(int M) {
+  const int bm = bm32_of(M);
+  int cls = 0;
+  while ((32 << cls) < bm) ++cls;
+  int cfg = g_cfg32_for_bm[cls];
+  if (32 * kCfgs32[cfg].MI * kCfgs32[cfg].WM > bm) cfg = 3 - cls;
+  if (cfg == 4 && cls != 0) cfg = 3 - cls;
+  return cfg;
+}
+
+int conv32_tile_bn(int M) {
+  const TileCfg32& c = kCfgs32[conv32_cfg(M)];
+  return 32 * c.NI * c.WN;
+}
+
+// w: [Cout][Cin][KS] with Cin per group.  Layout [group][ms32][chunk][tap][half][lane][4]:
+// lane l, half hf, component e -> k-step ks = 4*hf + e -> W[32*ms + (l & 31)][16*c + 2*ks + (l >> 5)][tap]
+void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
+                         int& Mpad, int& nchunk, int groups) {
+  const int Mg = Cout / groups;
+  const int bm = bm32_of(Mg);
+  Mpad = (Mg + bm - 1) / bm * bm;
+  nchunk = (Cin + KC - 1) / KC;
+  const int nsub = Mpad / 32;
+  packed.assign((size_t)groups * nsub * nchunk * KS * 2 * 64 * 4, 0.f);
+  for (int gi = 0; gi < groups; ++gi)
+    for (int ms = 0; ms < nsub; ++ms)
+      for (int c = 0; c < nchunk; ++c)
+        for (int j = 0; j < KS; ++j)
+          for (int hf = 0; hf < 2; ++hf)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 4; ++e) {
+                const int co = ms * 32 + (lane & 31);
+                const int ci = c * KC + 2 * (4 * hf + e) + (lane >> 5);
+                if (co < Mg && ci < Cin)
+                  packed[((((((size_t)gi * nsub + ms) * nchunk + c) * KS + j) * 2 + hf) * 64 + lane) * 4 + e] =
+                      w[((size_t)(gi * Mg + co) * Cin + ci) * KS + j];
+              }
+}
+
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1>
+static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
+  constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN, NW = WM * WN;
+  constexpr int CW = 32 * NI + 4;
+  a.mt_per_group = (a.M + BM - 1) / BM;
+  dim3 grid((Lmax_out + BN - 1) / BN, a.mt_per_group * a.groups, B);
+  size_t lds_f = (size_t)2 * KC * CPB * a.XW;
+  if (lds_f < (size_t)NW * 8 * CW) lds_f = (size_t)NW * 8 * CW;
+  const size_t lds = lds_f * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    DISSC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>), grid, dim3(64 * WM * WN), lds,
+                     stream, a);
+  DISSC_HIP_CHECK(hipGetLastError());
+  return DISSC_OK;
+}
+
+int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t stream) {
+  const int span = (a.KS - 1) * a.dil;
+  const int cfg = conv32_cfg(a.M);
+  if (stride == 2 && span <= MAX_TAP_SPAN && a.up == 1) {
+    if (cfg == 0) return launch32_t<2, 2, 4, 1, 2, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    set_error("launch_conv32: stride 2 needs >= 256 output rows (got %d)", a.M);
+    return DISSC_EINVAL;
+  }
+  if (stride != 1) {
+    set_error("launch_conv32: stride %d unsupported", stride);
+    return DISSC_EINVAL;
+  }
+  if (span > MAX_TAP_SPAN) {
+    if (span <= WIDE_TAP_SPAN && cfg == 3) return launch32_t<1, 2, 1, 4, 1, WIDE_TAP_SPAN>(a, B, Lmax_out, stream);
+    set_error("launch_conv32: kernel %d x dilation %d unsupported for %d rows", a.KS, a.dil, a.M);
+    return DISSC_EINVAL;
+  }
+  if (span == 0 && cfg == 0 && a.nchunk >= 8)  // 1x1 convs: 64 channels per barrier
+    return launch32_t<2, 2, 4, 1, 1, 0, 4>(a, B, Lmax_out, stream);
+  switch (cfg) {
+    case 0: return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 1: return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 2: return launch32_t<1, 2, 2, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 3: return launch32_t<1, 2, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 4: return launch32_t<1, 4, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    default: return launch32_t<2, 2, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+  }
+}
+
+}  // namespace dissc

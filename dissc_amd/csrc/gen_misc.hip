@@ -134,6 +134,24 @@ void launch_wav_postprocess(float* wav, const int32_t* n_samples, int B, int ld,
 
 // ---- diagnostics: sustained fp32 MFMA rate of this GPU at its real clocks -------------
 namespace dissc {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) mfma_peak32_kernel(float* out, int iters) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  const float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f + 1.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][7] + acc[i][15];
+  if (s == 12345.678f) out[0] = s;
+}
+
 __global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters) {
   f32x4 acc[8];
 #pragma unroll
@@ -152,16 +170,20 @@ __global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters) {
 
 extern "C" int dissc_mfma_peak(int iters, float* tflops) {
   using namespace dissc;
-  if (!tflops || iters <= 0) return DISSC_EINVAL;
+  if (!tflops || iters == 0) return DISSC_EINVAL;
   float* d = nullptr;
   DISSC_HIP_CHECK(hipMalloc((void**)&d, 16));
   hipEvent_t e0, e1;
   DISSC_HIP_CHECK(hipEventCreate(&e0));
   DISSC_HIP_CHECK(hipEventCreate(&e1));
+  const bool use32 = iters < 0;  // negative iters: the 32x32x2 form (same FLOPs per iteration)
+  if (use32) iters = -iters;
   const int blocks = 256 * 4;  // 4 blocks x 4 waves per CU
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, d, 100);
+  if (use32) hipLaunchKernelGGL(mfma_peak32_kernel, dim3(blocks), dim3(256), 0, nullptr, d, 100);
+  else hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, d, 100);
   DISSC_HIP_CHECK(hipEventRecord(e0, nullptr));
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, d, iters);
+  if (use32) hipLaunchKernelGGL(mfma_peak32_kernel, dim3(blocks), dim3(256), 0, nullptr, d, iters);
+  else hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, d, iters);
   DISSC_HIP_CHECK(hipEventRecord(e1, nullptr));
   DISSC_HIP_CHECK(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -398,6 +398,14 @@ int dissc_set_option(const char* key, int value) {
   }
   if (strcmp(key, "fused_bn16") == 0) { fused_set_option(0, value); return DISSC_OK; }
   if (strcmp(key, "fused_bn32") == 0) { fused_set_option(1, value); return DISSC_OK; }
+  if (strcmp(key, "mfma32") == 0) { g_use_mfma32 = value; return DISSC_OK; }
+  if (strncmp(key, "conv32_cfg_bm", 13) == 0) {
+    const int bm = atoi(key + 13);
+    int cls = 0;
+    while ((32 << cls) < bm) ++cls;
+    conv32_set_cfg(cls, value);
+    return DISSC_OK;
+  }
   if (strcmp(key, "fused_max_c") == 0) { fused_set_option(2, value); return DISSC_OK; }
   if (strcmp(key, "fused_variant") == 0) { fused_set_option(3, value); return DISSC_OK; }
   set_error("dissc_set_option: unknown key %s", key);

@@ -26,5 +26,6 @@ e1.record(); torch.cuda.synchronize()
 print(json.dumps(opts), round(e0.elapsed_time(e1) / 10, 3), "ms/step")
 ''' % ROOT
 import json
-for opts in ({"fused_max_c": 0}, {"fused_max_c": 16}, {"fused_max_c": 16, "fused_variant": 3}, {"fused_max_c": 16, "fused_variant": 4}):
+SETS = [json.loads(x) for x in sys.argv[1:]] or [{"fused_max_c": 0}, {"fused_max_c": 16}]
+for opts in SETS:
     subprocess.run([sys.executable, "-c", CODE, json.dumps(opts)], check=False)
