@@ -58,6 +58,7 @@ struct ConvArgs {
   int mt_per_group;     // M tiles (blockIdx.y) per group
   int nsub_group;       // 16-row subtiles per group in the packed weights / bias arrays
   int act;              // 0 none, 1 exact GELU on (conv + bias) before any residual
+  int mfast;            // 1: blockIdx.x walks the M tiles (XCD i keeps M tiles i, i+8, ... of the weights in its L2)
   int m32;              // 1: weights packed for / launched on the 32x32x2 kernel (conv_mfma32.hip)
   int CIN, M, KS, dil, nchunk;
   int XW;               // LDS row stride (floats), XW % 32 == 16
@@ -87,6 +88,7 @@ int conv32_cfg(int M);
 void conv32_set_cfg(int bm_class, int cfg);
 void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
                          int& Mpad, int& nchunk, int groups);
+extern int g_mfast;       // tuning: 0 disables the M-fastest block order
 extern int g_use_mfma32;  // tuning: 0 forces the 16x16x4 kernel everywhere
 
 // Host-side weight packing.  w: [Cout][Cin][KS] (Conv1d layout).  Returns the packed

@@ -118,6 +118,7 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
   a.lengths_out = io.lengths_out; a.olen_default = io.olen_default;
   a.CIN = dc.CIN; a.M = dc.M; a.KS = dc.KS; a.dil = dc.dil; a.nchunk = dc.nchunk;
   a.pad_left = dc.pad_left >= 0 ? dc.pad_left : ((dc.KS - 1) * dc.dil) / 2;
+  a.mfast = 0;
   a.groups = dc.groups; a.nsub_group = dc.Mpad / (dc.m32 ? 32 : 16); a.act = dc.act; a.m32 = dc.m32;
   a.XW = conv_xw(dc.M, dc.KS, dc.dil, dc.stride, dc.m32);
   a.ldx = ldx; a.ldo = ldo;

@@ -398,6 +398,7 @@ int dissc_set_option(const char* key, int value) {
   }
   if (strcmp(key, "fused_bn16") == 0) { fused_set_option(0, value); return DISSC_OK; }
   if (strcmp(key, "fused_bn32") == 0) { fused_set_option(1, value); return DISSC_OK; }
+  if (strcmp(key, "mfast") == 0) { g_mfast = value; return DISSC_OK; }
   if (strcmp(key, "mfma32") == 0) { g_use_mfma32 = value; return DISSC_OK; }
   if (strncmp(key, "conv32_cfg_bm", 13) == 0) {
     const int bm = atoi(key + 13);
