@@ -31,6 +31,8 @@ void set_error(const char* fmt, ...) {
 
 using namespace dissc;
 
+static int g_multistream = 1;  // "multistream" option: concurrent ResBlock chains (read at create)
+
 struct dissc_gen {
   DisscGenConfig cfg;
   int hop = 1;
@@ -44,6 +46,11 @@ struct dissc_gen {
   float* dict_w = nullptr;
   float* spkr_w = nullptr;
   std::vector<int> stage_C, stage_mul;  // channels / length multiplier after ups[i]
+  // The num_kernels ResBlocks of a stage are independent until the MRF accumulate: they run as
+  // concurrent chains (chain 0 on the caller's stream, the others on these) so bandwidth-bound
+  // small-kernel layers overlap with matrix-bound large-kernel ones.
+  hipStream_t aux[DISSC_MAX_RK] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_x = nullptr, ev_fin[DISSC_MAX_RK] = {nullptr, nullptr, nullptr, nullptr};
   ~dissc_gen() {
     free_conv(conv_pre);
     for (auto& v : ups) for (auto& c : v) free_conv(c);
@@ -53,6 +60,11 @@ struct dissc_gen {
     for (float* p : fused_b) if (p) (void)hipFree(p);
     if (post_w) (void)hipFree(post_w);
     if (post_b) (void)hipFree(post_b);
+    for (int j = 0; j < DISSC_MAX_RK; ++j) {
+      if (aux[j]) (void)hipStreamDestroy(aux[j]);
+      if (ev_fin[j]) (void)hipEventDestroy(ev_fin[j]);
+    }
+    if (ev_x) (void)hipEventDestroy(ev_x);
     if (dict_w) (void)hipFree(dict_w);
     if (spkr_w) (void)hipFree(spkr_w);
   }
@@ -214,6 +226,14 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
     if ((rc = upload(std::vector<float>(w, w + (size_t)cfg->num_speakers * E), &g->spkr_w)))
       return fail(rc);
   }
+  if (g_multistream && nk > 1) {
+    if (hipEventCreateWithFlags(&g->ev_x, hipEventDisableTiming) != hipSuccess) return fail(DISSC_EHIP);
+    for (int j = 0; j < nk; ++j) {
+      if (hipEventCreateWithFlags(&g->ev_fin[j], hipEventDisableTiming) != hipSuccess) return fail(DISSC_EHIP);
+      if (j > 0 && hipStreamCreateWithFlags(&g->aux[j], hipStreamNonBlocking) != hipSuccess)
+        return fail(DISSC_EHIP);
+    }
+  }
   *out = g;
   return DISSC_OK;
 }
@@ -232,7 +252,7 @@ static size_t gen_buf_floats(const dissc_gen* g, int B, int Tmax) {
 
 size_t dissc_gen_workspace_bytes(dissc_gen_t g, int B, int Tmax) {
   if (!g || B <= 0 || Tmax <= 0) return 0;
-  return 4 * gen_buf_floats(g, B, Tmax) * sizeof(float) + 256;
+  return (size_t)(2 + 2 * g->cfg.num_kernels) * gen_buf_floats(g, B, Tmax) * sizeof(float) + 256;
 }
 
 double dissc_gen_flops(dissc_gen_t g, int64_t frames) {
@@ -275,9 +295,15 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
   const size_t nbuf = gen_buf_floats(g, B, Tmax);
   float* base = (float*)round_up((size_t)workspace, 256);
   float* X = base;
-  float* TMP = base + nbuf;
-  float* XK = base + 2 * nbuf;
-  float* ACC = base + 3 * nbuf;
+  float* ACC = base + nbuf;
+  float* TMPj[DISSC_MAX_RK];
+  float* XKj[DISSC_MAX_RK];
+  for (int j = 0; j < g->cfg.num_kernels; ++j) {
+    TMPj[j] = base + (size_t)(2 + 2 * j) * nbuf;
+    XKj[j] = base + (size_t)(3 + 2 * j) * nbuf;
+  }
+  float* TMP = TMPj[0];
+  const bool multi = g->ev_x != nullptr;
   const DisscGenConfig& c = g->cfg;
   int rc;
 
@@ -302,31 +328,44 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
         return rc;
     ch = ch_out; mul = mul_out; ld = ld_out;
     const int L = Tmax * mul;
+    if (multi) DISSC_HIP_CHECK(hipEventRecord(g->ev_x, stream));  // X is ready
     for (int j = 0; j < nk; ++j) {
+      hipStream_t sj = (multi && j > 0) ? g->aux[j] : stream;
+      if (multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_x, 0));
       if (g->fused_w[(size_t)i * nk + j]) {  // narrow stage: the whole ResBlock in one launch
         const int epi = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET)
                                  : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
+        if (multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));
         if ((rc = launch_resblock_fused(ch, X, ACC, g->fused_w[(size_t)i * nk + j],
                                         g->fused_b[(size_t)i * nk + j], lengths, L, mul,
                                         c.resblock_kernel_sizes[j], c.resblock_dilations[j], B, L, ld,
-                                        0.1f, epi, (float)nk, stream)))
+                                        0.1f, epi, (float)nk, sj)))
           return rc;
+        if (multi) DISSC_HIP_CHECK(hipEventRecord(g->ev_fin[j], sj));
         continue;
       }
+      float* TMPc = multi ? TMPj[j] : TMPj[0];
+      float* XKc = multi ? XKj[j] : XKj[0];
       for (int m = 0; m < 3; ++m) {
         const size_t idx = ((size_t)i * nk + j) * 3 + m;
-        const float* xin = (m == 0) ? X : XK;
-        if ((rc = run_conv(g->rb1[idx], xin, TMP, nullptr, nullptr, lengths, L, mul, B, ch, ld, ld,
-                           L, 0.1f, EPI_STORE, 1.f, stream)))
+        const float* xin = (m == 0) ? X : XKc;
+        if ((rc = run_conv(g->rb1[idx], xin, TMPc, nullptr, nullptr, lengths, L, mul, B, ch, ld, ld,
+                           L, 0.1f, EPI_STORE, 1.f, sj)))
           return rc;
         int epi = EPI_RES;
-        if (m == 2) epi = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET)
-                                   : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
-        if ((rc = run_conv(g->rb2[idx], TMP, XK, xin, ACC, lengths, L, mul, B, ch, ld, ld, L, 0.1f,
-                           epi, (float)nk, stream)))
+        if (m == 2) {
+          epi = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET)
+                         : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
+          // xs = r0; xs += r1; x = (xs + r2)/3: only the chains' LAST convs are ordered
+          if (multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));
+        }
+        if ((rc = run_conv(g->rb2[idx], TMPc, XKc, xin, ACC, lengths, L, mul, B, ch, ld, ld, L, 0.1f,
+                           epi, (float)nk, sj)))
           return rc;
       }
+      if (multi) DISSC_HIP_CHECK(hipEventRecord(g->ev_fin[j], sj));
     }
+    if (multi) DISSC_HIP_CHECK(hipStreamWaitEvent(stream, g->ev_fin[nk - 1], 0));  // stage output complete
   }
   // tail: lrelu(0.01) -> conv_post -> tanh
   launch_conv_post(ACC, g->post_w, g->post_b, lengths, mul, B, ch, g->post_KS, Tmax * mul, ld,
@@ -398,6 +437,7 @@ int dissc_set_option(const char* key, int value) {
   }
   if (strcmp(key, "fused_bn16") == 0) { fused_set_option(0, value); return DISSC_OK; }
   if (strcmp(key, "fused_bn32") == 0) { fused_set_option(1, value); return DISSC_OK; }
+  if (strcmp(key, "multistream") == 0) { g_multistream = value; return DISSC_OK; }
   if (strcmp(key, "mfast") == 0) { g_mfast = value; return DISSC_OK; }
   if (strcmp(key, "mfma32") == 0) { g_use_mfma32 = value; return DISSC_OK; }
   if (strncmp(key, "conv32_cfg_bm", 13) == 0) {
