@@ -94,7 +94,7 @@ def main():
     torch.cuda.set_device(dev)
 
     import dissc_amd
-    from oracle import synth  # synthetic weights/inputs + the cpu_baseline leg only
+    import synthdata as synth  # deterministic synthetic checkpoints / inputs
 
     sd = synth.synth_generator_state_dict(seed=0)
     g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to(dev)

@@ -293,12 +293,15 @@ static const TileCfg32 kCfgs32[] = {
     {1, 2, 1, 4},  // 3:  32 x 256
     {1, 4, 1, 4},  // 4:  32 x 512
     {2, 2, 1, 4},  // 5:  64 x 256
+    {2, 2, 4, 2},  // 6: 256 x 128 (8 waves)
+    {2, 2, 2, 4},  // 7: 128 x 256 (8 waves)
 };
+int g_cpb2 = 0;  // "cpb2" option: kernels with KS <= this stage 32 channels per barrier
 int g_mfast = 0;  // measured neutral on HuBERT linears (weights are L2/MALL resident either way)
 static int g_cfg32_for_bm[4] = {3, 2, 1, 0};  // BM class 32, 64, 128, 256 -> cfg id
 
 void conv32_set_cfg(int bm_class, int cfg) {
-  if (bm_class >= 0 && bm_class < 4 && cfg >= 0 && cfg < 6) g_cfg32_for_bm[bm_class] = cfg;
+  if (bm_class >= 0 && bm_class < 4 && cfg >= 0 && cfg < 8) g_cfg32_for_bm[bm_class] = cfg;
 }
 
 static int bm32_of(int M) { return M >= 256 ? 256 : (M >= 128 ? 128 : (M >= 64 ? 64 : 32)); }
@@ -386,14 +389,21 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
     set_error("launch_conv32: kernel %d x dilation %d unsupported for %d rows", a.KS, a.dil, a.M);
     return DISSC_EINVAL;
   }
-  if (span == 0 && cfg == 0 && a.nchunk >= 8)  // 1x1 convs: 64 channels per barrier
+  if (span == 0 && bm32_of(a.M) == 256 && a.nchunk >= 8)  // 1x1 convs: 64 channels per barrier
     return launch32_t<2, 2, 4, 1, 1, 0, 4>(a, B, Lmax_out, stream);
+  if (g_cpb2 && a.KS <= g_cpb2 && a.nchunk >= 4 && a.up == 1) {  // two chunks per barrier for short kernels
+    if (cfg == 0) return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
+    if (cfg == 1) return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
+    if (cfg == 2) return launch32_t<1, 2, 2, 2, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
+  }
   switch (cfg) {
     case 0: return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     case 1: return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     case 2: return launch32_t<1, 2, 2, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     case 3: return launch32_t<1, 2, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     case 4: return launch32_t<1, 4, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 6: return launch32_t<2, 2, 4, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 7: return launch32_t<2, 2, 2, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     default: return launch32_t<2, 2, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
   }
 }

@@ -1,4 +1,7 @@
-"""Deterministic synthetic checkpoints and inputs (test infrastructure).
+"""Deterministic synthetic checkpoints and inputs for tests, benchmarks and profiling.
+
+Not part of the oracle and not part of the compute path: pure numpy/torch generators of
+random-but-reproducible weights in the reference's checkpoint layouts and of input batches.
 
 No real DISSC checkpoint exists offline (Google-Drive links, reference
 README.md:76,93,117,142), so parity is pinned on synthetic weights laid out

@@ -4,7 +4,7 @@
 
 Imports the reference modules unmodified from /root/reference (which does not
 exist on the GPU box -- only the .npz outputs travel).  Weights/inputs come
-from oracle/synth.py (numpy RandomState, reproducible anywhere), are loaded
+from synthdata.py (numpy RandomState, reproducible anywhere), are loaded
 into the reference modules with strict ``load_state_dict`` (which also pins our
 checkpoint key/shape layout against the reference's), and the reference's
 outputs are stored.  Nothing of the reference's source is stored.
@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
 
-from oracle import synth  # noqa: E402
+import synthdata as synth  # noqa: E402
 
 
 def _import_ref_sr():

@@ -42,7 +42,7 @@ def test_abi_version_and_error_string(built):
 
 def test_generator_wrapper_host_logic(built):
     import torch
-    from oracle import synth
+    import synthdata as synth
     g = built.CodeGenerator(synth.VCTK_CONFIG)
     sd = synth.synth_generator_state_dict(0)
     g.load_state_dict(sd)

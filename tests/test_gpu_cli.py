@@ -29,7 +29,7 @@ def gpu():
 
 
 def test_infer_cli_matches_reference(gpu, golden_dir, tmp_path):
-    from oracle import synth
+    import synthdata as synth
     g = np.load(os.path.join(golden_dir, "pred.npz"))
     td = str(tmp_path)
     for d in ("len", "pitch", "out", "in"):
@@ -60,7 +60,7 @@ def test_infer_cli_matches_reference(gpu, golden_dir, tmp_path):
 
 
 def test_sr_inference_cli_matches_reference(gpu, golden_dir, tmp_path):
-    from oracle import synth
+    import synthdata as synth
     g = np.load(os.path.join(golden_dir, "sr_inference.npz"))
     td = str(tmp_path)
     for d in ("ckpt", "wav", "out", "meta"):
@@ -99,7 +99,7 @@ def test_sr_inference_cli_matches_reference(gpu, golden_dir, tmp_path):
 def test_encode_cli_roundtrip(gpu, golden_dir, tmp_path):
     """data/encode.py on the reference's two fixture wavs: units equal the CPU oracle's."""
     from oracle import hubert_ref as hr
-    from oracle import synth
+    import synthdata as synth
     td = str(tmp_path)
     os.makedirs(f"{td}/ckpt")
     os.makedirs(f"{td}/wav")

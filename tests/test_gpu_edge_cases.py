@@ -16,7 +16,7 @@ def env():
     import dissc_amd
     from dissc_amd import _lib
     from oracle import generator_ref as gr
-    from oracle import synth
+    import synthdata as synth
     sd = synth.synth_generator_state_dict(seed=0)
     g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
     g.load_state_dict(sd)

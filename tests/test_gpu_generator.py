@@ -18,7 +18,7 @@ def env():
     import dissc_amd
     from dissc_amd import _lib
     from oracle import generator_ref as gr
-    from oracle import synth
+    import synthdata as synth
     sd = synth.synth_generator_state_dict(seed=0)
     g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
     g.load_state_dict(sd)
@@ -184,7 +184,7 @@ def test_fused_resblock_option_keeps_parity(golden_dir):
 import sys, numpy as np, torch
 sys.path.insert(0, %r)
 import dissc_amd
-from oracle import synth
+import synthdata as synth
 g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
 g.load_state_dict(synth.synth_generator_state_dict(0)); g.eval().remove_weight_norm()
 gold = np.load(%r)

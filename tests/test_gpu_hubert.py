@@ -14,7 +14,7 @@ def env(golden_dir):
         pytest.skip("no GPU")
     from dissc_amd.hubert import HubertEncoder
     from oracle import hubert_ref as hr
-    from oracle import synth
+    import synthdata as synth
     sd = synth.synth_hubert_state_dict(6)
     centers = synth.synth_kmeans_centers()
     enc = HubertEncoder(sd, centers, n_layers=6).to("cuda:0")

@@ -14,7 +14,7 @@ def env(golden_dir):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from dissc_amd import predictors as P
-    from oracle import synth
+    import synthdata as synth
     g = np.load(os.path.join(golden_dir, "pred.npz"))
     lm = P.LenPredictor(n_tokens=100, n_speakers=108).to("cuda:0")
     lm.load_state_dict(synth.synth_len_state_dict(100, 108))

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import generator_ref as gr
-from oracle import synth
+import synthdata as synth
 
 
 @pytest.fixture(scope="module")

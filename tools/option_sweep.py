@@ -9,7 +9,7 @@ import sys, json, torch
 sys.path.insert(0, %r)
 import dissc_amd
 from dissc_amd._lib import lib
-from oracle import synth
+import synthdata as synth
 opts = json.loads(sys.argv[1])
 for k, v in opts.items():
     assert lib.dissc_set_option(k.encode(), int(v)) == 0

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dissc_amd  # noqa: E402
 from dissc_amd import predictors as P  # noqa: E402
 from dissc_amd.hubert import HubertEncoder  # noqa: E402
-from oracle import synth  # noqa: E402  (synthetic checkpoints / inputs only)
+import synthdata as synth  # noqa: E402  (synthetic checkpoints / inputs only)
 
 
 def main():
