@@ -57,6 +57,30 @@ def cpu_baseline(synth, sd, code, f0, spkr, budget_s=12.0, max_utts=400):
                       f"{threads} threads (best of a probe; {avail} logical CPUs available), {dt:.1f} s wall"}
 
 
+class _FakeGenerator:
+    """CPU stand-in used only by the DISSC_BENCH_FAKE dry run."""
+
+    def __call__(self, code, f0, spkr):
+        return (code.float().mean(1, keepdim=True) + spkr.float()).unsqueeze(2).expand(-1, 1, 320 * code.shape[1]).contiguous()
+
+    def flops(self, frames):
+        return 321.664e6 * frames
+
+
+class _FakeEvent:
+    def __init__(self, enable_timing=True):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def synchronize(self):
+        pass
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
 def hbm_traffic(B, T):
     """HBM bytes per step from the committed PMC capture (profiles/r01/hbm_traffic.json:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950
@@ -78,6 +102,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    # DISSC_BENCH_FAKE=1: CPU/gloo dry run of the distributed bookkeeping only (tests/test_bench_dist.py);
+    # it measures nothing and never replaces the HIP path in a real run.
+    fake = os.environ.get("DISSC_BENCH_FAKE") == "1"
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -86,21 +113,28 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if fake:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     n_gpus = world
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
-    import dissc_amd
     import synthdata as synth  # deterministic synthetic checkpoints / inputs
-
     sd = synth.synth_generator_state_dict(seed=0)
-    g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to(dev)
-    g.load_state_dict(sd)
-    g.eval()
-    g.remove_weight_norm()
+    if fake:
+        dev = torch.device("cpu")
+        g = _FakeGenerator()
+        torch.cuda.synchronize = lambda *a, **k: None
+        torch.cuda.Event = _FakeEvent
+    else:
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+        import dissc_amd
+        g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to(dev)
+        g.load_state_dict(sd)
+        g.eval()
+        g.remove_weight_norm()
 
     B, T = a.batch, a.frames
     code, f0, spkr, _ = synth.synth_generator_inputs(B, T, seed=1234 + rank)

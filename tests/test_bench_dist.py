@@ -1,0 +1,31 @@
+"""bench.py's N>1 bookkeeping (barrier, per-rank inputs, all-gather shapes, max-over-ranks timing,
+one JSON line on rank 0) exercised on CPU with gloo through the same launcher the driver uses.
+The generator itself is replaced by a stand-in (DISSC_BENCH_FAKE=1): this checks plumbing only."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_gloo_dry_run():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, DISSC_BENCH_FAKE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--frames", "20"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["unit"] == "audio-sec/sec" and j["value"] > 0 and j["higher_is_better"] is True
+    # whole-job aggregate: 2 ranks x 4 utterances x 20 frames x 20 ms per step
+    assert abs(j["value"] * j["ms_per_step"] / 1e3 - 2 * 4 * 20 * 0.02) < 1e-3 * 2 * 4 * 20 * 0.02 + 1e-2
+    assert "cpu_baseline" not in j and j["roofline"]["bound"] == "mfma"
