@@ -296,6 +296,7 @@ static const TileCfg32 kCfgs32[] = {
     {2, 2, 4, 2},  // 6: 256 x 128 (8 waves)
     {2, 2, 2, 4},  // 7: 128 x 256 (8 waves)
 };
+int g_lin_tile = 2;  // "lin_tile" option: channels per barrier / 16 of the 1x1 (linear) convs (2 or 4)
 int g_cpb2 = 0;  // "cpb2" option: kernels with KS <= this stage 32 channels per barrier
 int g_mfast = 0;  // measured neutral on HuBERT linears (weights are L2/MALL resident either way)
 static int g_cfg32_for_bm[4] = {3, 2, 1, 0};  // BM class 32, 64, 128, 256 -> cfg id
@@ -389,8 +390,11 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
     set_error("launch_conv32: kernel %d x dilation %d unsupported for %d rows", a.KS, a.dil, a.M);
     return DISSC_EINVAL;
   }
-  if (span == 0 && bm32_of(a.M) == 256 && a.nchunk >= 8)  // 1x1 convs: 64 channels per barrier
-    return launch32_t<2, 2, 4, 1, 1, 0, 4>(a, B, Lmax_out, stream);
+  if (span == 0 && bm32_of(a.M) == 256 && a.nchunk >= 8) {  // 1x1 convs: 64 channels per barrier
+    // (the tile must stay the default 256 x 64: a.XW was sized for its BN)
+    if (g_lin_tile == 4) return launch32_t<2, 2, 4, 1, 1, 0, 4>(a, B, Lmax_out, stream);  // 64 ch / barrier
+    return launch32_t<2, 2, 4, 1, 1, 0, 2>(a, B, Lmax_out, stream);                        // 32 ch / barrier
+  }
   if (g_cpb2 && a.KS <= g_cpb2 && a.nchunk >= 4 && a.up == 1) {  // two chunks per barrier for short kernels
     if (cfg == 0) return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
     if (cfg == 1) return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
