@@ -122,3 +122,61 @@ def test_encode_cli_roundtrip(gpu, golden_dir, tmp_path):
         top2 = torch.topk(dist, 2, largest=False).values
         safe = ((top2[:, 1] - top2[:, 0]) > 0.02).numpy()
         np.testing.assert_array_equal(np.array(d["units"])[safe], units.numpy()[safe])
+
+
+def test_in_memory_converter_equals_file_pipeline(gpu, golden_dir, tmp_path):
+    """dissc_amd.pipeline.Converter (device-resident hand-off) == encode.py -> infer.py ->
+    sr/inference.py through JSONL files, sample for sample."""
+    import synthdata as synth
+    import dissc_amd
+    from dissc_amd import predictors as P
+    from dissc_amd.hubert import HubertEncoder
+    from dissc_amd.pipeline import Converter
+    td = str(tmp_path)
+    for d in ("hub", "wav", "enc", "len", "pitch", "pred", "ckpt", "meta", "out"):
+        os.makedirs(f"{td}/{d}")
+    hsd, centers = synth.synth_hubert_state_dict(6), synth.synth_kmeans_centers()
+    torch.save({"model": hsd}, f"{td}/hub/hubert-base-ls960.pt")
+    np.save(f"{td}/hub/kmeans_100.npy", centers.numpy())
+    names = ["p226_001.wav", "p300_002.wav"]
+    for i, nm in enumerate(names):
+        shutil.copy(os.path.join(golden_dir, f"s1_{i + 1}.wav"), f"{td}/wav/{nm}")
+    torch.save(synth.synth_len_state_dict(100, 108), f"{td}/len/best_model.pth")
+    torch.save(synth.synth_len_norm_stats(), f"{td}/len/len_norm_stats.pth")
+    torch.save(synth.synth_pitch_state_dict("new", 100, 108), f"{td}/pitch/best_model.pth")
+    shutil.copy(os.path.join(golden_dir, "vctk_id_to_spkr.pkl"), f"{td}/enc/id_to_spkr.pkl")
+    shutil.copy(os.path.join(golden_dir, "vctk_id_to_spkr.pkl"), f"{td}/meta/id_to_spkr.pkl")
+    cfg = dict(synth.VCTK_CONFIG, input_training_file=f"{td}/meta/train.txt", f0_normalize=False, f0_stats=None)
+    json.dump(cfg, open(f"{td}/ckpt/config.json", "w"))
+    gsd = synth.synth_generator_state_dict(seed=0)
+    torch.save({"generator": gsd}, f"{td}/ckpt/g_00000001")
+    # file pipeline
+    _load("enc_cli2", "data/encode.py").main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/enc/val.txt",
+                                              "--checkpoint_dir", f"{td}/hub"])
+    _load("infer_cli2", "infer.py").main(["--input_path", f"{td}/enc/val.txt", "-n", "10", "--out_path", f"{td}/pred",
+                                          "--pred_len", "--pred_pitch", "--len_model", f"{td}/len/", "--f0_model",
+                                          f"{td}/pitch/", "--f0_path", os.path.join(golden_dir, "vctk_f0_stats.pkl"),
+                                          "--vc", "--target_speakers", "p231"])
+    _load("sr_cli2", "sr/inference.py").main(["--input_code_file", f"{td}/pred/p231_val.txt", "--data_path", f"{td}/wav",
+                                              "--output_dir", f"{td}/out", "--checkpoint_file", f"{td}/ckpt/", "--vc",
+                                              "--target-speakers", "p231", "--unseen_speaker", "--id_to_spkr",
+                                              f"{td}/meta/id_to_spkr.pkl", "-n", "-1"])
+    # in-memory pipeline with the same models
+    enc = HubertEncoder(hsd, centers, 6).to("cuda:0")
+    lm = P.LenPredictor(100, 108).to("cuda:0")
+    lm.load_state_dict(synth.synth_len_state_dict(100, 108))
+    lm.norm_mean, lm.norm_std = synth.synth_len_norm_stats()
+    pm = P.PitchPredictor(100, 108).to("cuda:0")
+    pm.load_state_dict(synth.synth_pitch_state_dict("new", 100, 108))
+    g = dissc_amd.CodeGenerator(cfg).to("cuda:0")
+    g.load_state_dict(gsd)
+    g.eval().remove_weight_norm()
+    cli = _load("enc_cli3", "data/encode.py")
+    waves = [cli.load_wav(f"{td}/wav/{nm}")[0] for nm in names]
+    out = Converter(enc, lm, pm, g)(waves, [6])  # p231 = id 6
+    for i, nm in enumerate(names):
+        rate, ref = wavfile.read(f"{td}/out/{nm[:-4]}_6_gen.wav")
+        got = out[(i, 6)]
+        assert got.shape == ref.shape and rate == 16000
+        # the only difference is the JSON text round trip of F0 (float32 -> decimal -> float32: exact)
+        np.testing.assert_array_equal(got, ref)
