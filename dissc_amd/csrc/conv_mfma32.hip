@@ -87,7 +87,15 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
           const bool ok = rowok && (t + e) >= 0 && (t + e) < len;
           val[e] = ok ? lrelu(val[e], slope) : 0.f;
         }
-        *reinterpret_cast<f32x4*>(buf + r * XW + 4 * v) = val;
+        if constexpr (STRIDE == 2) {
+          // even / odd samples go to separate half-rows so the stride-2 fragment reads of the
+          // strided conv become stride-1 (conflict-free) LDS reads
+          float* rowp = buf + r * XW + 2 * v;
+          *reinterpret_cast<float2*>(rowp) = make_float2(val[0], val[2]);
+          *reinterpret_cast<float2*>(rowp + (XW >> 1)) = make_float2(val[1], val[3]);
+        } else {
+          *reinterpret_cast<f32x4*>(buf + r * XW + 4 * v) = val;
+        }
       }
       v += dv;
       r += dr;
@@ -123,7 +131,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
   _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                          \
       acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][(KS_) >> 2][(KS_) & 3], BV[ni], acc[mi][ni], 0, 0, 0);
 
-  const int boff = h * XW + sh + (wn * (32 * NI) + l31) * STRIDE;
+  const int boff = (STRIDE == 2) ? h * XW + wn * (32 * NI) + l31 : h * XW + sh + (wn * (32 * NI) + l31);
+  constexpr int CS = (STRIDE == 2) ? 1 : STRIDE;  // column step of the fragment reads
+  const int XH = XW >> 1;
   const int XW2 = 2 * XW;
   int q = 0;
   const int nblk = (a.nchunk + CPB - 1) / CPB;
@@ -133,10 +143,12 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
 #pragma unroll 1
     for (int sc = 0; sc < CPB; ++sc) {
       if (cb * CPB + sc >= a.nchunk) break;
-      const float* bj = blk + sc * (KC * XW);
+      const float* bch = blk + sc * (KC * XW);
+      // tap j of a stride-2 conv reads plane (sh+j)&1 at column offset (sh+j)>>1
+      const float* bj = (STRIDE == 2) ? bch + (sh & 1) * XH + (sh >> 1) : bch;
       float b0[NI], bk[7][NI], b0n[NI];
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b0[ni] = bj[ni * 32 * STRIDE];
+      for (int ni = 0; ni < NI; ++ni) b0[ni] = bj[ni * 32 * CS];
       for (int j = 0; j < a.KS; ++j, ++q) {
         const int qn = (q + 1 < nq) ? q + 1 : q;
 #pragma unroll
@@ -149,11 +161,16 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
 #pragma unroll
         for (int s = 0; s < 7; ++s)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) bk[s][ni] = bj[(s + 1) * XW2 + ni * 32 * STRIDE];
+          for (int ni = 0; ni < NI; ++ni) bk[s][ni] = bj[(s + 1) * XW2 + ni * 32 * CS];
         DISSC_MFMA_STEP(0, b0)
-        bj += a.dil;
+        if constexpr (STRIDE == 2) {
+          const int tj = sh + j + 1;
+          bj = bch + (tj & 1) * XH + (tj >> 1);
+        } else {
+          bj += a.dil;
+        }
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b0n[ni] = bj[ni * 32 * STRIDE];  // next tap's first k-step
+        for (int ni = 0; ni < NI; ++ni) b0n[ni] = bj[ni * 32 * CS];  // next tap's first k-step
         DISSC_MFMA_STEP(1, bk[0])
         DISSC_MFMA_STEP(2, bk[1])
         DISSC_MFMA_STEP(3, bk[2])
