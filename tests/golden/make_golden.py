@@ -222,6 +222,24 @@ def make_predictors():
                 out[f"val/{fn}/{i}/units"] = np.array(d["units"], dtype=np.int64)
                 out[f"val/{fn}/{i}/f0"] = np.array(d["f0"], dtype=np.float64)
                 out[f"val/{fn}/{i}/audio"] = np.array(d["audio"])
+        # rhythm-only conversion (--pred_len without --pred_pitch): F0 is the source contour morphed
+        # per unit run by utils.morph_seq_len (reference infer.py:40-41, utils.py:39-52)
+        os.makedirs(f"{td}/out2")
+        a2 = argparse.Namespace(**{**vars(a), "pred_pitch": False, "out_path": f"{td}/out2"})
+        ref_infer.args = a2
+        ref_infer.infer(a2.input_path, "cpu", a2)
+        for fn in sorted(os.listdir(f"{td}/out2")):
+            for i, ln in enumerate(open(f"{td}/out2/{fn}").read().strip().split("\n")):
+                d = _json.loads(ln)
+                out[f"lenonly/{fn}/{i}/units"] = np.array(d["units"], dtype=np.int64)
+                out[f"lenonly/{fn}/{i}/f0"] = np.array(d["f0"], dtype=np.float64)
+        import utils as ref_utils_root  # reference root utils.py (tensorflow stubbed)
+        rs3 = np.random.RandomState(5)
+        for j, (u, tl) in enumerate([([3, 3, 3, 7, 7, 1], [5, 1, 2]), ([4], [3]), ([1, 2, 2, 2, 2, 9, 9], [2, 2, 5]),
+                                     ([5, 5, 6, 6, 6], [0, 4])]):
+            pitch = rs3.rand(len(u)) * 100
+            out[f"morph/{j}/units"], out[f"morph/{j}/pitch"], out[f"morph/{j}/lens"] = np.array(u), pitch, np.array(tl)
+            out[f"morph/{j}/out"] = np.asarray(ref_utils_root.morph_seq_len(np.array(u), pitch, np.array(tl)), dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, "pred.npz"), **out)
     print("pred.npz", len(out), "arrays")
 

@@ -180,3 +180,26 @@ def test_in_memory_converter_equals_file_pipeline(gpu, golden_dir, tmp_path):
         assert got.shape == ref.shape and rate == 16000
         # the only difference is the JSON text round trip of F0 (float32 -> decimal -> float32: exact)
         np.testing.assert_array_equal(got, ref)
+
+
+def test_infer_cli_rhythm_only_matches_reference(gpu, golden_dir, tmp_path):
+    """--pred_len without --pred_pitch: predicted lengths + the source F0 morphed per unit run."""
+    import synthdata as synth
+    g = np.load(os.path.join(golden_dir, "pred.npz"))
+    td = str(tmp_path)
+    for d in ("len", "out", "in"):
+        os.makedirs(f"{td}/{d}")
+    torch.save(synth.synth_len_state_dict(100, 108), f"{td}/len/best_model.pth")
+    torch.save(synth.synth_len_norm_stats(), f"{td}/len/len_norm_stats.pth")
+    shutil.copy(os.path.join(golden_dir, "vctk_id_to_spkr.pkl"), f"{td}/in/id_to_spkr.pkl")
+    open(f"{td}/in/val.txt", "w").write(str(g["val/manifest"]))
+    infer = _load("dissc_infer_cli_len", "infer.py")
+    infer.main(["--input_path", f"{td}/in/val.txt", "-n", "3", "--out_path", f"{td}/out", "--pred_len",
+                "--len_model", f"{td}/len/", "--f0_path", os.path.join(golden_dir, "vctk_f0_stats.pkl"), "--vc",
+                "--target_speakers", "p231", "p225"])
+    for fn in ("val.txt", "p231_val.txt", "p225_val.txt"):
+        lines = open(f"{td}/out/{fn}").read().strip().split("\n")
+        for i, ln in enumerate(lines):
+            d = json.loads(ln)
+            np.testing.assert_array_equal(d["units"], g[f"lenonly/{fn}/{i}/units"])
+            assert np.abs(np.array(d["f0"]) - g[f"lenonly/{fn}/{i}/f0"]).max() <= 1e-5

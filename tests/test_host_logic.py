@@ -1,0 +1,70 @@
+"""CPU tests of the host-side logic of the entry points (no GPU): manifest parsing, stats
+tensors, morph_seq_len (reference utils.py:39-52), WAV/GT handling of sr/inference.py."""
+import importlib.util
+import json
+import os
+import pickle
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, rel))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_morph_seq_len_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pred.npz"))
+    infer = _load("infer_host", "infer.py")
+    for j in range(4):
+        got = infer.morph_seq_len(g[f"morph/{j}/units"], g[f"morph/{j}/pitch"], g[f"morph/{j}/lens"])
+        np.testing.assert_array_equal(np.asarray(got, dtype=np.float64), g[f"morph/{j}/out"])
+
+
+def test_manifest_parsing_and_stats(tmp_path, golden_dir):
+    from dissc_amd import formats
+    p = tmp_path / "m.txt"
+    p.write_text(json.dumps({"units": [1, 1, 2], "f0": [0.0, 101.5, float("nan")], "audio": "p225_001.wav"}) + "\n"
+                 + "{'units': [3], 'f0': [1.0], 'durations': [1], 'audio': 'x/p226_002.wav'}\n"
+                 + "plain/path.wav\n\n")
+    m = formats.read_manifest(str(p))
+    assert m[0]["units"] == [1, 1, 2] and np.isnan(m[0]["f0"][2])
+    assert m[1]["audio"] == "x/p226_002.wav" and m[2] == {"audio": "plain/path.wav"}
+    assert formats.speaker_of("a/b/p226_002.wav") == "p226"
+    ids = pickle.load(open(os.path.join(golden_dir, "vctk_id_to_spkr.pkl"), "rb"))
+    d = formats.spk_id_dict_from_list(ids)
+    assert d["p225"] == 0 and d["p231"] == 6 and len(d) == 108
+    infer = _load("infer_host2", "infer.py")
+    stats = pickle.load(open(os.path.join(golden_dir, "vctk_f0_stats.pkl"), "rb"))
+    mean, std = infer.prep_stats_tensors(d, stats)
+    assert mean.shape == (108,) and abs(float(mean[d["p330"]]) - 186.08009) < 1e-3
+    assert abs(float(std[d["p277"]]) - 29.187865) < 1e-3
+
+
+def test_sr_inference_gt_and_selection(tmp_path, golden_dir):
+    sr = _load("sr_host", "sr/inference.py")
+    g = np.load(os.path.join(golden_dir, "sr_inference.npz"))
+    gt = sr.load_gt(os.path.join(golden_dir, "s1_1.wav"), 90)
+    assert gt.shape == (31950,)  # 32000 samples trimmed to 90 * (32000 // 90)
+    np.testing.assert_array_equal(sr.peak_normalize(gt), g["sr/out/p226_001_gt.wav"])
+    assert sr.load_gt(str(tmp_path / "missing.wav"), 10) is None
+    assert sr.scan_checkpoint(str(tmp_path), "g_") == ""
+    for n in ("g_00000002", "g_00000010", "g_00000009"):
+        (tmp_path / n).write_bytes(b"")
+    assert sr.scan_checkpoint(str(tmp_path), "g_").endswith("g_00000010")
+    x = sr.peak_normalize(np.array([0.0, -2.0, 1.0], dtype=np.float32))
+    np.testing.assert_array_equal(x, np.array([0.0, -1.0, 0.5], dtype=np.float32))
+
+
+def test_infer_cli_argument_contract():
+    infer = _load("infer_host3", "infer.py")
+    import pytest
+    with pytest.raises(AssertionError):  # must convert pitch or rhythm (reference infer.py:197)
+        infer.main(["--input_path", "x.txt"])
+    with pytest.raises(AssertionError):  # wild samples need both (reference infer.py:198)
+        infer.main(["--input_path", "x.txt", "--wild_sample", "--pred_len"])
