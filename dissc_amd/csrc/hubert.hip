@@ -310,6 +310,107 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S
   for (int j = lane; j < T; j += 64) p[j] = __fdiv_rn(p[j], sum);
 }
 
+// ---- fused exact attention for one (utterance, head, 64-query tile) ---------------------------
+// qkv is channels-first [B][3D][ld] (rows: Q | K | V, head h owns rows h*64..h*64+63 of each,
+// Q already scaled by 1/sqrt(64)).  Per wave: 16 queries.  S^T[key][query] = K^T Q is formed on
+// the matrix pipe with rows = keys, so a lane's 4 accumulator registers are 4 keys of ONE
+// query: the online-softmax reductions are in-lane plus two cross-group shuffles, and the
+// probabilities are already in MFMA B-operand position for O[d][query] += V[d][key] P^T[key][query]
+// (k-step s of the PV product uses key 4*g + s, i.e. register s of the same lane) -- no LDS
+// round trip for P, no HBM round trip for S.
+constexpr int AT_Q = 64;    // queries per block (4 waves x 16)
+constexpr int AT_K = 64;    // keys per LDS tile
+constexpr int AT_LDQ = 80;  // row stride of the Q / K tiles (80 % 32 == 16: conflict-free fragment reads)
+constexpr int AT_LDV = 65;  // row stride of the V tile (odd: lanes walk rows)
+
+__global__ void __launch_bounds__(256) attn_fused_kernel(const float* __restrict__ qkv,
+                                                         const int32_t* __restrict__ lens, int D,
+                                                         int hd, int ld, float* __restrict__ out) {
+  __shared__ float Qs[64 * AT_LDQ];
+  __shared__ float Ks[64 * AT_LDQ];
+  __shared__ float Vs[64 * AT_LDV];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int T = lens[b];
+  const int q0 = blockIdx.x * AT_Q;
+  if (q0 >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const float* qb = qkv + ((size_t)b * 3 * D + (size_t)h * hd) * ld;
+  const float* kb = qb + (size_t)D * ld;
+  const float* vb = qb + (size_t)2 * D * ld;
+  // Q tile -> LDS (zero beyond T)
+  for (int e = tid; e < 64 * AT_Q; e += 256) {
+    const int d = e >> 6, c = e & 63;
+    Qs[d * AT_LDQ + c] = (q0 + c < T) ? qb[(size_t)d * ld + q0 + c] : 0.f;
+  }
+  __syncthreads();
+  float qf[16];  // this wave's Q fragments: k-step ks -> Q[d = 4*ks + g][query = wave*16 + l15]
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) qf[ks] = Qs[(4 * ks + g) * AT_LDQ + wave * 16 + l15];
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < T; k0 += AT_K) {
+    __syncthreads();  // previous tile fully consumed
+    for (int e = tid; e < 64 * AT_K; e += 256) {
+      const int d = e >> 6, c = e & 63;
+      const bool ok = k0 + c < T;
+      Ks[d * AT_LDQ + c] = ok ? kb[(size_t)d * ld + k0 + c] : 0.f;
+      Vs[d * AT_LDV + c] = ok ? vb[(size_t)d * ld + k0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      if (k0 + sub * 16 >= T) break;  // uniform
+      f32x4 sT = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        sT = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(4 * ks + g) * AT_LDQ + sub * 16 + l15], qf[ks], sT, 0, 0, 0);
+      // sT[r] = S[query l15][key k0 + sub*16 + 4g + r]
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (k0 + sub * 16 + 4 * g + r >= T) sT[r] = -INFINITY;
+        mx = fmaxf(mx, sT[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mn = fmaxf(m, mx);  // finite: the sub-tile has at least one valid key
+      const float alpha = expf(m - mn);
+      float p[4], ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] = expf(sT[r] - mn);
+        ps += p[r];
+      }
+      ps += __shfl_xor(ps, 16);
+      ps += __shfl_xor(ps, 32);
+      l = l * alpha + ps;
+      m = mn;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          o[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(i * 16 + l15) * AT_LDV + sub * 16 + 4 * g + st], p[st], o[i], 0, 0, 0);
+    }
+  }
+  // o[i][r] = O[d = i*16 + 4g + r][query = wave*16 + l15] (unnormalised)
+  const int q = q0 + wave * 16 + l15;
+  if (q < T) {
+    const float inv = 1.f / l;
+    float* ob = out + ((size_t)b * D + (size_t)h * hd) * ld + q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ob[(size_t)(i * 16 + 4 * g + r) * ld] = o[i][r] * inv;
+  }
+}
+
 // units[b][t] = argmin_k (cnorm[k] - 2 * xc[b][k][t]), lowest index on ties
 __global__ void kmeans_argmin_kernel(const float* __restrict__ xc, const float* __restrict__ cnorm,
                                      const int32_t* __restrict__ lens, int K, int Kld, int ld, int T,
@@ -335,6 +436,10 @@ __global__ void kmeans_argmin_kernel(const float* __restrict__ xc, const float* 
 }  // namespace dissc
 
 using namespace dissc;
+
+namespace dissc {
+int g_attn_fused = 1;  // "attn_fused" option: 0 = S=QK^T -> softmax -> PV through HBM (3 kernels)
+}
 
 struct dissc_hubert {
   int n_layers = 6, H = 12, D = 768, F = 3072, CF = 512, K = 0;
@@ -530,7 +635,8 @@ static HubertWs carve(const dissc_hubert* m, int B, int Nmax, void* base_) {
   w.t1 = (float*)take((size_t)B * m->D * ldT * 4);
   w.qkv = (float*)take((size_t)B * 3 * m->D * ldT * 4);
   w.ffn = (float*)take((size_t)B * m->F * ldT * 4);
-  w.S = (float*)take((size_t)B * m->H * (size_t)(T > 0 ? T : 1) * ldT * 4);
+  const bool need_s = !(g_attn_fused && m->D / m->H == 64);  // the fused attention keeps S on chip
+  w.S = (float*)take(need_s ? (size_t)B * m->H * (size_t)(T > 0 ? T : 1) * ldT * 4 : 256);
   w.xc = (float*)take((size_t)B * rup(m->K > 0 ? m->K : 1, 128) * ldT * 4);
   w.bytes = (size_t)(p - p0) + 256;
   return w;
@@ -605,25 +711,30 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
   for (int i = 0; i < m->n_layers; ++i) {
     auto& L = m->layers[i];
     if ((rc = run_conv_ex(L.qkv, w.x, w.qkv, nullptr, ioT, B, D, ldT, ldT, T, 1.0f, EPI_STORE, st))) return rc;
+    if (g_attn_fused && hd == 64) {
+      hipLaunchKernelGGL(attn_fused_kernel, dim3((T + AT_Q - 1) / AT_Q, H, B), dim3(256), 0, st, w.qkv, lensT, D,
+                         hd, ldT, w.t1);
+    } else {
     BGemmArgs a;
-    // S[b,h][i][j] = sum_d Q[d][i] K[d][j]      (Q already scaled by 1/sqrt(hd))
-    a.A = w.qkv; a.B = w.qkv + (size_t)D * ldT; a.C = w.S;
-    a.a_bs = (long long)3 * D * ldT; a.a_hs = (long long)hd * ldT; a.b_bs = a.a_bs; a.b_hs = a.a_hs;
-    a.c_bs = (long long)H * T * ldT; a.c_hs = (long long)T * ldT;
-    a.sam = 1; a.sak = ldT; a.sbk = ldT; a.sbn = 1; a.scm = ldT;
-    a.lens = lensT; a.m_is_t = 1; a.n_is_t = 1; a.k_is_t = 0; a.fixed = hd; a.H = H; a.alpha = 1.f;
-    dim3 gs((T + 63) / 64, (T + 63) / 64, B * H);
-    hipLaunchKernelGGL(bgemm_kernel, gs, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((T + 3) / 4, H, B), dim3(256), 0, st, w.S, lensT, H, T, ldT);
-    // O[h*hd + d][i] = sum_j V[d][j] P[i][j]  -> t1 (channels-first)
-    a.A = w.qkv + (size_t)2 * D * ldT; a.B = w.S; a.C = w.t1;
-    a.a_bs = (long long)3 * D * ldT; a.a_hs = (long long)hd * ldT;
-    a.b_bs = (long long)H * T * ldT; a.b_hs = (long long)T * ldT;
-    a.c_bs = (long long)D * ldT; a.c_hs = (long long)hd * ldT;
-    a.sam = ldT; a.sak = 1; a.sbk = 1; a.sbn = ldT; a.scm = ldT;
-    a.m_is_t = 0; a.n_is_t = 1; a.k_is_t = 1; a.fixed = hd;
-    dim3 go((T + 63) / 64, (hd + 63) / 64, B * H);
-    hipLaunchKernelGGL(bgemm_kernel, go, dim3(256), 0, st, a);
+      // S[b,h][i][j] = sum_d Q[d][i] K[d][j]      (Q already scaled by 1/sqrt(hd))
+      a.A = w.qkv; a.B = w.qkv + (size_t)D * ldT; a.C = w.S;
+      a.a_bs = (long long)3 * D * ldT; a.a_hs = (long long)hd * ldT; a.b_bs = a.a_bs; a.b_hs = a.a_hs;
+      a.c_bs = (long long)H * T * ldT; a.c_hs = (long long)T * ldT;
+      a.sam = 1; a.sak = ldT; a.sbk = ldT; a.sbn = 1; a.scm = ldT;
+      a.lens = lensT; a.m_is_t = 1; a.n_is_t = 1; a.k_is_t = 0; a.fixed = hd; a.H = H; a.alpha = 1.f;
+      dim3 gs((T + 63) / 64, (T + 63) / 64, B * H);
+      hipLaunchKernelGGL(bgemm_kernel, gs, dim3(256), 0, st, a);
+      hipLaunchKernelGGL(softmax_rows_kernel, dim3((T + 3) / 4, H, B), dim3(256), 0, st, w.S, lensT, H, T, ldT);
+      // O[h*hd + d][i] = sum_j V[d][j] P[i][j]  -> t1 (channels-first)
+      a.A = w.qkv + (size_t)2 * D * ldT; a.B = w.S; a.C = w.t1;
+      a.a_bs = (long long)3 * D * ldT; a.a_hs = (long long)hd * ldT;
+      a.b_bs = (long long)H * T * ldT; a.b_hs = (long long)T * ldT;
+      a.c_bs = (long long)D * ldT; a.c_hs = (long long)hd * ldT;
+      a.sam = ldT; a.sak = 1; a.sbk = 1; a.sbn = ldT; a.scm = ldT;
+      a.m_is_t = 0; a.n_is_t = 1; a.k_is_t = 1; a.fixed = hd;
+      dim3 go((T + 63) / 64, (hd + 63) / 64, B * H);
+      hipLaunchKernelGGL(bgemm_kernel, go, dim3(256), 0, st, a);
+    }
     // x = LN(x + out_proj(O))
     if ((rc = run_conv_ex(L.out, w.t1, w.y, w.x, ioT, B, D, ldT, ldT, T, 1.0f, EPI_RES, st))) return rc;
     hipLaunchKernelGGL(ln_cf_kernel, gln, dim3(64 * LN_WAVES), 0, st, w.y, (const float*)nullptr, L.ln1_g, L.ln1_b, lensT, D,
