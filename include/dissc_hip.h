@@ -115,10 +115,19 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
                            const int32_t* lengths, int B, int Cin, int Cout, int k, int stride,
                            int ldx, int ldo, int Lmax, float in_slope, void* stream);
 
-/* Tuning hook: "conv_cfg_bm{16,32,64,128,256}" = tile-shape id used for convs whose GEMM
- * M falls in that class (see kCfgs in conv_mfma.hip); "fused_max_c" = widest ResBlock that
- * runs as one fused launch (0 = never), "fused_bn16/32" = its time tile.  Process-wide; set
- * before dissc_gen_create. */
+/* Tuning hook (process-wide; set before the handles are created; also reachable through the
+ * environment variable DISSC_OPTIONS="key=value,key=value" read by the Python binding):
+ *   multistream (1)      generator: the ResBlocks of a stage run as concurrent chains on HIP streams
+ *   mfma32 (1)           use the 32x32x2 MFMA kernel for layers with >= 32 output rows
+ *   conv_cfg_bm{16,32,64,128,256} / conv32_cfg_bm{32,64,128,256}
+ *                        tile-shape id per GEMM-M class (tables in conv_mfma.hip / conv_mfma32.hip)
+ *   lin_tile (2)         1x1 convs: 16-channel chunks staged per barrier (2 or 4)
+ *   cpb2 (0)             k <= value convs stage 32 channels per barrier
+ *   fused_max_c (0)      widest ResBlock run as ONE fused launch (experimental: 16 or 32)
+ *   fused_variant (0)    wave/tile split of the fused C=16 kernel
+ *   attn_fused (1)       HuBERT attention as one fused kernel (0: batched GEMM -> softmax -> batched GEMM)
+ *   mfast (0)            M-fastest block order for convs with many M tiles
+ * Unknown keys return DISSC_EINVAL. */
 int dissc_set_option(const char* key, int value);
 
 /* Diagnostics (not on the product path): average milliseconds of `iters` launches of

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""GPU tuning sweep over generator conv shapes x tile configs x ablation flags
-(uses the diagnostics entry point dissc_conv_bench).  Prints a markdown table."""
+"""GPU tuning sweep over generator conv shapes x tile configs of the 16x16x4 kernel
+(diagnostics entry point dissc_conv_bench; run with DISSC_OPTIONS=mfma32=0 -- the 32x32x2
+kernel's tile shapes are tuned with tools/option_sweep.py instead).  Prints a markdown table."""
 import ctypes
 import sys
 
