@@ -88,6 +88,8 @@ int conv32_cfg(int M);
 void conv32_set_cfg(int bm_class, int cfg);
 void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
                          int& Mpad, int& nchunk, int groups);
+extern int g_stream16;
+int try_launch_conv16_stream(const ConvArgs& a, int B, int Lmax, int stride, hipStream_t stream);
 extern int g_attn_fused;
 extern int g_lin_tile;
 extern int g_cpb2;

@@ -438,6 +438,7 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "fused_bn16") == 0) { fused_set_option(0, value); return DISSC_OK; }
   if (strcmp(key, "fused_bn32") == 0) { fused_set_option(1, value); return DISSC_OK; }
   if (strcmp(key, "multistream") == 0) { g_multistream = value; return DISSC_OK; }
+  if (strcmp(key, "stream16") == 0) { g_stream16 = value; return DISSC_OK; }
   if (strcmp(key, "attn_fused") == 0) { g_attn_fused = value; return DISSC_OK; }
   if (strcmp(key, "lin_tile") == 0) { g_lin_tile = value; return DISSC_OK; }
   if (strcmp(key, "cpb2") == 0) { g_cpb2 = value; return DISSC_OK; }

@@ -125,6 +125,7 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   cpb2 (0)             k <= value convs stage 32 channels per barrier
  *   fused_max_c (0)      widest ResBlock run as ONE fused launch (experimental: 16 or 32)
  *   fused_variant (0)    wave/tile split of the fused C=16 kernel
+ *   stream16 (4)         time tiles per workgroup of the streaming 16-channel conv kernel (0 = off)
  *   attn_fused (1)       HuBERT attention as one fused kernel (0: batched GEMM -> softmax -> batched GEMM)
  *   mfast (0)            M-fastest block order for convs with many M tiles
  * Unknown keys return DISSC_EINVAL. */
