@@ -157,15 +157,23 @@ def main():
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     gen_ms = 0.0
+    pending = None  # (work, y): the previous step's all-gather, still in flight on RCCL's stream
     t0 = time.perf_counter()
     for _ in range(a.steps):
         ev0.record()
         y = g(code=d_code, f0=d_f0, spkr=d_spkr)
         ev1.record()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, y)
+            # The gather of step k runs on RCCL's stream while step k+1's generator kernels run
+            # on the compute stream; it is only waited for right before the next gather reuses
+            # `gathered` (and after the loop), so all K gathers are inside the timed region.
+            if pending is not None:
+                pending[0].wait()
+            pending = (dist.all_gather_into_tensor(gathered, y, async_op=True), y)
         ev1.synchronize()
         gen_ms += ev0.elapsed_time(ev1)
+    if pending is not None:
+        pending[0].wait()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
