@@ -31,6 +31,7 @@ void set_error(const char* fmt, ...) {
 
 using namespace dissc;
 
+static int g_stream_prio = 1;  // "stream_prio" option: prioritise the longer ResBlock chains
 static int g_multistream = 1;  // "multistream" option: concurrent ResBlock chains (read at create)
 
 struct dissc_gen {
@@ -230,7 +231,13 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
     if (hipEventCreateWithFlags(&g->ev_x, hipEventDisableTiming) != hipSuccess) return fail(DISSC_EHIP);
     for (int j = 0; j < nk; ++j) {
       if (hipEventCreateWithFlags(&g->ev_fin[j], hipEventDisableTiming) != hipSuccess) return fail(DISSC_EHIP);
-      if (j > 0 && hipStreamCreateWithFlags(&g->aux[j], hipStreamNonBlocking) != hipSuccess)
+      // later chains have larger kernels (k = 3 < 7 < 11): the longest one is the stage's critical
+      // path, so it gets the highest stream priority and the short chains fill in around it
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent, hi = most urgent (numerically lower)
+      int prio = lo;
+      if (g_stream_prio && nk > 1) prio = lo + (hi - lo) * j / (nk - 1);
+      if (j > 0 && hipStreamCreateWithPriority(&g->aux[j], hipStreamNonBlocking, prio) != hipSuccess)
         return fail(DISSC_EHIP);
     }
   }
@@ -437,6 +444,7 @@ int dissc_set_option(const char* key, int value) {
   }
   if (strcmp(key, "fused_bn16") == 0) { fused_set_option(0, value); return DISSC_OK; }
   if (strcmp(key, "fused_bn32") == 0) { fused_set_option(1, value); return DISSC_OK; }
+  if (strcmp(key, "stream_prio") == 0) { g_stream_prio = value; return DISSC_OK; }
   if (strcmp(key, "multistream") == 0) { g_multistream = value; return DISSC_OK; }
   if (strcmp(key, "stream16") == 0) { g_stream16 = value; return DISSC_OK; }
   if (strcmp(key, "attn_fused") == 0) { g_attn_fused = value; return DISSC_OK; }

@@ -118,6 +118,7 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
 /* Tuning hook (process-wide; set before the handles are created; also reachable through the
  * environment variable DISSC_OPTIONS="key=value,key=value" read by the Python binding):
  *   multistream (1)      generator: the ResBlocks of a stage run as concurrent chains on HIP streams
+ *   stream_prio (1)      ... and the longer chains get higher HIP stream priority
  *   mfma32 (1)           use the 32x32x2 MFMA kernel for layers with >= 32 output rows
  *   conv_cfg_bm{16,32,64,128,256} / conv32_cfg_bm{32,64,128,256}
  *                        tile-shape id per GEMM-M class (tables in conv_mfma.hip / conv_mfma32.hip)
