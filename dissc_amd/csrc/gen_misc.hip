@@ -195,3 +195,55 @@ extern "C" int dissc_mfma_peak(int iters, float* tflops) {
   (void)hipFree(d);
   return DISSC_OK;
 }
+
+// ---- diagnostics: do the fp32 VALU pipe and the MFMA pipe overlap on this part? ----------------
+namespace dissc {
+__global__ void __launch_bounds__(256) valu_peak_kernel(float* out, int iters) {
+  float a[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 1e-3f + i;
+  const float m = 1.0001f, c = 1e-3f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = fmaf(a[i], m, c);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += a[i];
+  if (s == 12345.678f) out[0] = s;
+}
+}  // namespace dissc
+
+// ms[0] = MFMA kernel alone, ms[1] = VALU kernel alone, ms[2] = both concurrently (two streams)
+extern "C" int dissc_pipe_overlap(int mfma_iters, int valu_iters, float* ms) {
+  using namespace dissc;
+  if (!ms || mfma_iters <= 0 || valu_iters <= 0) return DISSC_EINVAL;
+  float* d = nullptr;
+  DISSC_HIP_CHECK(hipMalloc((void**)&d, 16));
+  hipStream_t s1, s2;
+  DISSC_HIP_CHECK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  DISSC_HIP_CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  hipEvent_t e0, e1, e2;
+  DISSC_HIP_CHECK(hipEventCreate(&e0));
+  DISSC_HIP_CHECK(hipEventCreate(&e1));
+  DISSC_HIP_CHECK(hipEventCreate(&e2));
+  const int blocks = 256 * 2;  // 2 blocks x 4 waves per CU per kernel: both kernels fit side by side
+  for (int mode = 0; mode < 3; ++mode) {
+    hipLaunchKernelGGL(mfma_peak32_kernel, dim3(blocks), dim3(256), 0, s1, d, 10);
+    hipLaunchKernelGGL(valu_peak_kernel, dim3(blocks), dim3(256), 0, s2, d, 10);
+    DISSC_HIP_CHECK(hipDeviceSynchronize());
+    DISSC_HIP_CHECK(hipEventRecord(e0, s1));
+    DISSC_HIP_CHECK(hipStreamWaitEvent(s2, e0, 0));
+    if (mode == 0 || mode == 2) hipLaunchKernelGGL(mfma_peak32_kernel, dim3(blocks), dim3(256), 0, s1, d, mfma_iters);
+    if (mode == 1 || mode == 2) hipLaunchKernelGGL(valu_peak_kernel, dim3(blocks), dim3(256), 0, s2, d, valu_iters);
+    DISSC_HIP_CHECK(hipEventRecord(e2, s2));
+    DISSC_HIP_CHECK(hipStreamWaitEvent(s1, e2, 0));
+    DISSC_HIP_CHECK(hipEventRecord(e1, s1));
+    DISSC_HIP_CHECK(hipEventSynchronize(e1));
+    DISSC_HIP_CHECK(hipEventElapsedTime(&ms[mode], e0, e1));
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2);
+  (void)hipFree(d);
+  return DISSC_OK;
+}
