@@ -16,7 +16,9 @@
  *     on the given hipStream_t (passed as void*; NULL = the null stream);
  *   - return 0 on success, a negative DISSC_E* code on failure; nothing throws
  *     across the ABI; dissc_last_error() returns a thread-local message;
- *   - one handle per process/GPU, handles are independent, no global state.
+ *   - one handle per process/GPU, handles are independent; calls on ONE handle must be stream-ordered
+ *     (a handle owns helper streams/events and the caller's workspace is its scratch); the only
+ *     process-wide state is the tuning table behind dissc_set_option.
  */
 #ifndef DISSC_HIP_H
 #define DISSC_HIP_H
