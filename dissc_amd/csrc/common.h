@@ -59,6 +59,7 @@ struct ConvArgs {
   int nsub_group;       // 16-row subtiles per group in the packed weights / bias arrays
   int act;              // 0 none, 1 exact GELU on (conv + bias) before any residual
   int mfast;            // 1: blockIdx.x walks the M tiles (XCD i keeps M tiles i, i+8, ... of the weights in its L2)
+  int prec;             // 0 exact fp32 MFMA; 1 split-bf16 ("bf16x3") on the bf16 matrix cores (opt-in)
   int m32;              // 1: weights packed for / launched on the 32x32x2 kernel (conv_mfma32.hip)
   int CIN, M, KS, dil, nchunk;
   int XW;               // LDS row stride (floats), XW % 32 == 16
@@ -94,6 +95,9 @@ extern int g_attn_fused;
 extern int g_lin_tile;
 extern int g_cpb2;
 extern int g_mfast;       // tuning: 0 disables the M-fastest block order
+void pack_conv_weights32_bf3(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
+                             int& Mpad, int& nchunk, int groups);
+extern int g_precision;   // 0 = fp32 (default); 1 = split-bf16 where an instance exists (read at create)
 extern int g_use_mfma32;  // tuning: 0 forces the 16x16x4 kernel everywhere
 
 // Host-side weight packing.  w: [Cout][Cin][KS] (Conv1d layout).  Returns the packed
@@ -117,6 +121,7 @@ struct DevConv {
   int up_np = 1, up_p0 = 0;                                 // ConvTranspose phase group (see ConvArgs)
   int act = 0;
   int m32 = 0;              // packed for the 32x32x2 kernel
+  int prec = 0;             // 1: packed as split-bf16 hi/lo fragments
   double macs_per_t = 0;  // MACs per input time step (algorithmic, zero taps excluded)
 };
 // Per-call extras of run_conv_ex (strided / valid convolutions with their own output lengths).

@@ -7,6 +7,7 @@
 namespace dissc {
 
 int g_use_mfma32 = 1;
+int g_precision = 0;
 
 int upload(const std::vector<float>& h, float** d) {
   DISSC_HIP_CHECK(hipMalloc((void**)d, h.size() * sizeof(float)));
@@ -21,7 +22,12 @@ int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int 
   int Mpad, nchunk;
   const int Mg = Cout / groups, Cg = Cin / groups;
   dc.m32 = (g_use_mfma32 && Mg >= 32) ? 1 : 0;  // 64-cycle MFMAs wherever a 32-row tile is not mostly padding
-  if (dc.m32) pack_conv_weights32(w, Cout, Cg, KS, packed, Mpad, nchunk, groups);
+  // split-bf16 only where conv_mfma32.hip has an instance for it
+  const bool lin_big = (KS == 1 && Mg >= 256 && (Cg + KC - 1) / KC >= 8);
+  dc.prec = (g_precision == 1 && dc.m32 && stride == 1 && groups == 1 && (KS - 1) * dil <= MAX_TAP_SPAN && !lin_big)
+                ? 1 : 0;
+  if (dc.prec) pack_conv_weights32_bf3(w, Cout, Cg, KS, packed, Mpad, nchunk, groups);
+  else if (dc.m32) pack_conv_weights32(w, Cout, Cg, KS, packed, Mpad, nchunk, groups);
   else pack_conv_weights(w, Cout, Cg, KS, packed, Mpad, nchunk, groups);
   std::vector<float> b((size_t)Mpad * groups, 0.f);
   if (bias)
@@ -119,7 +125,7 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
   a.CIN = dc.CIN; a.M = dc.M; a.KS = dc.KS; a.dil = dc.dil; a.nchunk = dc.nchunk;
   a.pad_left = dc.pad_left >= 0 ? dc.pad_left : ((dc.KS - 1) * dc.dil) / 2;
   a.mfast = 0;
-  a.groups = dc.groups; a.nsub_group = dc.Mpad / (dc.m32 ? 32 : 16); a.act = dc.act; a.m32 = dc.m32;
+  a.groups = dc.groups; a.nsub_group = dc.Mpad / (dc.m32 ? 32 : 16); a.act = dc.act; a.m32 = dc.m32; a.prec = dc.prec;
   a.XW = conv_xw(dc.M, dc.KS, dc.dil, dc.stride, dc.m32);
   a.ldx = ldx; a.ldo = ldo;
   a.x_bstride = (long long)C_x_total * ldx;

@@ -3,11 +3,14 @@
 // conv_mfma_kernel (conv_mfma.hip); only the fragment geometry differs:
 //   A: lane l holds W[row = l & 31][k = l >> 5], B: lane l holds X[k = l >> 5][col = l & 31],
 //   D: 16 registers, col = l & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
+#include <string.h>
+
 #include "common.h"
 
 namespace dissc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
@@ -17,7 +20,11 @@ __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + 
 // STRIDE: input step per output position (1; 2 for HuBERT's strided feature convs).
 // SPAN: largest (KS-1)*dil the staging registers are sized for.
 // CPB: 16-channel chunks staged per barrier (4 for 1x1 convs, whose chunk is a single tap).
-template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1>
+// PREC = 1: split-bf16 ("bf16x3") arithmetic -- every fp32 operand is split on the fly into
+// hi + lo bf16 halves and each product is formed as hi*hi + hi*lo + lo*hi on the bf16 matrix
+// cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate): ~2^-17 relative product error instead of
+// exact fp32, at a multiple of the fp32-MFMA rate.  Opt-in only (dissc_set_option("precision", 1)).
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1, int PREC = 0>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const ConvArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BN = 32 * NI * WN;
@@ -143,51 +150,95 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
 #pragma unroll 1
     for (int sc = 0; sc < CPB; ++sc) {
       if (cb * CPB + sc >= a.nchunk) break;
-      const float* bch = blk + sc * (KC * XW);
-      // tap j of a stride-2 conv reads plane (sh+j)&1 at column offset (sh+j)>>1
-      const float* bj = (STRIDE == 2) ? bch + (sh & 1) * XH + (sh >> 1) : bch;
-      float b0[NI], bk[7][NI], b0n[NI];
+      if constexpr (PREC == 1) {
+        // ---- split-bf16 path: rows 8h..8h+7 of the chunk are this lane's 8 k-values ----
+        const float* bj = blk + sc * (KC * XW) + 7 * h * XW;  // blk already holds h*XW
+        for (int j = 0; j < a.KS; ++j, ++q) {
+          const int qn = (q + 1 < nq) ? q + 1 : q;
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b0[ni] = bj[ni * 32 * CS];
-      for (int j = 0; j < a.KS; ++j, ++q) {
-        const int qn = (q + 1 < nq) ? q + 1 : q;
+          for (int mi = 0; mi < MI; ++mi) {
+            avn[mi][0] = wp[mi][(size_t)qn * 128];
+            avn[mi][1] = wp[mi][(size_t)qn * 128 + 64];
+          }
+          if (j == 0 && sc == 0 && more) stage_load(cb + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          bf16x8 bh[NI], bl[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          avn[mi][0] = wp[mi][(size_t)qn * 128];
-          avn[mi][1] = wp[mi][(size_t)qn * 128 + 64];
-        }
-        if (j == 0 && sc == 0 && more) stage_load(cb + 1);  // in flight behind this block's MFMAs
-        __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of the MFMAs
+          for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-        for (int s = 0; s < 7; ++s)
+            for (int e = 0; e < 8; ++e) {
+              const float x = bj[e * XW + ni * 32 * CS];
+              const __bf16 xh = (__bf16)x;
+              bh[ni][e] = xh;
+              bl[ni][e] = (__bf16)(x - (float)xh);
+            }
+          }
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) bk[s][ni] = bj[(s + 1) * XW2 + ni * 32 * CS];
-        DISSC_MFMA_STEP(0, b0)
-        if constexpr (STRIDE == 2) {
-          const int tj = sh + j + 1;
-          bj = bch + (tj & 1) * XH + (tj >> 1);
-        } else {
+          for (int mi = 0; mi < MI; ++mi) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, av[mi][0]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, av[mi][1]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            av[mi][0] = avn[mi][0];
+            av[mi][1] = avn[mi][1];
+          }
           bj += a.dil;
         }
+      } else {
+      const float* bch = blk + sc * (KC * XW);
+        // tap j of a stride-2 conv reads plane (sh+j)&1 at column offset (sh+j)>>1
+        const float* bj = (STRIDE == 2) ? bch + (sh & 1) * XH + (sh >> 1) : bch;
+        float b0[NI], bk[7][NI], b0n[NI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b0n[ni] = bj[ni * 32 * CS];  // next tap's first k-step
-        DISSC_MFMA_STEP(1, bk[0])
-        DISSC_MFMA_STEP(2, bk[1])
-        DISSC_MFMA_STEP(3, bk[2])
-        DISSC_MFMA_STEP(4, bk[3])
-        DISSC_MFMA_STEP(5, bk[4])
-        DISSC_MFMA_STEP(6, bk[5])
-        DISSC_MFMA_STEP(7, bk[6])
-        __builtin_amdgcn_sched_barrier(0);  // the register rotation below must not creep upwards
+        for (int ni = 0; ni < NI; ++ni) b0[ni] = bj[ni * 32 * CS];
+        for (int j = 0; j < a.KS; ++j, ++q) {
+          const int qn = (q + 1 < nq) ? q + 1 : q;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b0[ni] = b0n[ni];
+          for (int mi = 0; mi < MI; ++mi) {
+            avn[mi][0] = wp[mi][(size_t)qn * 128];
+            avn[mi][1] = wp[mi][(size_t)qn * 128 + 64];
+          }
+          if (j == 0 && sc == 0 && more) stage_load(cb + 1);  // in flight behind this block's MFMAs
+          __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of the MFMAs
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          av[mi][0] = avn[mi][0];
-          av[mi][1] = avn[mi][1];
+          for (int s = 0; s < 7; ++s)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bk[s][ni] = bj[(s + 1) * XW2 + ni * 32 * CS];
+          DISSC_MFMA_STEP(0, b0)
+          if constexpr (STRIDE == 2) {
+            const int tj = sh + j + 1;
+            bj = bch + (tj & 1) * XH + (tj >> 1);
+          } else {
+            bj += a.dil;
+          }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) b0n[ni] = bj[ni * 32 * CS];  // next tap's first k-step
+          DISSC_MFMA_STEP(1, bk[0])
+          DISSC_MFMA_STEP(2, bk[1])
+          DISSC_MFMA_STEP(3, bk[2])
+          DISSC_MFMA_STEP(4, bk[3])
+          DISSC_MFMA_STEP(5, bk[4])
+          DISSC_MFMA_STEP(6, bk[5])
+          DISSC_MFMA_STEP(7, bk[6])
+          __builtin_amdgcn_sched_barrier(0);  // the register rotation below must not creep upwards
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) b0[ni] = b0n[ni];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            av[mi][0] = avn[mi][0];
+            av[mi][1] = avn[mi][1];
+          }
         }
-      }
     }
+      }
     if (more) stage_store(xs + ((cb + 1) & 1) * (KCB * XW), cb + 1);
     __syncthreads();
   }
@@ -364,7 +415,51 @@ void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<
               }
 }
 
-template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1>
+static inline uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// Split-bf16 A fragments in the same [group][ms32][chunk][tap][half][lane] 16-byte slots as the fp32
+// form: half 0 = hi, half 1 = lo; element e of a slot is k = 8*(lane>>5) + e, i.e. channel
+// 16*c + 8*(lane>>5) + e of row 32*ms + (lane & 31).
+void pack_conv_weights32_bf3(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
+                             int& Mpad, int& nchunk, int groups) {
+  const int Mg = Cout / groups;
+  const int bm = bm32_of(Mg);
+  Mpad = (Mg + bm - 1) / bm * bm;
+  nchunk = (Cin + KC - 1) / KC;
+  const int nsub = Mpad / 32;
+  packed.assign((size_t)groups * nsub * nchunk * KS * 2 * 64 * 4, 0.f);
+  uint16_t* p16 = reinterpret_cast<uint16_t*>(packed.data());
+  for (int gi = 0; gi < groups; ++gi)
+    for (int ms = 0; ms < nsub; ++ms)
+      for (int c = 0; c < nchunk; ++c)
+        for (int j = 0; j < KS; ++j)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+              const int co = ms * 32 + (lane & 31);
+              const int ci = c * KC + 8 * (lane >> 5) + e;
+              float v = 0.f;
+              if (co < Mg && ci < Cin) v = w[((size_t)(gi * Mg + co) * Cin + ci) * KS + j];
+              const uint16_t hi = f32_to_bf16_rne(v);
+              const uint16_t lo = f32_to_bf16_rne(v - bf16_to_f32(hi));
+              const size_t slot = (((((size_t)gi * nsub + ms) * nchunk + c) * KS + j) * 2) * 64 + lane;  // half 0
+              p16[slot * 8 + e] = hi;
+              p16[(slot + 64) * 8 + e] = lo;
+            }
+}
+
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1, int PREC = 0>
 static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN, NW = WM * WN;
   constexpr int CW = 32 * NI + 4;
@@ -380,11 +475,11 @@ static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>),
+        reinterpret_cast<const void*>(&conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB, PREC>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>), grid, dim3(64 * WM * WN), lds,
+  hipLaunchKernelGGL((conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB, PREC>), grid, dim3(64 * WM * WN), lds,
                      stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
@@ -411,6 +506,17 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
     // (the tile must stay the default 256 x 64: a.XW was sized for its BN)
     if (g_lin_tile == 4) return launch32_t<2, 2, 4, 1, 1, 0, 4>(a, B, Lmax_out, stream);  // 64 ch / barrier
     return launch32_t<2, 2, 4, 1, 1, 0, 2>(a, B, Lmax_out, stream);                        // 32 ch / barrier
+  }
+  if (a.prec == 1) {  // split-bf16 instances (stride 1, taps <= MAX_TAP_SPAN, 16 channels per barrier)
+    switch (cfg) {
+      case 0: return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN, 1, 1>(a, B, Lmax_out, stream);
+      case 1: return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN, 1, 1>(a, B, Lmax_out, stream);
+      case 2: return launch32_t<1, 2, 2, 2, 1, MAX_TAP_SPAN, 1, 1>(a, B, Lmax_out, stream);
+      case 3: return launch32_t<1, 2, 1, 4, 1, MAX_TAP_SPAN, 1, 1>(a, B, Lmax_out, stream);
+      default:
+        set_error("launch_conv32: no split-bf16 instance for tile config %d", cfg);
+        return DISSC_EINVAL;
+    }
   }
   if (g_cpb2 && a.KS <= g_cpb2 && a.nchunk >= 4 && a.up == 1) {  // two chunks per barrier for short kernels
     if (cfg == 0) return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);

@@ -444,6 +444,7 @@ int dissc_set_option(const char* key, int value) {
   }
   if (strcmp(key, "fused_bn16") == 0) { fused_set_option(0, value); return DISSC_OK; }
   if (strcmp(key, "fused_bn32") == 0) { fused_set_option(1, value); return DISSC_OK; }
+  if (strcmp(key, "precision") == 0) { g_precision = value; return DISSC_OK; }
   if (strcmp(key, "stream_prio") == 0) { g_stream_prio = value; return DISSC_OK; }
   if (strcmp(key, "multistream") == 0) { g_multistream = value; return DISSC_OK; }
   if (strcmp(key, "stream16") == 0) { g_stream16 = value; return DISSC_OK; }

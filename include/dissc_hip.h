@@ -121,6 +121,9 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  * environment variable DISSC_OPTIONS="key=value,key=value" read by the Python binding):
  *   multistream (1)      generator: the ResBlocks of a stage run as concurrent chains on HIP streams
  *   stream_prio (1)      ... and the longer chains get higher HIP stream priority
+ *   precision (0)        0 = exact fp32 MFMA everywhere (default, what bench.py reports); 1 = split-bf16
+ *                        ("bf16x3": hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate) for the
+ *                        layers that have such an instance -- ~2^-17 product error, waveform RMS ~4e-6
  *   mfma32 (1)           use the 32x32x2 MFMA kernel for layers with >= 32 output rows
  *   conv_cfg_bm{16,32,64,128,256} / conv32_cfg_bm{32,64,128,256}
  *                        tile-shape id per GEMM-M class (tables in conv_mfma.hip / conv_mfma32.hip)
