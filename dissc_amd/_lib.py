@@ -15,7 +15,8 @@ _LIB_NAME = "libdissc_hip.so"
 
 
 def library_path():
-    return os.path.join(_HERE, _LIB_NAME)
+    # DISSC_HIP_LIB: development hook for A/B-ing an alternative build of the same library
+    return os.environ.get("DISSC_HIP_LIB") or os.path.join(_HERE, _LIB_NAME)
 
 
 class DisscError(RuntimeError):

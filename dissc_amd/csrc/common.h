@@ -95,9 +95,14 @@ extern int g_attn_fused;
 extern int g_lin_tile;
 extern int g_cpb2;
 extern int g_mfast;       // tuning: 0 disables the M-fastest block order
-void pack_conv_weights32_bf3(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
-                             int& Mpad, int& nchunk, int groups);
-extern int g_precision;   // 0 = fp32 (default); 1 = split-bf16 where an instance exists (read at create)
+// split-bf16 ("precision" = 1) form of the same conv (conv_bf3.hip); groups == 1 only
+void pack_conv_weights_bf3(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
+                           int& Mpad, int& nchunk);
+int launch_conv_bf3(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream);
+int conv_bf3_tile_bn(int M);
+extern int g_precision;   // "precision" option: 0 = fp32 (default); 1 = split-bf16 generator (read at create)
+extern int g_conv_prec;   // precision make_conv packs for: g_precision inside dissc_gen_create, else 0
+                          // (predictors and HuBERT feed integer decisions and always stay fp32)
 extern int g_use_mfma32;  // tuning: 0 forces the 16x16x4 kernel everywhere
 
 // Host-side weight packing.  w: [Cout][Cin][KS] (Conv1d layout).  Returns the packed
@@ -156,6 +161,15 @@ int launch_resblock_fused(int C, const float* x, float* acc, const float* wpack,
                           const int32_t* lengths, int len_default, int len_mul, int KS, const int* dil,
                           int B, int Lmax, int ld, float slope, int epi, float mrf_div,
                           hipStream_t stream);
+
+// the same block in split-bf16 arithmetic ("precision" = 1 only; resblock_bf3.hip)
+bool resblock_bf3_supported(int C, int KS, const int* dil);
+void resblock_bf3_set_variant(int v);
+void pack_resblock_bf3(int C, int KS, const float* const* w6, std::vector<float>& packed);
+int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, const float* bias,
+                        const int32_t* lengths, int len_default, int len_mul, int KS, const int* dil,
+                        int B, int Lmax, int ld, float slope, int epi, float mrf_div,
+                        hipStream_t stream);
 
 // misc kernels (gen_misc.hip)
 void launch_embed_concat(const int64_t* code, const float* f0, const int64_t* spkr,

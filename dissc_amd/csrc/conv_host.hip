@@ -8,6 +8,7 @@ namespace dissc {
 
 int g_use_mfma32 = 1;
 int g_precision = 0;
+int g_conv_prec = 0;  // what make_conv packs for; dissc_gen_create raises it to g_precision for its own layers
 
 int upload(const std::vector<float>& h, float** d) {
   DISSC_HIP_CHECK(hipMalloc((void**)d, h.size() * sizeof(float)));
@@ -24,9 +25,9 @@ int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int 
   dc.m32 = (g_use_mfma32 && Mg >= 32) ? 1 : 0;  // 64-cycle MFMAs wherever a 32-row tile is not mostly padding
   // split-bf16 only where conv_mfma32.hip has an instance for it
   const bool lin_big = (KS == 1 && Mg >= 256 && (Cg + KC - 1) / KC >= 8);
-  dc.prec = (g_precision == 1 && dc.m32 && stride == 1 && groups == 1 && (KS - 1) * dil <= MAX_TAP_SPAN && !lin_big)
+  dc.prec = (g_conv_prec == 1 && dc.m32 && stride == 1 && groups == 1 && (KS - 1) * dil <= MAX_TAP_SPAN && !lin_big)
                 ? 1 : 0;
-  if (dc.prec) pack_conv_weights32_bf3(w, Cout, Cg, KS, packed, Mpad, nchunk, groups);
+  if (dc.prec) pack_conv_weights_bf3(w, Cout, Cg, KS, packed, Mpad, nchunk);
   else if (dc.m32) pack_conv_weights32(w, Cout, Cg, KS, packed, Mpad, nchunk, groups);
   else pack_conv_weights(w, Cout, Cg, KS, packed, Mpad, nchunk, groups);
   std::vector<float> b((size_t)Mpad * groups, 0.f);

@@ -6,25 +6,17 @@
 #include <string.h>
 
 #include "common.h"
+#include "conv_epilogue32.h"
 
 namespace dissc {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
-__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
 // 32x32x2 form of the kernel in conv_mfma.hip (64-cycle MFMAs sustain ~155 TFLOP/s on this part,
 // the 16x16x4 form ~130-139): tile units are 32 rows x 32 columns, a k-step is 2 channels.
 // STRIDE: input step per output position (1; 2 for HuBERT's strided feature convs).
 // SPAN: largest (KS-1)*dil the staging registers are sized for.
 // CPB: 16-channel chunks staged per barrier (4 for 1x1 convs, whose chunk is a single tap).
-// PREC = 1: split-bf16 ("bf16x3") arithmetic -- every fp32 operand is split on the fly into
-// hi + lo bf16 halves and each product is formed as hi*hi + hi*lo + lo*hi on the bf16 matrix
-// cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate): ~2^-17 relative product error instead of
-// exact fp32, at a multiple of the fp32-MFMA rate.  Opt-in only (dissc_set_option("precision", 1)).
-template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1, int PREC = 0>
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const ConvArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BN = 32 * NI * WN;
@@ -150,49 +142,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
 #pragma unroll 1
     for (int sc = 0; sc < CPB; ++sc) {
       if (cb * CPB + sc >= a.nchunk) break;
-      if constexpr (PREC == 1) {
-        // ---- split-bf16 path: rows 8h..8h+7 of the chunk are this lane's 8 k-values ----
-        const float* bj = blk + sc * (KC * XW) + 7 * h * XW;  // blk already holds h*XW
-        for (int j = 0; j < a.KS; ++j, ++q) {
-          const int qn = (q + 1 < nq) ? q + 1 : q;
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            avn[mi][0] = wp[mi][(size_t)qn * 128];
-            avn[mi][1] = wp[mi][(size_t)qn * 128 + 64];
-          }
-          if (j == 0 && sc == 0 && more) stage_load(cb + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          bf16x8 bh[NI], bl[NI];
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float x = bj[e * XW + ni * 32 * CS];
-              const __bf16 xh = (__bf16)x;
-              bh[ni][e] = xh;
-              bl[ni][e] = (__bf16)(x - (float)xh);
-            }
-          }
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, av[mi][0]);
-            const bf16x8 al = __builtin_bit_cast(bf16x8, av[mi][1]);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            av[mi][0] = avn[mi][0];
-            av[mi][1] = avn[mi][1];
-          }
-          bj += a.dil;
-        }
-      } else {
+      {
       const float* bch = blk + sc * (KC * XW);
         // tap j of a stride-2 conv reads plane (sh+j)&1 at column offset (sh+j)>>1
         const float* bj = (STRIDE == 2) ? bch + (sh & 1) * XH + (sh >> 1) : bch;
@@ -244,109 +194,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
   }
 #undef DISSC_MFMA_STEP
 
-  const int epi = a.epi;
-  const size_t ob = (size_t)b * a.o_bstride;
-  // C/D layout of 32x32x2: col = lane & 31 (time), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-  if (a.up != 1) {
-    // ConvTranspose pixel shuffle straight from registers: row = co*np + pi -> out[co][t*up + p0 + pi]
-    const int tbase = t0 + wn * (32 * NI) + l31;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (ms0 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row >= a.M) continue;
-        const float bz = a.bias[row];  // ConvTranspose path: groups == 1
-        const int co = row / a.up_np;
-        const int p = a.up_p0 + row - co * a.up_np;
-        const size_t rowoff = ob + (size_t)co * a.ldo + p;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int t = tbase + ni * 32;
-          if (t < olen) a.out[rowoff + (size_t)t * a.up] = acc[mi][ni][r] + bz;
-        }
-      }
-    }
-    return;
-  }
-
-  // Transposed epilogue: 8 rows at a time through a wave-private LDS patch [8][CW] -> 16 B per lane.
-  float* ep = xs + wave * (8 * CW);
-  constexpr int LPR = 8 * NI;        // float4 lanes per output row (32*NI columns)
-  constexpr int RPP = 64 / LPR;      // rows per pass
-  constexpr int NPASS = 8 / RPP;
-  const int prow = lane / LPR, pc4 = lane % LPR;
-  const int tcol = t0 + wn * (32 * NI) + 4 * pc4;
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {  // rows 8*qd .. 8*qd+7 of the 32-row subtile
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ep[(4 * h + r) * CW + ni * 32 + l31] = acc[mi][ni][qd * 4 + r];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        const int rl = p * RPP + prow;
-        const int row = (ms0 + mi) * 32 + qd * 8 + rl;  // within the group
-        f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * CW + 4 * pc4);
-        if (row >= a.M || tcol >= olen) continue;
-        const int prow_idx = grp * a.nsub_group * 32 + row;  // bias/scale/shift are [groups][Mpad]
-        const float bz = a.bias[prow_idx];
-        v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
-        if (a.scale) {  // eval-mode BatchNorm1d as PyTorch evaluates it: x * alpha + beta
-          const float sc = a.scale[prow_idx], sf = a.shift[prow_idx];
-          v[0] = v[0] * sc + sf; v[1] = v[1] * sc + sf; v[2] = v[2] * sc + sf; v[3] = v[3] * sc + sf;
-        }
-        if (a.act == 1) {
-          v[0] = gelu_exact(v[0]); v[1] = gelu_exact(v[1]); v[2] = gelu_exact(v[2]); v[3] = gelu_exact(v[3]);
-        }
-        const size_t idx = ob + (size_t)(grp * a.M + row) * a.ldo + tcol;
-        const int nv = olen - tcol;  // >= 1
-        if (nv >= 4) {
-          if (epi == EPI_STORE) {
-            *reinterpret_cast<f32x4*>(a.out + idx) = v;
-          } else {
-            const f32x4 rs = *reinterpret_cast<const f32x4*>(a.res + idx);
-            v[0] += rs[0]; v[1] += rs[1]; v[2] += rs[2]; v[3] += rs[3];
-            if (epi == EPI_RES) {
-              *reinterpret_cast<f32x4*>(a.out + idx) = v;
-            } else if (epi == EPI_MRF_SET) {
-              *reinterpret_cast<f32x4*>(a.acc + idx) = v;
-            } else {
-              const f32x4 ac = *reinterpret_cast<const f32x4*>(a.acc + idx);
-              v[0] = ac[0] + v[0]; v[1] = ac[1] + v[1]; v[2] = ac[2] + v[2]; v[3] = ac[3] + v[3];
-              if (epi == EPI_MRF_DIV) {
-                v[0] = __fdiv_rn(v[0], a.mrf_div); v[1] = __fdiv_rn(v[1], a.mrf_div);
-                v[2] = __fdiv_rn(v[2], a.mrf_div); v[3] = __fdiv_rn(v[3], a.mrf_div);
-              }
-              *reinterpret_cast<f32x4*>(a.acc + idx) = v;
-            }
-          }
-        } else {
-          for (int e = 0; e < nv; ++e) {
-            float x = v[e];
-            if (epi == EPI_STORE) {
-              a.out[idx + e] = x;
-            } else {
-              x += a.res[idx + e];
-              if (epi == EPI_RES) {
-                a.out[idx + e] = x;
-              } else if (epi == EPI_MRF_SET) {
-                a.acc[idx + e] = x;
-              } else {
-                x = a.acc[idx + e] + x;
-                if (epi == EPI_MRF_DIV) x = __fdiv_rn(x, a.mrf_div);
-                a.acc[idx + e] = x;
-              }
-            }
-          }
-        }
-      }
-    }
-  }
+  conv_epilogue32<MI, NI>(a, acc, xs, b, t0, olen, grp, ms0, wn);
 }
 
 // ---------------------------------------------------------------------------------
@@ -415,51 +263,7 @@ void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<
               }
 }
 
-static inline uint16_t f32_to_bf16_rne(float f) {
-  uint32_t u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-static inline float bf16_to_f32(uint16_t h) {
-  uint32_t u = (uint32_t)h << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
-
-// Split-bf16 A fragments in the same [group][ms32][chunk][tap][half][lane] 16-byte slots as the fp32
-// form: half 0 = hi, half 1 = lo; element e of a slot is k = 8*(lane>>5) + e, i.e. channel
-// 16*c + 8*(lane>>5) + e of row 32*ms + (lane & 31).
-void pack_conv_weights32_bf3(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
-                             int& Mpad, int& nchunk, int groups) {
-  const int Mg = Cout / groups;
-  const int bm = bm32_of(Mg);
-  Mpad = (Mg + bm - 1) / bm * bm;
-  nchunk = (Cin + KC - 1) / KC;
-  const int nsub = Mpad / 32;
-  packed.assign((size_t)groups * nsub * nchunk * KS * 2 * 64 * 4, 0.f);
-  uint16_t* p16 = reinterpret_cast<uint16_t*>(packed.data());
-  for (int gi = 0; gi < groups; ++gi)
-    for (int ms = 0; ms < nsub; ++ms)
-      for (int c = 0; c < nchunk; ++c)
-        for (int j = 0; j < KS; ++j)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < 8; ++e) {
-              const int co = ms * 32 + (lane & 31);
-              const int ci = c * KC + 8 * (lane >> 5) + e;
-              float v = 0.f;
-              if (co < Mg && ci < Cin) v = w[((size_t)(gi * Mg + co) * Cin + ci) * KS + j];
-              const uint16_t hi = f32_to_bf16_rne(v);
-              const uint16_t lo = f32_to_bf16_rne(v - bf16_to_f32(hi));
-              const size_t slot = (((((size_t)gi * nsub + ms) * nchunk + c) * KS + j) * 2) * 64 + lane;  // half 0
-              p16[slot * 8 + e] = hi;
-              p16[(slot + 64) * 8 + e] = lo;
-            }
-}
-
-template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1, int PREC = 0>
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1>
 static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN, NW = WM * WN;
   constexpr int CW = 32 * NI + 4;
@@ -475,11 +279,11 @@ static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB, PREC>),
+        reinterpret_cast<const void*>(&conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB, PREC>), grid, dim3(64 * WM * WN), lds,
+  hipLaunchKernelGGL((conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>), grid, dim3(64 * WM * WN), lds,
                      stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
@@ -507,17 +311,7 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
     if (g_lin_tile == 4) return launch32_t<2, 2, 4, 1, 1, 0, 4>(a, B, Lmax_out, stream);  // 64 ch / barrier
     return launch32_t<2, 2, 4, 1, 1, 0, 2>(a, B, Lmax_out, stream);                        // 32 ch / barrier
   }
-  if (a.prec == 1) {  // split-bf16 instances (stride 1, taps <= MAX_TAP_SPAN, 16 channels per barrier)
-    switch (cfg) {
-      case 0: return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN, 1, 1>(a, B, Lmax_out, stream);
-      case 1: return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN, 1, 1>(a, B, Lmax_out, stream);
-      case 2: return launch32_t<1, 2, 2, 2, 1, MAX_TAP_SPAN, 1, 1>(a, B, Lmax_out, stream);
-      case 3: return launch32_t<1, 2, 1, 4, 1, MAX_TAP_SPAN, 1, 1>(a, B, Lmax_out, stream);
-      default:
-        set_error("launch_conv32: no split-bf16 instance for tile config %d", cfg);
-        return DISSC_EINVAL;
-    }
-  }
+  if (a.prec == 1) return launch_conv_bf3(a, B, Lmax_out, stream);  // split-bf16 kernels (conv_bf3.hip)
   if (g_cpb2 && a.KS <= g_cpb2 && a.nchunk >= 4 && a.up == 1) {  // two chunks per barrier for short kernels
     if (cfg == 0) return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
     if (cfg == 1) return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);

@@ -41,6 +41,7 @@ struct dissc_gen {
   std::vector<std::vector<DevConv>> ups;  // per stage: one conv per phase group
   std::vector<DevConv> rb1, rb2;  // [stage*nk*3 + j*3 + m]
   std::vector<float*> fused_w, fused_b;  // [stage*nk + j]: 6 packed convs / biases of a fused ResBlock
+  std::vector<char> fused_bf3;           // ... packed for the split-bf16 kernel (resblock_bf3.hip)
   float* post_w = nullptr;
   float* post_b = nullptr;
   int post_C = 0, post_KS = 0;
@@ -129,6 +130,10 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
 
   dissc_gen* g = new dissc_gen();
   g->cfg = *cfg;
+  struct PrecScope {  // only the generator's layers may be packed for split-bf16
+    PrecScope() { g_conv_prec = g_precision; }
+    ~PrecScope() { g_conv_prec = 0; }
+  } prec_scope;
   int rc = DISSC_OK;
   const float *w = nullptr, *b = nullptr;
   const int c0 = cfg->upsample_initial_channel;
@@ -153,6 +158,7 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
   g->rb2.resize((size_t)cfg->num_upsamples * nk * 3);
   g->fused_w.assign((size_t)cfg->num_upsamples * nk, nullptr);
   g->fused_b.assign((size_t)cfg->num_upsamples * nk, nullptr);
+  g->fused_bf3.assign((size_t)cfg->num_upsamples * nk, 0);
   for (int i = 0; i < cfg->num_upsamples; ++i) {
     const int s = cfg->upsample_rates[i], k = cfg->upsample_kernel_sizes[i];
     if (s < 1 || k < s || (k - s) % 2 != 0) {  // L_out = s * L_in needs k - s even
@@ -176,8 +182,10 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
         set_error("dissc_gen_create: even resblock kernel size %d unsupported", rk);
         return fail(DISSC_EINVAL);
       }
-      const bool fuse = resblock_fused_supported(ch, rk, cfg->resblock_dilations[j]);
+      const bool bf3 = g_precision == 1 && resblock_bf3_supported(ch, rk, cfg->resblock_dilations[j]);
+      const bool fuse = !bf3 && resblock_fused_supported(ch, rk, cfg->resblock_dilations[j]);
       std::vector<float> fw, fb;
+      const float* w6[6];
       for (int m = 0; m < 3; ++m) {
         const int d = cfg->resblock_dilations[j][m];
         const size_t idx = ((size_t)i * nk + j) * 3 + m;
@@ -186,6 +194,10 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
         snprintf(name, sizeof(name), "resblocks.%d.convs1.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
         if ((rc = make_conv(w, b, ch, ch, rk, d, g->rb1[idx]))) return fail(rc);
+        if (bf3) {
+          w6[2 * m] = w;
+          fb.insert(fb.end(), b, b + ch);
+        }
         if (fuse) {
           std::vector<float> pk;
           int mp, nc;
@@ -198,6 +210,10 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
         snprintf(name, sizeof(name), "resblocks.%d.convs2.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
         if ((rc = make_conv(w, b, ch, ch, rk, 1, g->rb2[idx]))) return fail(rc);
+        if (bf3) {
+          w6[2 * m + 1] = w;
+          fb.insert(fb.end(), b, b + ch);
+        }
         if (fuse) {
           std::vector<float> pk;
           int mp, nc;
@@ -206,7 +222,11 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
           fb.insert(fb.end(), b, b + ch);
         }
       }
-      if (fuse) {
+      if (bf3) {
+        pack_resblock_bf3(ch, rk, w6, fw);
+        g->fused_bf3[(size_t)i * nk + j] = 1;
+      }
+      if (fuse || bf3) {
         if ((rc = upload(fw, &g->fused_w[(size_t)i * nk + j]))) return fail(rc);
         if ((rc = upload(fb, &g->fused_b[(size_t)i * nk + j]))) return fail(rc);
       }
@@ -343,10 +363,10 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
         const int epi = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET)
                                  : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
         if (multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));
-        if ((rc = launch_resblock_fused(ch, X, ACC, g->fused_w[(size_t)i * nk + j],
-                                        g->fused_b[(size_t)i * nk + j], lengths, L, mul,
-                                        c.resblock_kernel_sizes[j], c.resblock_dilations[j], B, L, ld,
-                                        0.1f, epi, (float)nk, sj)))
+        auto* fused = g->fused_bf3[(size_t)i * nk + j] ? &launch_resblock_bf3 : &launch_resblock_fused;
+        if ((rc = fused(ch, X, ACC, g->fused_w[(size_t)i * nk + j], g->fused_b[(size_t)i * nk + j],
+                        lengths, L, mul, c.resblock_kernel_sizes[j], c.resblock_dilations[j], B, L, ld,
+                        0.1f, epi, (float)nk, sj)))
           return rc;
         if (multi) DISSC_HIP_CHECK(hipEventRecord(g->ev_fin[j], sj));
         continue;
@@ -461,7 +481,11 @@ int dissc_set_option(const char* key, int value) {
     return DISSC_OK;
   }
   if (strcmp(key, "fused_max_c") == 0) { fused_set_option(2, value); return DISSC_OK; }
-  if (strcmp(key, "fused_variant") == 0) { fused_set_option(3, value); return DISSC_OK; }
+  if (strcmp(key, "fused_variant") == 0) {
+    fused_set_option(3, value);
+    resblock_bf3_set_variant(value);
+    return DISSC_OK;
+  }
   set_error("dissc_set_option: unknown key %s", key);
   return DISSC_EINVAL;
 }
@@ -480,7 +504,9 @@ int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int e
     v = ((s >> 8) / 16777216.0f - 0.5f) * 0.05f;
   }
   DevConv dc;
+  g_conv_prec = g_precision;  // diagnostics follow the "precision" option like the generator does
   int rc = make_conv(w.data(), bias.data(), Cout, Cin, k, dilation, dc);
+  g_conv_prec = 0;
   if (rc) return rc;
   const int ld = (L + 3) / 4 * 4;
   const size_t nx = (size_t)B * Cin * ld, no = (size_t)B * Cout * ld;

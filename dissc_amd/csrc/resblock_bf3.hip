@@ -1,0 +1,354 @@
+// Fused ResBlock1 in split-bf16 ("bf16x3") arithmetic for the narrow stages of the generator.
+// Only used when the "precision" option is 1 (see dissc_set_option); the default fp32 path never
+// comes here.
+//
+//   x_k = x;  3 x { x_k = x_k + conv_1(lrelu(conv_d(lrelu(x_k)))) }, d = dil[0..2]    (KS taps each)
+//   then the MRF update of the stage accumulator:  acc = r | acc + r | (acc + r) / 3
+// (reference sr/models.py:34-41 and :103-109).
+//
+// Unfused, a narrow stage moves ~51 activation passes through HBM and is bandwidth bound; on the
+// bf16 matrix cores the arithmetic is nearly free, so the whole block runs out of LDS:
+//   - every wave OWNS a fixed set of 16-column tiles of the window [t0 - H, t0 + BN + H) for all six
+//     convs; the running value x_k of its columns stays in REGISTERS (fp32, MFMA D layout) from the
+//     first load to the MRF update;
+//   - what the other waves need -- lrelu(x_k) and the activated intermediate -- is published to LDS
+//     already split into hi/lo bf16 halves, in planes [channel octet][hi|lo][column][8 bf16], so
+//     a B fragment of v_mfma_f32_16x16x32_bf16 is one conflict-free ds_read_b128 at any tap
+//     offset, and nothing is split inside the tap loop;
+//   - K = 32 of one MFMA holds TWO taps x 16 channels (lane group g = l >> 4: tap 2jj + (g >> 1),
+//     channels 8 (g & 1) .. +7); an odd tap count is padded with a zero-weight tap;
+//   - the halo columns are recomputed and go stale inwards by p per layer; only the centre
+//     [t0, t0 + BN) is written back.  HBM traffic: one read of x, one read-modify-write of acc.
+// The reference's per-layer zero padding is reproduced by forcing every published value to 0
+// outside the utterance's [0, len).
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace dissc {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct ResblockBf3Args {
+  const float* x;        // [B][C][ld]   stage input
+  float* acc;            // [B][C][ld]   MRF accumulator
+  const bf16x8* wpack;   // [6 convs][NP tap pairs][hi|lo][64 lanes] x 8 bf16
+  const float* bias;     // [6][C]
+  const int32_t* lengths;
+  int len_default, len_mul;
+  int dil[3];
+  int BN, H4, ld;        // centre width, halo rounded up to 4, row stride
+  long long bstride;
+  float slope, mrf_div;
+  int epi;               // EPI_MRF_SET / EPI_MRF_ADD / EPI_MRF_DIV
+};
+
+__device__ __forceinline__ float lrelu_b(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+template <int KS, int NW, int NI>
+__global__ void __launch_bounds__(64 * NW) resblock16_bf3_kernel(const ResblockBf3Args a) {
+  constexpr int C = 16;
+  constexpr int NT = 64 * NW;
+  constexpr int NP = (KS + 1) / 2;   // tap pairs
+  constexpr int P2 = (KS - 1) / 2;
+  constexpr int COLS = 16 * NW * NI;  // window columns owned by the workgroup
+  constexpr int PAD = 32;             // >= P2 * 5 + 5: reach of the widest (padded) tap
+  constexpr int XW = COLS + 2 * PAD;
+  constexpr int TB = 4;               // tiles per accumulator batch
+  static_assert(NI % TB == 0, "NI must be a multiple of the tile batch");
+  extern __shared__ __attribute__((aligned(16))) bf16x8 lds8[];
+  bf16x8* Ap = lds8;           // lrelu(x_k):       planes [octet][hi|lo][XW]
+  bf16x8* Tp = lds8 + 4 * XW;  // lrelu(conv1 out): same layout
+  float* S = reinterpret_cast<float*>(Tp);  // fp32 [16][XW] transpose scratch (T is dead when used)
+
+  const int b = blockIdx.y;
+  const int len = a.lengths ? a.lengths[b] * a.len_mul : a.len_default;
+  const int t0 = blockIdx.x * a.BN;
+  if (t0 >= len) return;
+  const int tw0 = t0 - a.H4;  // time of window column 0 (a multiple of 4)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const float slope = a.slope;
+  const float* xb = a.x + (size_t)b * a.bstride;
+  const bf16x8* wl = a.wpack + lane;
+
+  bf16x8 w[NP][2];
+  auto load_w = [&](int layer) {
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) {
+      w[jj][0] = wl[((layer * NP + jj) * 2 + 0) * 64];
+      w[jj][1] = wl[((layer * NP + jj) * 2 + 1) * 64];
+    }
+  };
+  load_w(0);
+
+  // ---- window -> scratch (coalesced 16 B per lane), zero the A pads ----
+  {
+    constexpr int NV = COLS / 4;
+    for (int e = tid; e < C * NV; e += NT) {
+      const int r = e / NV, v = e - r * NV;
+      const int t = tw0 + 4 * v;
+      const int tc = t < 0 ? 0 : (t > a.ld - 4 ? a.ld - 4 : t);
+      f32x4 val = *reinterpret_cast<const f32x4*>(xb + (size_t)r * a.ld + tc);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) val[k] = (t + k >= 0 && t + k < len) ? val[k] : 0.f;
+      *reinterpret_cast<f32x4*>(S + r * XW + PAD + 4 * v) = val;
+    }
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = tid; e < 4 * 2 * PAD; e += NT) {
+      const int pl = e / (2 * PAD), c = e - pl * (2 * PAD);
+      Ap[pl * XW + (c < PAD ? c : COLS + c)] = z;
+    }
+  }
+  __syncthreads();
+
+  // publish 4 channels (rows 4g .. 4g+3) of column u, split into hi / lo halves
+  auto publish = [&](bf16x8* P, int u, const float (&v)[4]) {
+    bf16x4 vh, vl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const __bf16 h = (__bf16)v[r];
+      vh[r] = h;
+      vl[r] = (__bf16)(v[r] - (float)h);
+    }
+    __bf16* p = reinterpret_cast<__bf16*>(P + (2 * (g >> 1)) * XW + PAD + u) + 4 * (g & 1);
+    *reinterpret_cast<bf16x4*>(p) = vh;
+    *reinterpret_cast<bf16x4*>(p + XW * 8) = vl;
+  };
+
+  const int ucol = wave * (NI * 16);
+  float xk[NI][4];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int u = ucol + ni * 16 + l15;
+    float av[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xk[ni][r] = S[(4 * g + r) * XW + PAD + u];
+      av[r] = lrelu_b(xk[ni][r], slope);
+    }
+    publish(Ap, u, av);
+  }
+  __syncthreads();
+  {  // the scratch is consumed: zero the T pads (ordered before conv2 by the barrier after conv1)
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = tid; e < 4 * 2 * PAD; e += NT) {
+      const int pl = e / (2 * PAD), c = e - pl * (2 * PAD);
+      Tp[pl * XW + (c < PAD ? c : COLS + c)] = z;
+    }
+  }
+
+  // one conv over TB tiles starting at window column ub: acc += W (x) P[.. - p + j*d ..]
+  auto conv = [&](const bf16x8* P, int d, int ub, f32x4 (&acc)[TB]) {
+    const bf16x8* bj = P + (2 * (g & 1)) * XW + PAD + ub + l15 - P2 * d + (g >> 1) * d;
+#pragma unroll
+    for (int ni = 0; ni < TB; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) {
+#pragma unroll
+      for (int ni = 0; ni < TB; ++ni) {
+        const bf16x8 bh = bj[ni * 16];
+        const bf16x8 bl = bj[ni * 16 + XW];
+        acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][1], bh, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][0], bl, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][0], bh, acc[ni], 0, 0, 0);
+      }
+      bj += 2 * d;
+    }
+  };
+
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    // ---- conv1 (dilated): A -> T ----
+    {
+      float bz[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bz[r] = a.bias[(2 * m) * C + 4 * g + r];
+      const int d = a.dil[m];
+      f32x4 acc[NI / TB][TB];
+#pragma unroll
+      for (int tb = 0; tb < NI / TB; ++tb) conv(Ap, d, ucol + tb * (TB * 16), acc[tb]);
+      load_w(2 * m + 1);
+#pragma unroll
+      for (int tb = 0; tb < NI / TB; ++tb)
+#pragma unroll
+        for (int ni = 0; ni < TB; ++ni) {
+          const int u = ucol + (tb * TB + ni) * 16 + l15;
+          const int t = tw0 + u;
+          const bool inside = t >= 0 && t < len;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = inside ? lrelu_b(acc[tb][ni][r] + bz[r], slope) : 0.f;
+          publish(Tp, u, v);
+        }
+    }
+    __syncthreads();
+    // ---- conv2 (dilation 1): T -> x_k += ..., publish lrelu(x_k) to A ----
+    {
+      float bz[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bz[r] = a.bias[(2 * m + 1) * C + 4 * g + r];
+      f32x4 acc[NI / TB][TB];
+#pragma unroll
+      for (int tb = 0; tb < NI / TB; ++tb) conv(Tp, 1, ucol + tb * (TB * 16), acc[tb]);
+      if (m < 2) load_w(2 * m + 2);
+#pragma unroll
+      for (int tb = 0; tb < NI / TB; ++tb)
+#pragma unroll
+        for (int ni = 0; ni < TB; ++ni) {
+          const int nn = tb * TB + ni;
+          const int u = ucol + nn * 16 + l15;
+          const int t = tw0 + u;
+          const bool inside = t >= 0 && t < len;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            xk[nn][r] = inside ? xk[nn][r] + (acc[tb][ni][r] + bz[r]) : 0.f;
+            v[r] = lrelu_b(xk[nn][r], slope);
+          }
+          if (m < 2) publish(Ap, u, v);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- x_k -> scratch -> MRF update of the centre columns, 16 B per lane ----
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int u = ucol + ni * 16 + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(4 * g + r) * XW + PAD + u] = xk[ni][r];
+  }
+  __syncthreads();
+  {
+    const int nv = a.BN >> 2;
+    float* ab = a.acc + (size_t)b * a.bstride;
+    for (int e = tid; e < C * nv; e += NT) {
+      const int r = e / nv, v4 = e - r * nv;
+      const int t = t0 + 4 * v4;
+      if (t >= len) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(S + r * XW + PAD + a.H4 + 4 * v4);
+      float* dst = ab + (size_t)r * a.ld + t;
+      const int nval = len - t;
+      if (nval >= 4) {
+        if (a.epi != EPI_MRF_SET) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+          v[0] = o[0] + v[0]; v[1] = o[1] + v[1]; v[2] = o[2] + v[2]; v[3] = o[3] + v[3];
+          if (a.epi == EPI_MRF_DIV) {
+            v[0] = __fdiv_rn(v[0], a.mrf_div); v[1] = __fdiv_rn(v[1], a.mrf_div);
+            v[2] = __fdiv_rn(v[2], a.mrf_div); v[3] = __fdiv_rn(v[3], a.mrf_div);
+          }
+        }
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+        for (int k = 0; k < nval; ++k) {
+          float x = v[k];
+          if (a.epi != EPI_MRF_SET) {
+            x = dst[k] + x;
+            if (a.epi == EPI_MRF_DIV) x = __fdiv_rn(x, a.mrf_div);
+          }
+          dst[k] = x;
+        }
+      }
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------
+
+static inline uint16_t bf16_rne_host(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32_host(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+static int g_bf3_variant = 0;  // "fused_variant" in precision mode: 0 = 1024-column window, 1 = 512
+void resblock_bf3_set_variant(int v) { g_bf3_variant = v; }
+
+bool resblock_bf3_supported(int C, int KS, const int* dil) {
+  if (C != 16) return false;
+  if (KS != 3 && KS != 7 && KS != 11) return false;
+  for (int m = 0; m < 3; ++m)
+    if (dil[m] < 1 || dil[m] > 5) return false;
+  return true;
+}
+
+// w6: the six conv weights [C][C][KS] in execution order (c1_0, c2_0, c1_1, c2_1, c1_2, c2_2).
+// packed (as raw 32-bit words): [6][NP][hi|lo][64 lanes][8 bf16]
+void pack_resblock_bf3(int C, int KS, const float* const* w6, std::vector<float>& packed) {
+  const int NP = (KS + 1) / 2;
+  packed.assign((size_t)6 * NP * 2 * 64 * 4, 0.f);
+  uint16_t* p16 = reinterpret_cast<uint16_t*>(packed.data());
+  for (int l = 0; l < 6; ++l)
+    for (int jj = 0; jj < NP; ++jj)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int co = lane & 15, gq = lane >> 4;
+        const int tap = 2 * jj + (gq >> 1);
+        for (int e = 0; e < 8; ++e) {
+          const int ci = 8 * (gq & 1) + e;
+          const float v = tap < KS ? w6[l][((size_t)co * C + ci) * KS + tap] : 0.f;
+          const uint16_t hi = bf16_rne_host(v);
+          const uint16_t lo = bf16_rne_host(v - bf16_to_f32_host(hi));
+          const size_t slot = (((size_t)l * NP + jj) * 2) * 64 + lane;
+          p16[slot * 8 + e] = hi;
+          p16[(slot + 64) * 8 + e] = lo;
+        }
+      }
+}
+
+template <int KS, int NW, int NI>
+static int launch_bf3(ResblockBf3Args a, int B, int Lmax, hipStream_t stream) {
+  constexpr int COLS = 16 * NW * NI, XW = COLS + 64;
+  const int P2 = (KS - 1) / 2;
+  const int H = P2 * (a.dil[0] + a.dil[1] + a.dil[2] + 3);
+  a.H4 = (H + 3) & ~3;
+  a.BN = COLS - 2 * a.H4;
+  const size_t lds = (size_t)8 * XW * 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock16_bf3_kernel<KS, NW, NI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  dim3 grid((Lmax + a.BN - 1) / a.BN, B);
+  hipLaunchKernelGGL((resblock16_bf3_kernel<KS, NW, NI>), grid, dim3(64 * NW), lds, stream, a);
+  DISSC_HIP_CHECK(hipGetLastError());
+  return DISSC_OK;
+}
+
+int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, const float* bias,
+                        const int32_t* lengths, int len_default, int len_mul, int KS, const int* dil,
+                        int B, int Lmax, int ld, float slope, int epi, float mrf_div,
+                        hipStream_t stream) {
+  if (!resblock_bf3_supported(C, KS, dil)) {
+    set_error("launch_resblock_bf3: C=%d k=%d unsupported", C, KS);
+    return DISSC_EINVAL;
+  }
+  ResblockBf3Args a;
+  a.x = x; a.acc = acc; a.wpack = reinterpret_cast<const bf16x8*>(wpack); a.bias = bias; a.lengths = lengths;
+  a.len_default = len_default; a.len_mul = len_mul;
+  a.dil[0] = dil[0]; a.dil[1] = dil[1]; a.dil[2] = dil[2];
+  a.ld = ld; a.bstride = (long long)C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi;
+  a.BN = 0; a.H4 = 0;
+  if (g_bf3_variant == 1) {
+    if (KS == 3) return launch_bf3<3, 8, 4>(a, B, Lmax, stream);
+    if (KS == 7) return launch_bf3<7, 8, 4>(a, B, Lmax, stream);
+    return launch_bf3<11, 8, 4>(a, B, Lmax, stream);
+  }
+  if (KS == 3) return launch_bf3<3, 8, 8>(a, B, Lmax, stream);
+  if (KS == 7) return launch_bf3<7, 8, 8>(a, B, Lmax, stream);
+  return launch_bf3<11, 8, 8>(a, B, Lmax, stream);
+}
+
+}  // namespace dissc

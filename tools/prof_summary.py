@@ -32,7 +32,7 @@ def layer_list(B=32, T=500):
 
 def main():
     path = sys.argv[1]
-    rows = [r for r in csv.DictReader(open(path)) if "conv_mfma" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "conv_mfma" in r["Kernel_Name"] or "conv16_stream" in r["Kernel_Name"]]
     layers = layer_list()
     n = len(layers)
     assert len(rows) % n == 0, (len(rows), n)
