@@ -81,6 +81,35 @@ class _FakeEvent:
         return (other.t - self.t) * 1e3
 
 
+def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_sec_per_step):
+    """The opt-in split-bf16 ("bf16x3") arithmetic mode of the same generator, timed on the same
+    batch right after the fp32 run and checked against the fp32 waveform (north_star bar: 1e-4 RMS).
+    Reported next to the headline number, never instead of it."""
+    import dissc_amd
+    dissc_amd._lib.check(dissc_amd.lib.dissc_set_option(b"precision", 1), "set_option")
+    try:
+        g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to(dev)  # the option is read at create
+        g.load_state_dict(sd)
+        g.eval()
+        g.remove_weight_norm()
+        for _ in range(2):  # the handle is built (and the option read) on the first forward
+            y = g(code=d_code, f0=d_f0, spkr=d_spkr)
+        torch.cuda.synchronize()
+    finally:
+        dissc_amd.lib.dissc_set_option(b"precision", 0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        y = g(code=d_code, f0=d_f0, spkr=d_spkr)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    err = (y - y_fp32).double()
+    return {"arithmetic": "bf16 hi/lo operand split, 3 bf16 MFMAs per product, fp32 accumulate "
+                          "(dissc_set_option('precision', 1); default is exact fp32)",
+            "ms_per_step": round(dt * 1e3, 3), "value": round(audio_sec_per_step / dt, 1),
+            "unit": "audio-sec/sec", "rms_vs_fp32": float(err.pow(2).mean().sqrt()),
+            "max_abs_vs_fp32": float(err.abs().max()), "tolerance_rms": 1e-4}
+
+
 def hbm_traffic(B, T):
     """HBM bytes per step from the committed PMC capture (profiles/r01/hbm_traffic.json:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950
@@ -100,6 +129,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split-bf16", action="store_true", help="skip the extra split-bf16 leg (N=1 only)")
     a = ap.parse_args()
 
     # DISSC_BENCH_FAKE=1: CPU/gloo dry run of the distributed bookkeeping only (tests/test_bench_dist.py);
@@ -203,9 +233,12 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": hbm_traffic(B, T),
-                         "kernel": "conv_mfma_kernel (all generator convs; fp32 v_mfma_f32_16x16x4)",
+                         "kernel": "conv_mfma32_kernel family (all generator convs; fp32 v_mfma_f32_32x32x2, 16x16x4 on the 16-channel stage)",
                          "flops_per_step": flops_step, "kernel_ms_per_step": round(kern_s * 1e3, 3)},
         }
+        if not a.no_split_bf16 and n_gpus == 1 and not fake:
+            out["split_bf16"] = split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y, a.steps,
+                                               audio_sec_per_step)
         if not a.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(synth, sd, torch.from_numpy(code), torch.from_numpy(f0),
                                                torch.from_numpy(spkr))

@@ -273,7 +273,7 @@ static inline float bf16_to_f32_host(uint16_t h) {
   return f;
 }
 
-static int g_bf3_variant = 0;  // "fused_variant" in precision mode: 0 = 1024-column window, 1 = 512
+static int g_bf3_variant = 0;  // "fused_variant" in precision mode: 0 = 512-column window, 1 = 1024
 void resblock_bf3_set_variant(int v) { g_bf3_variant = v; }
 
 bool resblock_bf3_supported(int C, int KS, const int* dil) {
@@ -341,14 +341,15 @@ int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, c
   a.dil[0] = dil[0]; a.dil[1] = dil[1]; a.dil[2] = dil[2];
   a.ld = ld; a.bstride = (long long)C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi;
   a.BN = 0; a.H4 = 0;
-  if (g_bf3_variant == 1) {
-    if (KS == 3) return launch_bf3<3, 8, 4>(a, B, Lmax, stream);
-    if (KS == 7) return launch_bf3<7, 8, 4>(a, B, Lmax, stream);
-    return launch_bf3<11, 8, 4>(a, B, Lmax, stream);
+  if (g_bf3_variant == 1) {  // 1024-column windows: less halo recompute, but one workgroup per CU
+    if (KS == 3) return launch_bf3<3, 8, 8>(a, B, Lmax, stream);
+    if (KS == 7) return launch_bf3<7, 8, 8>(a, B, Lmax, stream);
+    return launch_bf3<11, 8, 8>(a, B, Lmax, stream);
   }
-  if (KS == 3) return launch_bf3<3, 8, 8>(a, B, Lmax, stream);
-  if (KS == 7) return launch_bf3<7, 8, 8>(a, B, Lmax, stream);
-  return launch_bf3<11, 8, 8>(a, B, Lmax, stream);
+  // default: 512-column windows, two workgroups per CU overlap each other's memory phases
+  if (KS == 3) return launch_bf3<3, 8, 4>(a, B, Lmax, stream);
+  if (KS == 7) return launch_bf3<7, 8, 4>(a, B, Lmax, stream);
+  return launch_bf3<11, 8, 4>(a, B, Lmax, stream);
 }
 
 }  // namespace dissc

@@ -121,16 +121,18 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  * environment variable DISSC_OPTIONS="key=value,key=value" read by the Python binding):
  *   multistream (1)      generator: the ResBlocks of a stage run as concurrent chains on HIP streams
  *   stream_prio (1)      ... and the longer chains get higher HIP stream priority
- *   precision (0)        0 = exact fp32 MFMA everywhere (default, what bench.py reports); 1 = split-bf16
- *                        ("bf16x3": hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate) for the
- *                        layers that have such an instance -- ~2^-17 product error, waveform RMS ~4e-6
+ *   precision (0)        0 = exact fp32 MFMA everywhere (default, bench.py's headline); 1 = split-bf16 GENERATOR
+ *                        ("bf16x3": hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate; conv_bf3.hip,
+ *                        resblock_bf3.hip) -- ~2^-17 product error, waveform RMS ~4e-6 vs the reference (bar 1e-4),
+ *                        ~2x the fp32 rate.  Predictors and HuBERT feed integer decisions and always stay fp32.
  *   mfma32 (1)           use the 32x32x2 MFMA kernel for layers with >= 32 output rows
  *   conv_cfg_bm{16,32,64,128,256} / conv32_cfg_bm{32,64,128,256}
  *                        tile-shape id per GEMM-M class (tables in conv_mfma.hip / conv_mfma32.hip)
  *   lin_tile (2)         1x1 convs: 16-channel chunks staged per barrier (2 or 4)
  *   cpb2 (0)             k <= value convs stage 32 channels per barrier
  *   fused_max_c (0)      widest ResBlock run as ONE fused launch (experimental: 16 or 32)
- *   fused_variant (0)    wave/tile split of the fused C=16 kernel
+ *   fused_variant (0)    wave/tile split of the fused C=16 kernels (fp32: experimental; split-bf16: 0 = 512-column
+ *                        windows, 1 = 1024)
  *   stream16 (4)         time tiles per workgroup of the streaming 16-channel conv kernel (0 = off)
  *   attn_fused (1)       HuBERT attention as one fused kernel (0: batched GEMM -> softmax -> batched GEMM)
  *   mfast (0)            M-fastest block order for convs with many M tiles
