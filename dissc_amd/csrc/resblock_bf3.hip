@@ -15,8 +15,6 @@
 //     already split into hi/lo bf16 halves, in planes [channel octet][hi|lo][column][8 bf16], so
 //     a B fragment of v_mfma_f32_16x16x32_bf16 is one conflict-free ds_read_b128 at any tap
 //     offset, and nothing is split inside the tap loop;
-//   - K = 32 of one MFMA holds TWO taps x 16 channels (lane group g = l >> 4: tap 2jj + (g >> 1),
-//     channels 8 (g & 1) .. +7); an odd tap count is padded with a zero-weight tap;
 //   - the halo columns are recomputed and go stale inwards by p per layer; only the centre
 //     [t0, t0 + BN) is written back.  HBM traffic: one read of x, one read-modify-write of acc.
 // The reference's per-layer zero padding is reproduced by forcing every published value to 0
@@ -35,7 +33,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 struct ResblockBf3Args {
   const float* x;        // [B][C][ld]   stage input
   float* acc;            // [B][C][ld]   MRF accumulator
-  const bf16x8* wpack;   // [6 convs][NP tap pairs][hi|lo][64 lanes] x 8 bf16
+  const bf16x8* wpack;   // [6 convs][NS steps][C/16 row blocks][hi|lo][64 lanes] x 8 bf16
   const float* bias;     // [6][C]
   const int32_t* lengths;
   int len_default, len_mul;
@@ -48,21 +46,30 @@ struct ResblockBf3Args {
 
 __device__ __forceinline__ float lrelu_b(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-template <int KS, int NW, int NI>
-__global__ void __launch_bounds__(64 * NW) resblock16_bf3_kernel(const ResblockBf3Args a) {
-  constexpr int C = 16;
+// C = 16: K = 32 of one MFMA holds TWO taps x 16 channels (lane group g = l >> 4: tap 2s + (g >> 1),
+//         channels 8 (g & 1) .. +7; an odd tap count is padded with a zero-weight tap); all weight
+//         fragments of a layer live in registers.
+// C = 32, 64: K = 32 is one tap x 32 channels (step s = tap * C/32 + kb: channels 32 kb + 8g .. +7),
+//         C/16 row blocks of 16 per tile; the weight fragments are streamed from L2 one step ahead
+//         of the MFMAs that use them.
+template <int C, int KS, int NW, int NI>
+__global__ void __launch_bounds__(64 * NW) resblock_bf3_kernel(const ResblockBf3Args a) {
+  static_assert(C == 16 || C == 32 || C == 64, "narrow stages only");
+  constexpr int MI = C / 16;          // 16-row blocks
+  constexpr int OCT = C / 8;          // channel octets = LDS planes per half
   constexpr int NT = 64 * NW;
-  constexpr int NP = (KS + 1) / 2;   // tap pairs
+  constexpr int KB = (C == 16) ? 1 : C / 32;              // 32-channel blocks per tap
+  constexpr int NS = (C == 16) ? (KS + 1) / 2 : KS * KB;  // MFMA K-steps per conv
   constexpr int P2 = (KS - 1) / 2;
   constexpr int COLS = 16 * NW * NI;  // window columns owned by the workgroup
   constexpr int PAD = 32;             // >= P2 * 5 + 5: reach of the widest (padded) tap
   constexpr int XW = COLS + 2 * PAD;
-  constexpr int TB = 4;               // tiles per accumulator batch
+  constexpr int TB = NI < 4 ? NI : 4; // tiles per accumulator batch
   static_assert(NI % TB == 0, "NI must be a multiple of the tile batch");
   extern __shared__ __attribute__((aligned(16))) bf16x8 lds8[];
-  bf16x8* Ap = lds8;           // lrelu(x_k):       planes [octet][hi|lo][XW]
-  bf16x8* Tp = lds8 + 4 * XW;  // lrelu(conv1 out): same layout
-  float* S = reinterpret_cast<float*>(Tp);  // fp32 [16][XW] transpose scratch (T is dead when used)
+  bf16x8* Ap = lds8;                 // lrelu(x_k):       planes [octet][hi|lo][XW]
+  bf16x8* Tp = lds8 + 2 * OCT * XW;  // lrelu(conv1 out): same layout
+  float* S = reinterpret_cast<float*>(Tp);  // fp32 [C][XW] transpose scratch (T is dead when used)
 
   const int b = blockIdx.y;
   const int len = a.lengths ? a.lengths[b] * a.len_mul : a.len_default;
@@ -73,15 +80,20 @@ __global__ void __launch_bounds__(64 * NW) resblock16_bf3_kernel(const ResblockB
   const int l15 = lane & 15, g = lane >> 4;
   const float slope = a.slope;
   const float* xb = a.x + (size_t)b * a.bstride;
+  // fragment of (layer, step, row block, half): wl[(((layer * NS + step) * MI + mi) * 2 + half) * 64]
   const bf16x8* wl = a.wpack + lane;
 
-  bf16x8 w[NP][2];
+  // C = 16: the whole layer; C = 32: the first step of the next layer (the rest is streamed)
+  constexpr int NWR = (C == 16) ? NS : 1;
+  bf16x8 w[NWR][MI][2];
   auto load_w = [&](int layer) {
 #pragma unroll
-    for (int jj = 0; jj < NP; ++jj) {
-      w[jj][0] = wl[((layer * NP + jj) * 2 + 0) * 64];
-      w[jj][1] = wl[((layer * NP + jj) * 2 + 1) * 64];
-    }
+    for (int s = 0; s < NWR; ++s)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        w[s][mi][0] = wl[(((layer * NS + s) * MI + mi) * 2 + 0) * 64];
+        w[s][mi][1] = wl[(((layer * NS + s) * MI + mi) * 2 + 1) * 64];
+      }
   };
   load_w(0);
 
@@ -98,15 +110,15 @@ __global__ void __launch_bounds__(64 * NW) resblock16_bf3_kernel(const ResblockB
       *reinterpret_cast<f32x4*>(S + r * XW + PAD + 4 * v) = val;
     }
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int e = tid; e < 4 * 2 * PAD; e += NT) {
+    for (int e = tid; e < 2 * OCT * 2 * PAD; e += NT) {
       const int pl = e / (2 * PAD), c = e - pl * (2 * PAD);
       Ap[pl * XW + (c < PAD ? c : COLS + c)] = z;
     }
   }
   __syncthreads();
 
-  // publish 4 channels (rows 4g .. 4g+3) of column u, split into hi / lo halves
-  auto publish = [&](bf16x8* P, int u, const float (&v)[4]) {
+  // publish rows 16 mi + 4g .. +3 of column u, split into hi / lo halves
+  auto publish = [&](bf16x8* P, int mi, int u, const float (&v)[4]) {
     bf16x4 vh, vl;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -114,49 +126,86 @@ __global__ void __launch_bounds__(64 * NW) resblock16_bf3_kernel(const ResblockB
       vh[r] = h;
       vl[r] = (__bf16)(v[r] - (float)h);
     }
-    __bf16* p = reinterpret_cast<__bf16*>(P + (2 * (g >> 1)) * XW + PAD + u) + 4 * (g & 1);
+    __bf16* p = reinterpret_cast<__bf16*>(P + (2 * (2 * mi + (g >> 1))) * XW + PAD + u) + 4 * (g & 1);
     *reinterpret_cast<bf16x4*>(p) = vh;
     *reinterpret_cast<bf16x4*>(p + XW * 8) = vl;
   };
 
   const int ucol = wave * (NI * 16);
-  float xk[NI][4];
+  float xk[MI][NI][4];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int u = ucol + ni * 16 + l15;
-    float av[4];
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      xk[ni][r] = S[(4 * g + r) * XW + PAD + u];
-      av[r] = lrelu_b(xk[ni][r], slope);
+    for (int ni = 0; ni < NI; ++ni) {
+      const int u = ucol + ni * 16 + l15;
+      float av[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xk[mi][ni][r] = S[(16 * mi + 4 * g + r) * XW + PAD + u];
+        av[r] = lrelu_b(xk[mi][ni][r], slope);
+      }
+      publish(Ap, mi, u, av);
     }
-    publish(Ap, u, av);
-  }
   __syncthreads();
   {  // the scratch is consumed: zero the T pads (ordered before conv2 by the barrier after conv1)
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int e = tid; e < 4 * 2 * PAD; e += NT) {
+    for (int e = tid; e < 2 * OCT * 2 * PAD; e += NT) {
       const int pl = e / (2 * PAD), c = e - pl * (2 * PAD);
       Tp[pl * XW + (c < PAD ? c : COLS + c)] = z;
     }
   }
 
   // one conv over TB tiles starting at window column ub: acc += W (x) P[.. - p + j*d ..]
-  auto conv = [&](const bf16x8* P, int d, int ub, f32x4 (&acc)[TB]) {
-    const bf16x8* bj = P + (2 * (g & 1)) * XW + PAD + ub + l15 - P2 * d + (g >> 1) * d;
+  auto conv = [&](const bf16x8* P, int layer, int d, int ub, f32x4 (&acc)[MI][TB]) {
+    const int oct = (C == 16) ? (g & 1) : g;
+    const int toff = (C == 16) ? (g >> 1) * d : 0;
+    const bf16x8* b0 = P + (2 * oct) * XW + PAD + ub + l15 - P2 * d + toff;
 #pragma unroll
-    for (int ni = 0; ni < TB; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int jj = 0; jj < NP; ++jj) {
+      for (int ni = 0; ni < TB; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wc[MI][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      wc[mi][0] = w[0][mi][0];
+      wc[mi][1] = w[0][mi][1];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      bf16x8 wn[MI][2];
+      if constexpr (C == 16) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          wn[mi][0] = w[s + 1 < NS ? s + 1 : s][mi][0];
+          wn[mi][1] = w[s + 1 < NS ? s + 1 : s][mi][1];
+        }
+      } else if (s + 1 < NS) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          wn[mi][0] = wl[(((layer * NS + s + 1) * MI + mi) * 2 + 0) * 64];
+          wn[mi][1] = wl[(((layer * NS + s + 1) * MI + mi) * 2 + 1) * 64];
+        }
+      }
+      // C = 16: step s covers taps 2s, 2s+1; else tap s / KB, channel block s % KB (8 planes each)
+      const bf16x8* bj = (C == 16) ? b0 + 2 * s * d : b0 + (s / KB) * d + (s % KB) * (8 * XW);
 #pragma unroll
       for (int ni = 0; ni < TB; ++ni) {
         const bf16x8 bh = bj[ni * 16];
         const bf16x8 bl = bj[ni * 16 + XW];
-        acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][1], bh, acc[ni], 0, 0, 0);
-        acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][0], bl, acc[ni], 0, 0, 0);
-        acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj][0], bh, acc[ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[mi][1], bh, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[mi][0], bl, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[mi][0], bh, acc[mi][ni], 0, 0, 0);
+        }
       }
-      bj += 2 * d;
+      if (s + 1 < NS) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          wc[mi][0] = wn[mi][0];
+          wc[mi][1] = wn[mi][1];
+        }
+      }
     }
   };
 
@@ -164,13 +213,15 @@ __global__ void __launch_bounds__(64 * NW) resblock16_bf3_kernel(const ResblockB
   for (int m = 0; m < 3; ++m) {
     // ---- conv1 (dilated): A -> T ----
     {
-      float bz[4];
+      float bz[MI][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bz[r] = a.bias[(2 * m) * C + 4 * g + r];
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bz[mi][r] = a.bias[(2 * m) * C + 16 * mi + 4 * g + r];
       const int d = a.dil[m];
-      f32x4 acc[NI / TB][TB];
+      f32x4 acc[NI / TB][MI][TB];
 #pragma unroll
-      for (int tb = 0; tb < NI / TB; ++tb) conv(Ap, d, ucol + tb * (TB * 16), acc[tb]);
+      for (int tb = 0; tb < NI / TB; ++tb) conv(Ap, 2 * m, d, ucol + tb * (TB * 16), acc[tb]);
       load_w(2 * m + 1);
 #pragma unroll
       for (int tb = 0; tb < NI / TB; ++tb)
@@ -179,21 +230,26 @@ __global__ void __launch_bounds__(64 * NW) resblock16_bf3_kernel(const ResblockB
           const int u = ucol + (tb * TB + ni) * 16 + l15;
           const int t = tw0 + u;
           const bool inside = t >= 0 && t < len;
-          float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = inside ? lrelu_b(acc[tb][ni][r] + bz[r], slope) : 0.f;
-          publish(Tp, u, v);
+          for (int mi = 0; mi < MI; ++mi) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = inside ? lrelu_b(acc[tb][mi][ni][r] + bz[mi][r], slope) : 0.f;
+            publish(Tp, mi, u, v);
+          }
         }
     }
     __syncthreads();
     // ---- conv2 (dilation 1): T -> x_k += ..., publish lrelu(x_k) to A ----
     {
-      float bz[4];
+      float bz[MI][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bz[r] = a.bias[(2 * m + 1) * C + 4 * g + r];
-      f32x4 acc[NI / TB][TB];
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int tb = 0; tb < NI / TB; ++tb) conv(Tp, 1, ucol + tb * (TB * 16), acc[tb]);
+        for (int r = 0; r < 4; ++r) bz[mi][r] = a.bias[(2 * m + 1) * C + 16 * mi + 4 * g + r];
+      f32x4 acc[NI / TB][MI][TB];
+#pragma unroll
+      for (int tb = 0; tb < NI / TB; ++tb) conv(Tp, 2 * m + 1, 1, ucol + tb * (TB * 16), acc[tb]);
       if (m < 2) load_w(2 * m + 2);
 #pragma unroll
       for (int tb = 0; tb < NI / TB; ++tb)
@@ -203,13 +259,16 @@ __global__ void __launch_bounds__(64 * NW) resblock16_bf3_kernel(const ResblockB
           const int u = ucol + nn * 16 + l15;
           const int t = tw0 + u;
           const bool inside = t >= 0 && t < len;
-          float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            xk[nn][r] = inside ? xk[nn][r] + (acc[tb][ni][r] + bz[r]) : 0.f;
-            v[r] = lrelu_b(xk[nn][r], slope);
+          for (int mi = 0; mi < MI; ++mi) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              xk[mi][nn][r] = inside ? xk[mi][nn][r] + (acc[tb][mi][ni][r] + bz[mi][r]) : 0.f;
+              v[r] = lrelu_b(xk[mi][nn][r], slope);
+            }
+            if (m < 2) publish(Ap, mi, u, v);
           }
-          if (m < 2) publish(Ap, u, v);
         }
     }
     __syncthreads();
@@ -217,11 +276,13 @@ __global__ void __launch_bounds__(64 * NW) resblock16_bf3_kernel(const ResblockB
 
   // ---- x_k -> scratch -> MRF update of the centre columns, 16 B per lane ----
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int u = ucol + ni * 16 + l15;
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S[(4 * g + r) * XW + PAD + u] = xk[ni][r];
-  }
+    for (int ni = 0; ni < NI; ++ni) {
+      const int u = ucol + ni * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[(16 * mi + 4 * g + r) * XW + PAD + u] = xk[mi][ni][r];
+    }
   __syncthreads();
   {
     const int nv = a.BN >> 2;
@@ -277,7 +338,10 @@ static int g_bf3_variant = 0;  // "fused_variant" in precision mode: 0 = 512-col
 void resblock_bf3_set_variant(int v) { g_bf3_variant = v; }
 
 bool resblock_bf3_supported(int C, int KS, const int* dil) {
-  if (C != 16) return false;
+  if (C != 16 && C != 32 && C != 64) return false;
+  // (C = 64 leaves room for 256-column windows only; with 11 taps the halo is 120 of them and the
+  // fused block alone is slower than its six layers, 3.2 vs 2.6 ms -- but it moves 5x fewer bytes,
+  // and with the three ResBlock chains of a stage running concurrently the stage is faster fused.)
   if (KS != 3 && KS != 7 && KS != 11) return false;
   for (int m = 0; m < 3; ++m)
     if (dil[m] < 1 || dil[m] > 5) return false;
@@ -285,44 +349,49 @@ bool resblock_bf3_supported(int C, int KS, const int* dil) {
 }
 
 // w6: the six conv weights [C][C][KS] in execution order (c1_0, c2_0, c1_1, c2_1, c1_2, c2_2).
-// packed (as raw 32-bit words): [6][NP][hi|lo][64 lanes][8 bf16]
+// packed (as raw 32-bit words): [6][NS steps][C/16 row blocks][hi|lo][64 lanes][8 bf16]; lane l of
+// row block mi holds row 16 mi + (l & 15) and, with g = l >> 4,
+//   C = 16: tap 2s + (g >> 1), channels 8 (g & 1) + e      else: tap s / (C/32), channels 32 (s % (C/32)) + 8g + e
 void pack_resblock_bf3(int C, int KS, const float* const* w6, std::vector<float>& packed) {
-  const int NP = (KS + 1) / 2;
-  packed.assign((size_t)6 * NP * 2 * 64 * 4, 0.f);
+  const int MI = C / 16;
+  const int KB = (C == 16) ? 1 : C / 32;
+  const int NS = (C == 16) ? (KS + 1) / 2 : KS * KB;
+  packed.assign((size_t)6 * NS * MI * 2 * 64 * 4, 0.f);
   uint16_t* p16 = reinterpret_cast<uint16_t*>(packed.data());
   for (int l = 0; l < 6; ++l)
-    for (int jj = 0; jj < NP; ++jj)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int co = lane & 15, gq = lane >> 4;
-        const int tap = 2 * jj + (gq >> 1);
-        for (int e = 0; e < 8; ++e) {
-          const int ci = 8 * (gq & 1) + e;
-          const float v = tap < KS ? w6[l][((size_t)co * C + ci) * KS + tap] : 0.f;
-          const uint16_t hi = bf16_rne_host(v);
-          const uint16_t lo = bf16_rne_host(v - bf16_to_f32_host(hi));
-          const size_t slot = (((size_t)l * NP + jj) * 2) * 64 + lane;
-          p16[slot * 8 + e] = hi;
-          p16[(slot + 64) * 8 + e] = lo;
+    for (int s = 0; s < NS; ++s)
+      for (int mi = 0; mi < MI; ++mi)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int co = 16 * mi + (lane & 15), gq = lane >> 4;
+          const int tap = (C == 16) ? 2 * s + (gq >> 1) : s / KB;
+          for (int e = 0; e < 8; ++e) {
+            const int ci = (C == 16) ? 8 * (gq & 1) + e : 32 * (s % KB) + 8 * gq + e;
+            const float v = tap < KS ? w6[l][((size_t)co * C + ci) * KS + tap] : 0.f;
+            const uint16_t hi = bf16_rne_host(v);
+            const uint16_t lo = bf16_rne_host(v - bf16_to_f32_host(hi));
+            const size_t slot = ((((size_t)l * NS + s) * MI + mi) * 2) * 64 + lane;
+            p16[slot * 8 + e] = hi;
+            p16[(slot + 64) * 8 + e] = lo;
+          }
         }
-      }
 }
 
-template <int KS, int NW, int NI>
+template <int C, int KS, int NW, int NI>
 static int launch_bf3(ResblockBf3Args a, int B, int Lmax, hipStream_t stream) {
   constexpr int COLS = 16 * NW * NI, XW = COLS + 64;
   const int P2 = (KS - 1) / 2;
   const int H = P2 * (a.dil[0] + a.dil[1] + a.dil[2] + 3);
   a.H4 = (H + 3) & ~3;
   a.BN = COLS - 2 * a.H4;
-  const size_t lds = (size_t)8 * XW * 16;
+  const size_t lds = (size_t)4 * (C / 8) * XW * 16;
   static bool attr_done = false;
   if (!attr_done) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock16_bf3_kernel<KS, NW, NI>),
+    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bf3_kernel<C, KS, NW, NI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   dim3 grid((Lmax + a.BN - 1) / a.BN, B);
-  hipLaunchKernelGGL((resblock16_bf3_kernel<KS, NW, NI>), grid, dim3(64 * NW), lds, stream, a);
+  hipLaunchKernelGGL((resblock_bf3_kernel<C, KS, NW, NI>), grid, dim3(64 * NW), lds, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
@@ -341,15 +410,25 @@ int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, c
   a.dil[0] = dil[0]; a.dil[1] = dil[1]; a.dil[2] = dil[2];
   a.ld = ld; a.bstride = (long long)C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi;
   a.BN = 0; a.H4 = 0;
+  if (C == 64) {  // 256-column windows fill the CU's 160 KB of LDS
+    if (KS == 3) return launch_bf3<64, 3, 8, 2>(a, B, Lmax, stream);
+    if (KS == 7) return launch_bf3<64, 7, 8, 2>(a, B, Lmax, stream);
+    return launch_bf3<64, 11, 8, 2>(a, B, Lmax, stream);
+  }
+  if (C == 32) {  // 512-column windows (145 KB of LDS): one workgroup of 8 waves per CU
+    if (KS == 3) return launch_bf3<32, 3, 8, 4>(a, B, Lmax, stream);
+    if (KS == 7) return launch_bf3<32, 7, 8, 4>(a, B, Lmax, stream);
+    return launch_bf3<32, 11, 8, 4>(a, B, Lmax, stream);
+  }
   if (g_bf3_variant == 1) {  // 1024-column windows: less halo recompute, but one workgroup per CU
-    if (KS == 3) return launch_bf3<3, 8, 8>(a, B, Lmax, stream);
-    if (KS == 7) return launch_bf3<7, 8, 8>(a, B, Lmax, stream);
-    return launch_bf3<11, 8, 8>(a, B, Lmax, stream);
+    if (KS == 3) return launch_bf3<16, 3, 8, 8>(a, B, Lmax, stream);
+    if (KS == 7) return launch_bf3<16, 7, 8, 8>(a, B, Lmax, stream);
+    return launch_bf3<16, 11, 8, 8>(a, B, Lmax, stream);
   }
   // default: 512-column windows, two workgroups per CU overlap each other's memory phases
-  if (KS == 3) return launch_bf3<3, 8, 4>(a, B, Lmax, stream);
-  if (KS == 7) return launch_bf3<7, 8, 4>(a, B, Lmax, stream);
-  return launch_bf3<11, 8, 4>(a, B, Lmax, stream);
+  if (KS == 3) return launch_bf3<16, 3, 8, 4>(a, B, Lmax, stream);
+  if (KS == 7) return launch_bf3<16, 7, 8, 4>(a, B, Lmax, stream);
+  return launch_bf3<16, 11, 8, 4>(a, B, Lmax, stream);
 }
 
 }  // namespace dissc
