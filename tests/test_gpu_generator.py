@@ -226,3 +226,24 @@ def test_split_bf16_precision_option_is_within_north_star_tolerance(golden_dir):
     for row in rows:
         rms, ref_rms = float(row[2]), float(row[6])
         assert rms <= 2e-5 and rms <= 1e-4 * ref_rms * 10  # measured ~4e-6 (fp32 path: ~4e-7)
+    # the same utterances as one ragged batch: bitwise the B=1 waveforms, silence after each end
+    ragged = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("ragged")]
+    assert len(ragged) == 4
+    for row in ragged:
+        assert row[3] == "1" and float(row[5]) == 0.0, row
+
+
+def test_precision_option_leaves_predictors_and_units_exact():
+    """precision=1 is a generator-only mode: durations, f0 and unit indices feed integer decisions
+    and must stay on the exact fp32 kernels (the predictor/HuBERT parity tests pass unchanged)."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DISSC_OPTIONS="precision=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                        os.path.join(root, "tests", "test_gpu_predictors.py"),
+                        os.path.join(root, "tests", "test_gpu_hubert.py")],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
