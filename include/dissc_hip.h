@@ -175,6 +175,13 @@ int dissc_pitch_forward(dissc_pred_t p, const int64_t* seq, const int64_t* spk,
                         const int32_t* lengths, int B, int Tmax, int norm, const float* id2mean,
                         const float* id2std, float* out, int ldo, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* Per-speaker F0 statistics over VOICED (non-zero) frames, fp64 (replaces reference
+ * data/data_utils.py:33-46 calculate_pitch_stats, the step between data/encode.py and infer.py).
+ * f0 f64 [offsets[n_speakers]]: the frames grouped by speaker, speaker s = [offsets[s], offsets[s+1]);
+ * -> mean, std (population, ddof = 0) f64 [n_speakers], count of voiced frames i64 [n_speakers].
+ * A speaker without voiced frames yields NaN like numpy.  Deterministic (fixed reduction tree). */
+int dissc_pitch_stats(const double* f0, const int64_t* offsets, int n_speakers, double* mean_out,
+                      double* std_out, int64_t* count_out, void* stream);
 /* run-length encode: units i64 [B,Tmax] -> vals i64 [B,Tmax], counts i32 [B,Tmax], n i32 [B] */
 int dissc_dedup(const int64_t* units, const int32_t* lengths, int B, int Tmax, int64_t* vals,
                 int32_t* counts, int32_t* n_out, void* stream);

@@ -357,8 +357,57 @@ def make_hubert():
     print("hubert.npz", {k: v.shape for k, v in out.items() if k.endswith("units")})
 
 
+def synth_units_jsonl(seed=7, n_spk=5, utts_per_spk=6):
+    """Encoded-dataset lines the way data/encode.py writes them: f0 in Hz as float32 values,
+    exact 0.0 on unvoiced frames; one speaker is entirely unvoiced in one utterance."""
+    rs = np.random.RandomState(seed)
+    lines = []
+    for s in range(n_spk):
+        base = 90.0 + 35.0 * s
+        for u in range(utts_per_spk):
+            T = int(rs.randint(20, 60))
+            f0 = (base + 20.0 * rs.randn(T)).astype(np.float32)
+            f0[rs.rand(T) < 0.35] = 0.0
+            if s == 1 and u == 0:
+                f0[:] = 0.0
+            units = rs.randint(0, 100, size=T)
+            lines.append(json.dumps({"units": units.tolist(), "f0": f0.tolist(), "durations": [1] * T,
+                                     "audio": f"sp{s:02d}_{u + 20}.wav"}))
+    order = rs.permutation(len(lines))  # speakers interleaved, like os.listdir order
+    return [lines[i] for i in order]
+
+
+def make_prep_dataset():
+    """reference data/data_utils.py calculate_pitch_stats + data_split on a synthetic encoded set."""
+    import pickle
+    import tempfile
+    sys.path.insert(0, os.path.join(REF, "data"))
+    import data_utils as ref_du
+    lines = synth_units_jsonl()
+    with open(os.path.join(HERE, "prep_units.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        man = os.path.join(td, "all.txt")
+        with open(man, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        ref_du.calculate_pitch_stats(man, os.path.join(td, "stats.pkl"))
+        stats = pickle.load(open(os.path.join(td, "stats.pkl"), "rb"))
+        np.random.seed(42)
+        tr, va = ref_du.data_split(man, "random")
+        out["random"] = (open(tr).read(), open(va).read())
+        tr, va = ref_du.data_split(man, "paired_val")
+        out["paired_val"] = (open(tr).read(), open(va).read())
+    with open(os.path.join(HERE, "prep_expected.pkl"), "wb") as f:
+        pickle.dump({"stats": {k: {"mean": float(v["mean"]), "std": float(v["std"])} for k, v in stats.items()},
+                     "split": out}, f)
+    print("prep_expected.pkl", {k: (round(v["mean"], 3), round(v["std"], 3)) for k, v in stats.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["generator", "predictors", "sr_inference", "hubert"]
+    which = sys.argv[1:] or ["generator", "predictors", "sr_inference", "hubert", "prep_dataset"]
+    if "prep_dataset" in which:
+        make_prep_dataset()
     if "hubert" in which:
         make_hubert()
     if "sr_inference" in which:
