@@ -23,7 +23,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 MFMA)
+HBM_PEAK_GBPS = 8000.0         # same guide: HBM3E ~8 TB/s
 
 
 def cpu_baseline(synth, sd, code, f0, spkr, budget_s=12.0, max_utts=400):
@@ -236,6 +237,11 @@ def main():
                          "kernel": "conv_mfma32_kernel family (all generator convs; fp32 v_mfma_f32_32x32x2, 16x16x4 on the 16-channel stage)",
                          "flops_per_step": flops_step, "kernel_ms_per_step": round(kern_s * 1e3, 3)},
         }
+        traffic = out["roofline"]["traffic"]
+        if traffic:  # north_star also asks for the fraction of the HBM roofline (the path is compute-bound)
+            gbps = traffic / kern_s / 1e9
+            out["roofline"]["hbm"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                      "frac": round(gbps / HBM_PEAK_GBPS, 4)}
         if not a.no_split_bf16 and n_gpus == 1 and not fake:
             out["split_bf16"] = split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y, a.steps,
                                                audio_sec_per_step)
