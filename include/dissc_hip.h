@@ -119,7 +119,8 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
 
 /* Tuning hook (process-wide; set before the handles are created; also reachable through the
  * environment variable DISSC_OPTIONS="key=value,key=value" read by the Python binding):
- *   multistream (1)      generator: the ResBlocks of a stage run as concurrent chains on HIP streams
+ *   multistream (1)      generator: the ResBlocks of a stage run as concurrent chains on HIP streams (two side
+ *                        streams per device, shared by all generator handles of the process)
  *   stream_prio (1)      ... and the longer chains get higher HIP stream priority
  *   precision (0)        0 = exact fp32 MFMA everywhere (default, bench.py's headline); 1 = split-bf16 GENERATOR
  *                        ("bf16x3": hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate; conv_bf3.hip,
