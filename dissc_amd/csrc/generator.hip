@@ -35,6 +35,7 @@ using namespace dissc;
 
 static int g_stream_prio = 1;  // "stream_prio" option: prioritise the longer ResBlock chains
 static int g_multistream = 1;  // "multistream" option: concurrent ResBlock chains (read at create)
+static int g_par_ups = 1;      // "par_ups" option: ConvTranspose phase groups on concurrent streams
 
 // The side streams of the concurrent ResBlock chains are shared by every generator handle of a
 // device (created on first use, kept for the life of the process): HIP multiplexes streams onto a
@@ -369,10 +370,22 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
     const int ch_out = ch / 2, mul_out = mul * s;
     const int ld_out = (int)round_up((size_t)Tmax * mul_out, 4);
     // lrelu(0.1) -> ConvTranspose: ACC [B,ch,ld] -> X [B,ch_out,ld_out]
-    for (auto& grp : g->ups[i])
-      if ((rc = run_conv(grp, ACC, X, nullptr, nullptr, lengths, Tmax * mul, mul, B, ch, ld, ld_out,
-                         Tmax * mul, 0.1f, EPI_STORE, 1.f, stream)))
+    // (phase groups write disjoint output phases: with side streams they run concurrently, which
+    // fills the CUs better than two or three small grids one after the other)
+    const int ngrp = (int)g->ups[i].size();
+    const bool par_ups = multi && g_par_ups && ngrp > 1 && ngrp <= nk;
+    if (par_ups) DISSC_HIP_CHECK(hipEventRecord(g->ev_x, stream));  // ACC is complete
+    for (int gi = 0; gi < ngrp; ++gi) {
+      hipStream_t sg = (par_ups && gi > 0) ? g->aux[gi] : stream;
+      if (par_ups && gi > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sg, g->ev_x, 0));
+      if ((rc = run_conv(g->ups[i][gi], ACC, X, nullptr, nullptr, lengths, Tmax * mul, mul, B, ch, ld,
+                         ld_out, Tmax * mul, 0.1f, EPI_STORE, 1.f, sg)))
         return rc;
+      if (par_ups && gi > 0) {
+        DISSC_HIP_CHECK(hipEventRecord(g->ev_fin[gi], sg));
+        DISSC_HIP_CHECK(hipStreamWaitEvent(stream, g->ev_fin[gi], 0));
+      }
+    }
     ch = ch_out; mul = mul_out; ld = ld_out;
     const int L = Tmax * mul;
     if (multi) DISSC_HIP_CHECK(hipEventRecord(g->ev_x, stream));  // X is ready
@@ -485,6 +498,7 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "fused_bn16") == 0) { fused_set_option(0, value); return DISSC_OK; }
   if (strcmp(key, "fused_bn32") == 0) { fused_set_option(1, value); return DISSC_OK; }
   if (strcmp(key, "precision") == 0) { g_precision = value; return DISSC_OK; }
+  if (strcmp(key, "par_ups") == 0) { g_par_ups = value; return DISSC_OK; }
   if (strcmp(key, "stream_prio") == 0) { g_stream_prio = value; return DISSC_OK; }
   if (strcmp(key, "multistream") == 0) { g_multistream = value; return DISSC_OK; }
   if (strcmp(key, "stream16") == 0) { g_stream16 = value; return DISSC_OK; }

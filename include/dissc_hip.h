@@ -122,6 +122,7 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   multistream (1)      generator: the ResBlocks of a stage run as concurrent chains on HIP streams (two side
  *                        streams per device, shared by all generator handles of the process)
  *   stream_prio (1)      ... and the longer chains get higher HIP stream priority
+ *   par_ups (1)          ... and the phase groups of a ConvTranspose layer run concurrently on the same streams
  *   precision (0)        0 = exact fp32 MFMA everywhere (default, bench.py's headline); 1 = split-bf16 GENERATOR
  *                        ("bf16x3": hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate; conv_bf3.hip,
  *                        resblock_bf3.hip) -- ~2^-17 product error, waveform RMS ~4e-6 vs the reference (bar 1e-4),
