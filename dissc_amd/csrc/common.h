@@ -166,10 +166,13 @@ int launch_resblock_fused(int C, const float* x, float* acc, const float* wpack,
 bool resblock_bf3_supported(int C, int KS, const int* dil);
 void resblock_bf3_set_variant(int v);
 void pack_resblock_bf3(int C, int KS, const float* const* w6, std::vector<float>& packed);
+// residual pairs [m0, m1) of the block; epi = EPI_STORE writes x_k to `acc` (a partial block)
 int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, const float* bias,
                         const int32_t* lengths, int len_default, int len_mul, int KS, const int* dil,
-                        int B, int Lmax, int ld, float slope, int epi, float mrf_div,
+                        int B, int Lmax, int ld, float slope, int epi, float mrf_div, int m0, int m1,
                         hipStream_t stream);
+bool resblock_bf3_pairs(int C);  // run the block as three pair launches (wide halos, little LDS)
+void resblock_bf3_set_pairs(int v);
 
 // misc kernels (gen_misc.hip)
 void launch_embed_concat(const int64_t* code, const float* f0, const int64_t* spkr,

@@ -395,12 +395,28 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
       if (g->fused_w[(size_t)i * nk + j]) {  // narrow stage: the whole ResBlock in one launch
         const int epi = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET)
                                  : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
-        if (multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));
-        auto* fused = g->fused_bf3[(size_t)i * nk + j] ? &launch_resblock_bf3 : &launch_resblock_fused;
-        if ((rc = fused(ch, X, ACC, g->fused_w[(size_t)i * nk + j], g->fused_b[(size_t)i * nk + j],
-                        lengths, L, mul, c.resblock_kernel_sizes[j], c.resblock_dilations[j], B, L, ld,
-                        0.1f, epi, (float)nk, sj)))
-          return rc;
+        const bool pairs = g->fused_bf3[(size_t)i * nk + j] && resblock_bf3_pairs(ch);
+        // the MRF update is inside the launch: a whole-block launch has to wait for the previous chain
+        if (multi && j > 0 && !pairs) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));
+        const float* fw = g->fused_w[(size_t)i * nk + j];
+        const float* fb = g->fused_b[(size_t)i * nk + j];
+        const int rk = c.resblock_kernel_sizes[j];
+        const int* dl = c.resblock_dilations[j];
+        if (!g->fused_bf3[(size_t)i * nk + j]) {
+          rc = launch_resblock_fused(ch, X, ACC, fw, fb, lengths, L, mul, rk, dl, B, L, ld, 0.1f, epi, (float)nk, sj);
+        } else if (!pairs) {
+          rc = launch_resblock_bf3(ch, X, ACC, fw, fb, lengths, L, mul, rk, dl, B, L, ld, 0.1f, epi, (float)nk, 0, 3, sj);
+        } else {  // X -> XK -> TMP -> MRF update of ACC, one launch per residual pair
+          float* xk = multi ? XKj[j] : XKj[0];
+          float* tm = multi ? TMPj[j] : TMPj[0];
+          rc = launch_resblock_bf3(ch, X, xk, fw, fb, lengths, L, mul, rk, dl, B, L, ld, 0.1f, EPI_STORE, 1.f, 0, 1, sj);
+          if (!rc)
+            rc = launch_resblock_bf3(ch, xk, tm, fw, fb, lengths, L, mul, rk, dl, B, L, ld, 0.1f, EPI_STORE, 1.f, 1, 2, sj);
+          if (!rc && multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));  // only the last pair
+          if (!rc)
+            rc = launch_resblock_bf3(ch, tm, ACC, fw, fb, lengths, L, mul, rk, dl, B, L, ld, 0.1f, epi, (float)nk, 2, 3, sj);
+        }
+        if (rc) return rc;
         if (multi) DISSC_HIP_CHECK(hipEventRecord(g->ev_fin[j], sj));
         continue;
       }
@@ -499,6 +515,7 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "fused_bn32") == 0) { fused_set_option(1, value); return DISSC_OK; }
   if (strcmp(key, "precision") == 0) { g_precision = value; return DISSC_OK; }
   if (strcmp(key, "par_ups") == 0) { g_par_ups = value; return DISSC_OK; }
+  if (strcmp(key, "bf3_pairs") == 0) { resblock_bf3_set_pairs(value); return DISSC_OK; }
   if (strcmp(key, "stream_prio") == 0) { g_stream_prio = value; return DISSC_OK; }
   if (strcmp(key, "multistream") == 0) { g_multistream = value; return DISSC_OK; }
   if (strcmp(key, "stream16") == 0) { g_stream16 = value; return DISSC_OK; }

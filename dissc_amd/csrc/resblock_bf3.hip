@@ -41,7 +41,8 @@ struct ResblockBf3Args {
   int BN, H4, ld;        // centre width, halo rounded up to 4, row stride
   long long bstride;
   float slope, mrf_div;
-  int epi;               // EPI_MRF_SET / EPI_MRF_ADD / EPI_MRF_DIV
+  int epi;               // EPI_MRF_SET / EPI_MRF_ADD / EPI_MRF_DIV, or EPI_STORE: acc = x_k (a partial block)
+  int m0, m1;            // residual pairs [m0, m1) of the block's three run in this launch
 };
 
 __device__ __forceinline__ float lrelu_b(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_bf3_kernel(const ResblockBf3
         w[s][mi][1] = wl[(((layer * NS + s) * MI + mi) * 2 + 1) * 64];
       }
   };
-  load_w(0);
+  load_w(2 * a.m0);
 
   // ---- window -> scratch (coalesced 16 B per lane), zero the A pads ----
   {
@@ -210,7 +211,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_bf3_kernel(const ResblockBf3
   };
 
 #pragma unroll 1
-  for (int m = 0; m < 3; ++m) {
+  for (int m = a.m0; m < a.m1; ++m) {
     // ---- conv1 (dilated): A -> T ----
     {
       float bz[MI][4];
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_bf3_kernel(const ResblockBf3
       f32x4 acc[NI / TB][MI][TB];
 #pragma unroll
       for (int tb = 0; tb < NI / TB; ++tb) conv(Tp, 2 * m + 1, 1, ucol + tb * (TB * 16), acc[tb]);
-      if (m < 2) load_w(2 * m + 2);
+      if (m + 1 < a.m1) load_w(2 * m + 2);
 #pragma unroll
       for (int tb = 0; tb < NI / TB; ++tb)
 #pragma unroll
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_bf3_kernel(const ResblockBf3
               xk[mi][nn][r] = inside ? xk[mi][nn][r] + (acc[tb][mi][ni][r] + bz[mi][r]) : 0.f;
               v[r] = lrelu_b(xk[mi][nn][r], slope);
             }
-            if (m < 2) publish(Ap, mi, u, v);
+            if (m + 1 < a.m1) publish(Ap, mi, u, v);
           }
         }
     }
@@ -286,6 +287,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_bf3_kernel(const ResblockBf3
   __syncthreads();
   {
     const int nv = a.BN >> 2;
+    const bool rmw = a.epi == EPI_MRF_ADD || a.epi == EPI_MRF_DIV;
     float* ab = a.acc + (size_t)b * a.bstride;
     for (int e = tid; e < C * nv; e += NT) {
       const int r = e / nv, v4 = e - r * nv;
@@ -295,7 +297,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_bf3_kernel(const ResblockBf3
       float* dst = ab + (size_t)r * a.ld + t;
       const int nval = len - t;
       if (nval >= 4) {
-        if (a.epi != EPI_MRF_SET) {
+        if (rmw) {
           const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
           v[0] = o[0] + v[0]; v[1] = o[1] + v[1]; v[2] = o[2] + v[2]; v[3] = o[3] + v[3];
           if (a.epi == EPI_MRF_DIV) {
@@ -307,7 +309,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_bf3_kernel(const ResblockBf3
       } else {
         for (int k = 0; k < nval; ++k) {
           float x = v[k];
-          if (a.epi != EPI_MRF_SET) {
+          if (rmw) {
             x = dst[k] + x;
             if (a.epi == EPI_MRF_DIV) x = __fdiv_rn(x, a.mrf_div);
           }
@@ -336,6 +338,13 @@ static inline float bf16_to_f32_host(uint16_t h) {
 
 static int g_bf3_variant = 0;  // "fused_variant" in precision mode: 0 = 512-column window, 1 = 1024
 void resblock_bf3_set_variant(int v) { g_bf3_variant = v; }
+
+static int g_bf3_pairs = -1;  // "bf3_pairs": -1 = by channel count (below), 0 = whole blocks, 1 = always pairs
+void resblock_bf3_set_pairs(int v) { g_bf3_pairs = v; }
+// One launch per residual pair instead of per block?  With 64 channels the LDS holds 256-column
+// windows only, and the 120-column halo of a whole 11-tap block would be recomputed ~2x; a pair's
+// halo is 10-30 columns, at the price of two more read+write passes of x_k per block.
+bool resblock_bf3_pairs(int C) { return g_bf3_pairs < 0 ? C >= 64 : g_bf3_pairs != 0; }
 
 bool resblock_bf3_supported(int C, int KS, const int* dil) {
   if (C != 16 && C != 32 && C != 64) return false;
@@ -380,7 +389,8 @@ template <int C, int KS, int NW, int NI>
 static int launch_bf3(ResblockBf3Args a, int B, int Lmax, hipStream_t stream) {
   constexpr int COLS = 16 * NW * NI, XW = COLS + 64;
   const int P2 = (KS - 1) / 2;
-  const int H = P2 * (a.dil[0] + a.dil[1] + a.dil[2] + 3);
+  int H = 0;
+  for (int m = a.m0; m < a.m1; ++m) H += P2 * (a.dil[m] + 1);
   a.H4 = (H + 3) & ~3;
   a.BN = COLS - 2 * a.H4;
   const size_t lds = (size_t)4 * (C / 8) * XW * 16;
@@ -398,9 +408,9 @@ static int launch_bf3(ResblockBf3Args a, int B, int Lmax, hipStream_t stream) {
 
 int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, const float* bias,
                         const int32_t* lengths, int len_default, int len_mul, int KS, const int* dil,
-                        int B, int Lmax, int ld, float slope, int epi, float mrf_div,
+                        int B, int Lmax, int ld, float slope, int epi, float mrf_div, int m0, int m1,
                         hipStream_t stream) {
-  if (!resblock_bf3_supported(C, KS, dil)) {
+  if (!resblock_bf3_supported(C, KS, dil) || m0 < 0 || m1 > 3 || m0 >= m1) {
     set_error("launch_resblock_bf3: C=%d k=%d unsupported", C, KS);
     return DISSC_EINVAL;
   }
@@ -409,7 +419,7 @@ int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, c
   a.len_default = len_default; a.len_mul = len_mul;
   a.dil[0] = dil[0]; a.dil[1] = dil[1]; a.dil[2] = dil[2];
   a.ld = ld; a.bstride = (long long)C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi;
-  a.BN = 0; a.H4 = 0;
+  a.BN = 0; a.H4 = 0; a.m0 = m0; a.m1 = m1;
   if (C == 64) {  // 256-column windows fill the CU's 160 KB of LDS
     if (KS == 3) return launch_bf3<64, 3, 8, 2>(a, B, Lmax, stream);
     if (KS == 7) return launch_bf3<64, 7, 8, 2>(a, B, Lmax, stream);

@@ -133,6 +133,8 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   lin_tile (2)         1x1 convs: 16-channel chunks staged per barrier (2 or 4)
  *   cpb2 (0)             k <= value convs stage 32 channels per barrier
  *   fused_max_c (0)      widest ResBlock run as ONE fused launch (experimental: 16 or 32)
+ *   bf3_pairs (-1)       split-bf16 fused ResBlocks as three launches of one residual pair each: -1 = for >= 64
+ *                        channels only, 0 = never, 1 = always
  *   fused_variant (0)    wave/tile split of the fused C=16 kernels (fp32: experimental; split-bf16: 0 = 512-column
  *                        windows, 1 = 1024)
  *   stream16 (4)         time tiles per workgroup of the streaming 16-channel conv kernel (0 = off)
