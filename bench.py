@@ -87,17 +87,13 @@ def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_se
     batch right after the fp32 run and checked against the fp32 waveform (north_star bar: 1e-4 RMS).
     Reported next to the headline number, never instead of it."""
     import dissc_amd
-    dissc_amd._lib.check(dissc_amd.lib.dissc_set_option(b"precision", 1), "set_option")
-    try:
-        g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to(dev)  # the option is read at create
-        g.load_state_dict(sd)
-        g.eval()
-        g.remove_weight_norm()
-        for _ in range(2):  # the handle is built (and the option read) on the first forward
-            y = g(code=d_code, f0=d_f0, spkr=d_spkr)
-        torch.cuda.synchronize()
-    finally:
-        dissc_amd.lib.dissc_set_option(b"precision", 0)
+    g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG, precision="split_bf16").to(dev)
+    g.load_state_dict(sd)
+    g.eval()
+    g.remove_weight_norm()
+    for _ in range(2):
+        y = g(code=d_code, f0=d_f0, spkr=d_spkr)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         y = g(code=d_code, f0=d_f0, spkr=d_spkr)
@@ -105,7 +101,7 @@ def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_se
     dt = (time.perf_counter() - t0) / steps
     err = (y - y_fp32).double()
     return {"arithmetic": "bf16 hi/lo operand split, 3 bf16 MFMAs per product, fp32 accumulate "
-                          "(dissc_set_option('precision', 1); default is exact fp32)",
+                          "(CodeGenerator(h, precision='split_bf16') / dissc_set_option('precision', 1); default is exact fp32)",
             "ms_per_step": round(dt * 1e3, 3), "value": round(audio_sec_per_step / dt, 1),
             "unit": "audio-sec/sec", "rms_vs_fp32": float(err.pow(2).mean().sqrt()),
             "max_abs_vs_fp32": float(err.abs().max()), "tolerance_rms": 1e-4}

@@ -502,6 +502,16 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
   return rc;
 }
 
+int dissc_get_option(const char* key, int* value) {
+  if (!key || !value) return DISSC_EINVAL;
+  if (strcmp(key, "precision") == 0) { *value = g_precision; return DISSC_OK; }
+  if (strcmp(key, "multistream") == 0) { *value = g_multistream; return DISSC_OK; }
+  if (strcmp(key, "stream_prio") == 0) { *value = g_stream_prio; return DISSC_OK; }
+  if (strcmp(key, "par_ups") == 0) { *value = g_par_ups; return DISSC_OK; }
+  set_error("dissc_get_option: '%s' cannot be read back", key);
+  return DISSC_EINVAL;
+}
+
 int dissc_set_option(const char* key, int value) {
   if (!key) return DISSC_EINVAL;
   if (strncmp(key, "conv_cfg_bm", 11) == 0) {  // "conv_cfg_bm16|32|64|128|256" -> tile config id

@@ -37,7 +37,15 @@ class CodeGenerator:
 
     _UNSUPPORTED = ("lambda_commit", "lambda_commit_code", "f0_quantizer_path")
 
-    def __init__(self, h):
+    _PRECISIONS = {"fp32": 0, "split_bf16": 1}
+
+    def __init__(self, h, precision=None):
+        """h: the vocoder config (reference sr/configs/*.json).  precision (not in the reference):
+        None = the process-wide "precision" option (default exact fp32), "fp32", or "split_bf16"
+        (bf16 matrix cores with hi/lo operand split and fp32 accumulation, waveform RMS ~4e-6)."""
+        if precision is not None and precision not in self._PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self._PRECISIONS)} or None")
+        self.precision = precision
         self.h = AttrDict(h)
         for k in self._UNSUPPORTED:
             if self.h.get(k, None):
@@ -153,8 +161,16 @@ class CodeGenerator:
             cfg = self._config()
             table, keep = _lib.make_tensor_table(self._folded)
             hnd = ctypes.c_void_p()
-            check(lib.dissc_gen_create(ctypes.byref(cfg), table, len(keep), ctypes.byref(hnd)),
-                  "dissc_gen_create")
+            saved = ctypes.c_int(0)
+            if self.precision is not None:  # the library reads the option when the handle is built
+                check(lib.dissc_get_option(b"precision", ctypes.byref(saved)), "dissc_get_option")
+                check(lib.dissc_set_option(b"precision", self._PRECISIONS[self.precision]), "dissc_set_option")
+            try:
+                check(lib.dissc_gen_create(ctypes.byref(cfg), table, len(keep), ctypes.byref(hnd)),
+                      "dissc_gen_create")
+            finally:
+                if self.precision is not None:
+                    lib.dissc_set_option(b"precision", saved.value)
             self._handle = hnd
             self.hop = lib.dissc_gen_hop(hnd)
 

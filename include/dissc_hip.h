@@ -142,6 +142,9 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   mfast (0)            M-fastest block order for convs with many M tiles
  * Unknown keys return DISSC_EINVAL. */
 int dissc_set_option(const char* key, int value);
+/* Read back one of: precision, multistream, stream_prio, par_ups (so that a wrapper can set an option
+ * around the creation of one handle and restore it). */
+int dissc_get_option(const char* key, int* value);
 
 /* Diagnostics (not on the product path): average milliseconds of `iters` launches of
  * one Conv1d layer shape on synthetic device data; `epi` 0 plain, 1 +residual,

@@ -157,6 +157,34 @@ def test_generator_full_size_properties(env):
     assert torch.equal(y, y2)
 
 
+def test_split_bf16_instance_next_to_fp32_instance(env):
+    """CodeGenerator(h, precision="split_bf16") at the BASELINE size: within the 1e-4 RMS bar of the
+    oracle, batch-independent and deterministic like the fp32 path -- and building it leaves the
+    process default (exact fp32) untouched for instances created afterwards."""
+    import dissc_amd
+    g, gr, synth = env["g"], env["gr"], env["synth"]
+    sd = synth.synth_generator_state_dict(seed=0)
+    gs = dissc_amd.CodeGenerator(synth.VCTK_CONFIG, precision="split_bf16").to("cuda:0")
+    gs.load_state_dict(sd)
+    gs.eval().remove_weight_norm()
+    code, f0, spkr, _ = synth.synth_generator_inputs(32, 500, seed=1234)
+    tc, tf, ts = torch.from_numpy(code), torch.from_numpy(f0), torch.from_numpy(spkr)
+    y32 = g(code=tc, f0=tf, spkr=ts).cpu()
+    ys = gs(code=tc, f0=tf, spkr=ts).cpu()
+    d = _rms((ys - y32).numpy())
+    assert 0.0 < d <= 2e-5, d                      # really a different arithmetic, far inside the bar
+    ref = gr.code_generator(env["folded"], synth.VCTK_CONFIG, code[3:4], f0[3:4], spkr[3:4])
+    assert _rms((ys[3:4] - ref).numpy()) <= 1e-4   # north_star tolerance vs the reference CPU path
+    assert torch.equal(gs(code=tc[7:8], f0=tf[7:8], spkr=ts[7:8]).cpu()[0], ys[7])
+    assert torch.equal(gs(code=tc, f0=tf, spkr=ts).cpu(), ys)
+    g2 = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")  # default: exact fp32
+    g2.load_state_dict(sd)
+    g2.eval().remove_weight_norm()
+    assert torch.equal(g2(code=tc[:4], f0=tf[:4], spkr=ts[:4]).cpu(), y32[:4])
+    with pytest.raises(ValueError):
+        dissc_amd.CodeGenerator(synth.VCTK_CONFIG, precision="fp8")
+
+
 def test_wav_postprocess_matches_oracle(env):
     from dissc_amd.generator import wav_postprocess_
     rs = np.random.RandomState(0)
