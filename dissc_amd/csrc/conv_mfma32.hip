@@ -23,8 +23,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
   constexpr int KCB = KC * CPB;  // channels staged per barrier
   constexpr int XW_MAX = ((BN - 1) * STRIDE + 1 + SPAN + 3 + 31) / 32 * 32 + 16;
   constexpr int SV = (KCB * (XW_MAX / 4) + NT - 1) / NT;  // float4 staging slots per thread
-  constexpr int CW = 32 * NI + 4;                        // epilogue patch row stride
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x [KCB][XW] | NW x [8][CW]
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x [KCB][XW] | NW x [8][32*NI+4] (epilogue)
 
   const int b = blockIdx.z;
   const int len = (a.lengths ? a.lengths[b] * a.len_mul : a.len_default);  // valid INPUT positions
