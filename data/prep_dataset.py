@@ -1,34 +1,46 @@
 #!/usr/bin/env python
-"""Train/val split + per-speaker F0 statistics of an encoded dataset: same command line as the
-reference's data/prep_dataset.py (reference data/prep_dataset.py:6-21).  The statistics file it
-writes is what infer.py reads through --f0_path."""
+"""Prepare an encoded dataset for infer.py: optional train/val split, then the per-speaker F0
+statistics file that infer.py reads through --f0_path.
+
+Command line compatible with the reference's data/prep_dataset.py (reference
+data/prep_dataset.py:6-21): --encoded_path, --stats_path, --seed, --split_method, same defaults.
+The statistics are reduced on the GPU (dissc_amd.stats -> csrc/pitch_stats.hip).
+"""
 import argparse
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from data_utils import calculate_pitch_stats, data_split  # noqa: E402
-from infer import seed_everything  # noqa: E402
+
+def build_parser():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--encoded_path", default="ESD/hubert100/train.txt",
+                    help="units JSONL written by data/encode.py")
+    ap.add_argument("--stats_path", default="ESD/hubert100/f0_stats.pkl",
+                    help="where to write {speaker: {'mean', 'std'}} of the training part")
+    ap.add_argument("--seed", default=42, type=int, help="seed of the random split")
+    ap.add_argument("--split_method", default=None,
+                    help="'random' or 'paired_val'; omit to treat the whole file as training data")
+    ap.add_argument("--device", default="cuda:0", help="GPU that reduces the statistics (extension)")
+    return ap
 
 
-if __name__ == '__main__':
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--encoded_path', default='ESD/hubert100/train.txt', help='Path for HuBERT encodings')
-    parser.add_argument('--stats_path', default='ESD/hubert100/f0_stats.pkl', help='Output path for train speaker stats')
-    parser.add_argument('--seed', default=42, type=int, help='number of unique HuBERT clusters to used')
-    parser.add_argument('--split_method', default=None, help='Method for train-test split. If None encoded path is all train and no split is performed')
-    parser.add_argument('--device', default='cuda:0', help='GPU that reduces the statistics (not in the reference)')
-
-    args = parser.parse_args()
-
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    from data_utils import calculate_pitch_stats, data_split
+    from infer import seed_everything
     if args.seed is not None:
         seed_everything(args.seed)
+    train_path = args.encoded_path
     if args.split_method:
         train_path, _ = data_split(args.encoded_path, split_method=args.split_method)
-    else:
-        train_path = args.encoded_path
     calculate_pitch_stats(train_path, args.stats_path, device=args.device)
+
+
+if __name__ == "__main__":
+    main()
