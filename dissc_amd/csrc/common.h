@@ -61,6 +61,7 @@ struct ConvArgs {
   int mfast;            // 1: blockIdx.x walks the M tiles (XCD i keeps M tiles i, i+8, ... of the weights in its L2)
   int prec;             // 0 exact fp32 MFMA; 1 split-bf16 ("bf16x3") on the bf16 matrix cores (opt-in)
   int m32;              // 1: weights packed for / launched on the 32x32x2 kernel (conv_mfma32.hip)
+  int cfg32;            // tile shape id chosen for this launch (conv32_pick_cfg), -1 = the class default
   int CIN, M, KS, dil, nchunk;
   int XW;               // LDS row stride (floats), XW % 32 == 16
   int ldx, ldo;
@@ -81,11 +82,14 @@ int launch_conv(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t 
 int conv_tile_bn(int M);
 int conv_cfg(int M);
 void conv_set_cfg(int bm_class, int cfg);  // tuning hook (dissc_conv_bench / dissc_set_option)
-int conv_xw(int M, int KS, int dil, int stride = 1, int m32 = 0);
+int conv_xw(int M, int KS, int dil, int stride = 1, int m32 = 0, int bn = 0);  // bn > 0: explicit time tile
 // 32x32x2 form (conv_mfma32.hip)
 int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t stream);
 int conv32_tile_bn(int M);
 int conv32_cfg(int M);
+int conv32_pick_cfg(int M, int B, int Lmax_out);  // per-launch choice (steps down on small grids)
+int conv32_cfg_bn(int cfg);
+extern int g_small_grid;
 void conv32_set_cfg(int bm_class, int cfg);
 void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
                          int& Mpad, int& nchunk, int groups);

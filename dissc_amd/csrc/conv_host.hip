@@ -127,7 +127,12 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
   a.pad_left = dc.pad_left >= 0 ? dc.pad_left : ((dc.KS - 1) * dc.dil) / 2;
   a.mfast = 0;
   a.groups = dc.groups; a.nsub_group = dc.Mpad / (dc.m32 ? 32 : 16); a.act = dc.act; a.m32 = dc.m32; a.prec = dc.prec;
-  a.XW = conv_xw(dc.M, dc.KS, dc.dil, dc.stride, dc.m32);
+  a.cfg32 = -1;
+  const int span = (dc.KS - 1) * dc.dil;
+  const bool lin_big = (dc.KS == 1 && dc.M >= 256 && dc.nchunk >= 8);
+  if (dc.m32 && !dc.prec && dc.stride == 1 && dc.groups == 1 && span <= MAX_TAP_SPAN && !lin_big)
+    a.cfg32 = conv32_pick_cfg(dc.M, B, Lmax_out);  // general path only: the special instances keep their tile
+  a.XW = conv_xw(dc.M, dc.KS, dc.dil, dc.stride, dc.m32, a.cfg32 >= 0 ? conv32_cfg_bn(a.cfg32) : 0);
   a.ldx = ldx; a.ldo = ldo;
   a.x_bstride = (long long)C_x_total * ldx;
   a.o_bstride = (long long)(dc.M * dc.groups / dc.up_np) * ldo;

@@ -321,8 +321,8 @@ int conv_tile_bn(int M) {
   return 16 * c.NI * c.WN;
 }
 
-int conv_xw(int M, int KS, int dil, int stride, int m32) {
-  const int bn = m32 ? conv32_tile_bn(M) : conv_tile_bn(M);
+int conv_xw(int M, int KS, int dil, int stride, int m32, int bn_) {
+  const int bn = bn_ > 0 ? bn_ : (m32 ? conv32_tile_bn(M) : conv_tile_bn(M));
   const int need = (bn - 1) * stride + 1 + (KS - 1) * dil + 3;  // +3: aligned window start
   int xw = (need + 31) / 32 * 32 + 16;
   if (xw - 32 >= need) xw -= 32;

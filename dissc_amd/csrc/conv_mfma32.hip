@@ -210,6 +210,10 @@ static const TileCfg32 kCfgs32[] = {
     {2, 2, 1, 4},  // 5:  64 x 256
     {2, 2, 4, 2},  // 6: 256 x 128 (8 waves)
     {2, 2, 2, 4},  // 7: 128 x 256 (8 waves)
+    {0, 0, 0, 0},  // 8, 9: unused
+    {0, 0, 0, 0},
+    {1, 1, 2, 2},  // 10:  64 x 64   (small grids only, see conv32_pick_cfg)
+    {1, 1, 1, 4},  // 11:  32 x 128  (likewise)
 };
 int g_lin_tile = 2;  // "lin_tile" option: channels per barrier / 16 of the 1x1 (linear) convs (2 or 4)
 int g_cpb2 = 0;  // "cpb2" option: kernels with KS <= this stage 32 channels per barrier
@@ -235,6 +239,33 @@ int conv32_cfg(int M) {
 int conv32_tile_bn(int M) {
   const TileCfg32& c = kCfgs32[conv32_cfg(M)];
   return 32 * c.NI * c.WN;
+}
+
+int conv32_cfg_bn(int cfg) { return 32 * kCfgs32[cfg].NI * kCfgs32[cfg].WN; }
+
+// Tile shape for one launch.  The defaults are tuned for grids that fill the chip several times;
+// a short or single utterance (the reference's one-at-a-time mode) gives a 256 x 64 tile only a
+// few dozen workgroups on 256 CUs, each walking the whole K loop.  Below one workgroup per CU the
+// launch steps down to smaller tiles.  Every output element still sees the same sequence of
+// 32x32x2 MFMAs over (chunk, tap, k), so the result is bit-identical for every tile shape and an
+// utterance's samples stay independent of the batch it runs in.
+int g_small_grid = 1;  // "small_grid" option: workgroups per CU below which a launch steps down (0 = never)
+int conv32_pick_cfg(int M, int B, int Lmax_out) {
+  const int base = conv32_cfg(M);
+  if (!g_small_grid) return base;
+  static const int kSteps[4][3] = {{3, 11, -1}, {2, 10, -1}, {1, 2, 10}, {0, 2, 10}};  // by BM class
+  int cls = 0;
+  while ((32 << cls) < bm32_of(M)) ++cls;
+  if (base != kSteps[cls][0]) return base;  // a tuning override is in force: leave it alone
+  int pick = base;
+  for (int i = 0; i < 3 && kSteps[cls][i] >= 0; ++i) {
+    pick = kSteps[cls][i];
+    const TileCfg32& c = kCfgs32[pick];
+    const int bm = 32 * c.MI * c.WM, bn = 32 * c.NI * c.WN;
+    const long long nwg = (long long)((Lmax_out + bn - 1) / bn) * ((M + bm - 1) / bm) * B;
+    if (nwg >= 256LL * g_small_grid) break;
+  }
+  return pick;
 }
 
 // w: [Cout][Cin][KS] with Cin per group.  Layout [group][ms32][chunk][tap][half][lane][4]:
@@ -290,7 +321,7 @@ static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
 
 int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t stream) {
   const int span = (a.KS - 1) * a.dil;
-  const int cfg = conv32_cfg(a.M);
+  const int cfg = a.cfg32 >= 0 ? a.cfg32 : conv32_cfg(a.M);
   if (stride == 2 && span <= MAX_TAP_SPAN && a.up == 1) {
     if (cfg == 0) return launch32_t<2, 2, 4, 1, 2, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     set_error("launch_conv32: stride 2 needs >= 256 output rows (got %d)", a.M);
@@ -324,6 +355,8 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
     case 4: return launch32_t<1, 4, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     case 6: return launch32_t<2, 2, 4, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     case 7: return launch32_t<2, 2, 2, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 10: return launch32_t<1, 1, 2, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 11: return launch32_t<1, 1, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     default: return launch32_t<2, 2, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
   }
 }

@@ -525,6 +525,7 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "fused_bn32") == 0) { fused_set_option(1, value); return DISSC_OK; }
   if (strcmp(key, "precision") == 0) { g_precision = value; return DISSC_OK; }
   if (strcmp(key, "par_ups") == 0) { g_par_ups = value; return DISSC_OK; }
+  if (strcmp(key, "small_grid") == 0) { g_small_grid = value; return DISSC_OK; }
   if (strcmp(key, "bf3_pairs") == 0) { resblock_bf3_set_pairs(value); return DISSC_OK; }
   if (strcmp(key, "stream_prio") == 0) { g_stream_prio = value; return DISSC_OK; }
   if (strcmp(key, "multistream") == 0) { g_multistream = value; return DISSC_OK; }

@@ -130,6 +130,7 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   mfma32 (1)           use the 32x32x2 MFMA kernel for layers with >= 32 output rows
  *   conv_cfg_bm{16,32,64,128,256} / conv32_cfg_bm{32,64,128,256}
  *                        tile-shape id per GEMM-M class (tables in conv_mfma.hip / conv_mfma32.hip)
+ *   small_grid (1)       launches with fewer than value x 256 workgroups step down to smaller conv tiles (0 = never)
  *   lin_tile (2)         1x1 convs: 16-channel chunks staged per barrier (2 or 4)
  *   cpb2 (0)             k <= value convs stage 32 channels per barrier
  *   fused_max_c (0)      widest ResBlock run as ONE fused launch (experimental: 16 or 32)
