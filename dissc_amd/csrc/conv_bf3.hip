@@ -247,7 +247,16 @@ int launch_conv_bf3(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream) 
               a.dil, a.M);
     return DISSC_EINVAL;
   }
-  switch (bf3_class(a.M)) {
+  const int cls = bf3_class(a.M);
+  if (cls >= 2 && g_small_grid) {
+    // small grids (short or single utterances): 64 x 128 tiles instead of the 128-accumulator ones,
+    // same MFMA sequence per output element, bit-identical result (cf. conv32_pick_cfg)
+    const TileBf3& t = kBf3[cls];
+    const int bm = 32 * t.MI * t.WM, bn = 32 * t.NI * t.WN;
+    const long long nwg = (long long)((Lmax_out + bn - 1) / bn) * ((a.M + bm - 1) / bm) * B;
+    if (nwg < 256LL * g_small_grid) return launch_bf3_t<1, 2, 2, 2>(a, B, Lmax_out, stream);
+  }
+  switch (cls) {
     case 0: return launch_bf3_t<1, 2, 1, 4>(a, B, Lmax_out, stream);
     case 1: return launch_bf3_t<1, 2, 2, 2>(a, B, Lmax_out, stream);
     case 2: return launch_bf3_t<2, 4, 2, 2>(a, B, Lmax_out, stream);
