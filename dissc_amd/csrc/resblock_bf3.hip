@@ -53,6 +53,12 @@ __device__ __forceinline__ float lrelu_b(float v, float slope) { return v > 0.f 
 // C = 32, 64: K = 32 is one tap x 32 channels (step s = tap * C/32 + kb: channels 32 kb + 8g .. +7),
 //         C/16 row blocks of 16 per tile; the weight fragments are streamed from L2 one step ahead
 //         of the MFMAs that use them.
+// LDS padding columns on each side of the window: taps reach P2*d <= 5*P2 columns out (C = 16: one
+// more dilation step for the zero-weight tap that pads an odd tap count to a pair)
+__host__ __device__ constexpr int bf3_pad(int C, int KS) {
+  return C == 16 ? 32 : ((KS - 1) / 2 * 5 + 3) & ~3;
+}
+
 template <int C, int KS, int NW, int NI>
 __global__ void __launch_bounds__(64 * NW) resblock_bf3_kernel(const ResblockBf3Args a) {
   static_assert(C == 16 || C == 32 || C == 64, "narrow stages only");
@@ -63,7 +69,7 @@ __global__ void __launch_bounds__(64 * NW) resblock_bf3_kernel(const ResblockBf3
   constexpr int NS = (C == 16) ? (KS + 1) / 2 : KS * KB;  // MFMA K-steps per conv
   constexpr int P2 = (KS - 1) / 2;
   constexpr int COLS = 16 * NW * NI;  // window columns owned by the workgroup
-  constexpr int PAD = 32;             // >= P2 * 5 + 5: reach of the widest (padded) tap
+  constexpr int PAD = bf3_pad(C, KS); // reach of the widest tap (dilation <= 5), a multiple of 4
   constexpr int XW = COLS + 2 * PAD;
   constexpr int TB = NI < 4 ? NI : 4; // tiles per accumulator batch
   static_assert(NI % TB == 0, "NI must be a multiple of the tile batch");
@@ -387,7 +393,7 @@ void pack_resblock_bf3(int C, int KS, const float* const* w6, std::vector<float>
 
 template <int C, int KS, int NW, int NI>
 static int launch_bf3(ResblockBf3Args a, int B, int Lmax, hipStream_t stream) {
-  constexpr int COLS = 16 * NW * NI, XW = COLS + 64;
+  constexpr int COLS = 16 * NW * NI, XW = COLS + 2 * bf3_pad(C, KS);
   const int P2 = (KS - 1) / 2;
   int H = 0;
   for (int m = a.m0; m < a.m1; ++m) H += P2 * (a.dil[m] + 1);
@@ -425,7 +431,7 @@ int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, c
     if (KS == 7) return launch_bf3<64, 7, 8, 2>(a, B, Lmax, stream);
     return launch_bf3<64, 11, 8, 2>(a, B, Lmax, stream);
   }
-  if (C == 32) {  // 512-column windows (145 KB of LDS): one workgroup of 8 waves per CU
+  if (C == 32) {  // 512-column windows (135-145 KB of LDS): one workgroup of 8 waves per CU
     if (KS == 3) return launch_bf3<32, 3, 8, 4>(a, B, Lmax, stream);
     if (KS == 7) return launch_bf3<32, 7, 8, 4>(a, B, Lmax, stream);
     return launch_bf3<32, 11, 8, 4>(a, B, Lmax, stream);
