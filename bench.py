@@ -143,9 +143,15 @@ def main():
         if fake:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            # DISSC_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+            # (ranks share devices round-robin, gloo stages the device tensors through the host);
+            # the driver's runs use the default, RCCL with one GPU per rank.
+            backend = os.environ.get("DISSC_BENCH_BACKEND", "nccl")
+            if backend != "nccl":
+                local_rank = local_rank % torch.cuda.device_count()
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     n_gpus = world
     import synthdata as synth  # deterministic synthetic checkpoints / inputs
     sd = synth.synth_generator_state_dict(seed=0)

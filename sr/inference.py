@@ -183,9 +183,14 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29512')
+        # DISSC_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks share devices
+        # round-robin); the default is RCCL with one GPU per rank
+        backend = os.environ.get('DISSC_DIST_BACKEND', 'nccl')
+        if backend != 'nccl':
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        kw = {'device_id': torch.device('cuda', local_rank)} if backend == 'nccl' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     device = torch.device('cuda', local_rank)
 
     if os.path.isdir(a.checkpoint_file):

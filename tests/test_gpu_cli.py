@@ -5,6 +5,7 @@ import importlib.util
 import json
 import os
 import shutil
+import sys
 
 import numpy as np
 import pytest
@@ -59,10 +60,9 @@ def test_infer_cli_matches_reference(gpu, golden_dir, tmp_path):
             assert np.abs(got[~flips] - want[~flips]).max() <= 2e-5
 
 
-def test_sr_inference_cli_matches_reference(gpu, golden_dir, tmp_path):
+def _sr_inference_setup(td, golden_dir, g):
+    """checkpoint dir, wav dir and manifest of the golden sr/inference.py case -> CLI arguments"""
     import synthdata as synth
-    g = np.load(os.path.join(golden_dir, "sr_inference.npz"))
-    td = str(tmp_path)
     for d in ("ckpt", "wav", "out", "meta"):
         os.makedirs(f"{td}/{d}")
     cfg = dict(synth.VCTK_CONFIG, input_training_file=f"{td}/meta/train.txt", f0_normalize=False,
@@ -76,9 +76,38 @@ def test_sr_inference_cli_matches_reference(gpu, golden_dir, tmp_path):
             shutil.copy(os.path.join(golden_dir, f"s1_{i + 1}.wav"), f"{td}/wav/{nm}")
             f.write(json.dumps({"units": g[f"sr/units{i}"].tolist(), "f0": g[f"sr/f0{i}"].tolist(),
                                 "audio": nm}) + "\n")
+    return ["--input_code_file", f"{td}/man.txt", "--data_path", f"{td}/wav", "--output_dir", f"{td}/out",
+            "--checkpoint_file", f"{td}/ckpt/", "--vc", "--target-speakers", "p231", "p225", "-n", "-1"]
+
+
+def test_sr_inference_two_ranks_equal_one_process(gpu, golden_dir, tmp_path):
+    """The rank-sharded path of sr/inference.py with device tensors: 2 ranks (sharing this box's GPU,
+    gloo instead of RCCL) must write exactly the files of a single process."""
+    import subprocess
+    g = np.load(os.path.join(golden_dir, "sr_inference.npz"))
+    td = str(tmp_path)
+    args = _sr_inference_setup(td, golden_dir, g)
+    cli = _load("dissc_sr_inference_cli2", "sr/inference.py")
+    cli.main(args)
+    os.rename(f"{td}/out", f"{td}/out_single")
+    os.makedirs(f"{td}/out")
+    env = dict(os.environ, DISSC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29537",
+                        os.path.join(ROOT, "sr", "inference.py")] + args,
+                       env=env, capture_output=True, text=True, timeout=900, cwd=td)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    files = sorted(os.listdir(f"{td}/out_single"))
+    assert files and sorted(os.listdir(f"{td}/out")) == files
+    for fn in files:
+        assert open(f"{td}/out/{fn}", "rb").read() == open(f"{td}/out_single/{fn}", "rb").read(), fn
+
+
+def test_sr_inference_cli_matches_reference(gpu, golden_dir, tmp_path):
+    g = np.load(os.path.join(golden_dir, "sr_inference.npz"))
+    td = str(tmp_path)
     cli = _load("dissc_sr_inference_cli", "sr/inference.py")
-    cli.main(["--input_code_file", f"{td}/man.txt", "--data_path", f"{td}/wav", "--output_dir", f"{td}/out",
-              "--checkpoint_file", f"{td}/ckpt/", "--vc", "--target-speakers", "p231", "p225", "-n", "-1"])
+    cli.main(_sr_inference_setup(td, golden_dir, g))
     want_files = sorted(k[len("sr/out/"):] for k in g.files if k.startswith("sr/out/"))
     assert sorted(os.listdir(f"{td}/out")) == want_files
     for fn in want_files:
