@@ -323,6 +323,61 @@ def make_sr_inference():
             assert rate == 16000
             out[f"sr/out/{fn}"] = data
         out["sr/names"] = np.array(names)
+
+        # ---- scenario B: unseen source speaker + per-target F0 re-normalisation (--f0-stats) + --parts
+        def run_ref(ns, n_items):
+            q2 = queue.Queue()
+            q2.put("cpu")
+            try:
+                ref_inf.init_worker(q2, ns)
+            except TypeError:
+                pass
+            for i in range(n_items):
+                ref_inf.inference(i)
+
+        os.makedirs(f"{td}/data/wav"); os.makedirs(f"{td}/out_b"); os.makedirs(f"{td}/out_c")
+        names_b = ["newspk_001.wav", "other_002_mic2.wav"]
+        man_b = f"{td}/man_b.txt"
+        with open(man_b, "w") as f:
+            for i, (nm, sr_, T) in enumerate(zip(names_b, srcs, lens)):
+                shutil.copy(os.path.join(REF, "data/unseen/wav_orig", sr_), f"{td}/data/wav/{nm}")
+                code, f0, _, _ = synth.synth_generator_inputs(1, T, seed=950 + i)
+                hz = np.where(f0[0, 0] != 0, 180.0 + 40.0 * f0[0, 0], 0.0).astype(np.float32)  # F0 in Hz
+                f.write(_json.dumps({"units": code[0].tolist(), "f0": hz.tolist(), "audio": nm}) + "\n")
+                out[f"srb/units{i}"], out[f"srb/f0{i}"] = code[0], hz
+        id_to_spkr = pickle.load(open(f"{td}/meta/id_to_spkr.pkl", "rb"))
+        tids = [id_to_spkr.index("p231"), id_to_spkr.index("p225")]
+        stats = {tids[0]: {"f0_mean": 121.5, "f0_std": 23.25}, "f0_mean": 150.0, "f0_std": 30.0}  # p225 falls back
+        torch.save(stats, f"{td}/meta/tgt_f0_stats.pt")
+        b = argparse.Namespace(**{**vars(a), "input_code_file": man_b, "data_path": f"{td}/data/wav",
+                                  "output_dir": f"{td}/out_b", "f0_stats": f"{td}/meta/tgt_f0_stats.pt",
+                                  "parts": True, "unseen_speaker": True, "id_to_spkr": f"{td}/meta/id_to_spkr.pkl"})
+        run_ref(b, 2)
+        for fn in sorted(os.listdir(f"{td}/out_b")):
+            out[f"srb/out/{fn.replace(os.path.basename(td) + '_', 'TD_')}"] = wavfile.read(f"{td}/out_b/{fn}")[1]
+        out["srb/names"] = np.array(names_b)
+        out["srb/stats"] = np.array([tids[0], 121.5, 23.25, 150.0, 30.0])
+
+        # ---- scenario C: --sample_df (only the listed source/target pairs, no GT, no resynthesis)
+        import pandas as pd
+        names_c = ["p226_001.wav", "p300_002_mic2.wav"]
+        man_c = f"{td}/man_c.txt"
+        with open(man_c, "w") as f:
+            for i, (nm, nb) in enumerate(zip(names_c, names_b)):
+                shutil.copy(f"{td}/data/wav/{nb}", f"{td}/data/wav/{nm}")
+                f.write(_json.dumps({"units": out[f"srb/units{i}"].tolist(), "f0": out[f"sr/f0{i}"][:lens[i]].tolist(),
+                                     "audio": nm}) + "\n")
+        df = pd.DataFrame({"syn_sample": ["p226_001", "p300_002", "p300_002"],
+                           "syn_trgt": ["p231", "p225", "p231"]})
+        df.to_csv(f"{td}/meta/pairs.csv")
+        c = argparse.Namespace(**{**vars(a), "input_code_file": man_c, "data_path": f"{td}/data/wav",
+                                  "output_dir": f"{td}/out_c", "sample_df": f"{td}/meta/pairs.csv",
+                                  "target_speakers": ["p231", "p225", "p226"]})
+        run_ref(c, 2)
+        for fn in sorted(os.listdir(f"{td}/out_c")):
+            out[f"src/out/{fn}"] = wavfile.read(f"{td}/out_c/{fn}")[1]
+        out["src/pairs"] = np.array([list(df.syn_sample), list(df.syn_trgt)])
+        out["src/names"] = np.array(names_c)
     np.savez_compressed(os.path.join(HERE, "sr_inference.npz"), **out)
     print("sr_inference.npz", sorted(k for k in out if k.startswith("sr/out")))
 

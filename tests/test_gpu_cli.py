@@ -103,6 +103,61 @@ def test_sr_inference_two_ranks_equal_one_process(gpu, golden_dir, tmp_path):
         assert open(f"{td}/out/{fn}", "rb").read() == open(f"{td}/out_single/{fn}", "rb").read(), fn
 
 
+def _check_wavs(out_dir, g, prefix):
+    want_files = sorted(k[len(prefix):] for k in g.files if k.startswith(prefix))
+    assert sorted(os.listdir(out_dir)) == want_files
+    for fn in want_files:
+        rate, data = wavfile.read(f"{out_dir}/{fn}")
+        ref = g[prefix + fn]
+        assert rate == 16000 and data.dtype == np.float32 and data.shape == ref.shape, fn
+        if fn.endswith("_gt.wav"):
+            np.testing.assert_array_equal(data, ref)
+        else:
+            d = np.abs(data - ref)
+            assert d.max() <= 1e-4, (fn, d.max())
+            assert np.sqrt(np.mean(d ** 2)) <= 1e-5
+            assert (d > 1e-6).mean() <= 0.02
+
+
+def test_sr_inference_unseen_speaker_f0_stats_parts_and_sample_df(gpu, golden_dir, tmp_path):
+    """More of the reference harness's branches, against its own outputs: an unseen source speaker
+    (no resynthesis, speaker id 0), --f0-stats (voiced F0 re-normalised to each target, with the
+    global fallback for a target that has no entry), --parts output names, and --sample_df (only the
+    listed source/target pairs, no ground-truth copies)."""
+    import pandas as pd
+    import synthdata as synth
+    g = np.load(os.path.join(golden_dir, "sr_inference.npz"))
+    td = str(tmp_path)
+    for d in ("ckpt", "data/wav", "out_b", "out_c", "meta"):
+        os.makedirs(f"{td}/{d}")
+    cfg = dict(synth.VCTK_CONFIG, input_training_file=f"{td}/meta/train.txt", f0_normalize=False,
+               f0_stats=None, test_base_path=f"{td}/data/wav")
+    json.dump(cfg, open(f"{td}/ckpt/config.json", "w"))
+    torch.save({"generator": synth.synth_generator_state_dict(seed=0)}, f"{td}/ckpt/g_00000001")
+    shutil.copy(os.path.join(golden_dir, "vctk_id_to_spkr.pkl"), f"{td}/meta/id_to_spkr.pkl")
+    tid, m0, s0, mg, sg = g["srb/stats"]
+    torch.save({int(tid): {"f0_mean": float(m0), "f0_std": float(s0)}, "f0_mean": float(mg), "f0_std": float(sg)},
+               f"{td}/meta/tgt_f0_stats.pt")
+    for key, man, f0key in (("srb/names", "man_b.txt", "srb/f0"), ("src/names", "man_c.txt", "sr/f0")):
+        with open(f"{td}/{man}", "w") as f:
+            for i, nm in enumerate(str(x) for x in g[key]):
+                shutil.copy(os.path.join(golden_dir, f"s1_{i + 1}.wav"), f"{td}/data/wav/{nm}")
+                f.write(json.dumps({"units": g[f"srb/units{i}"].tolist(), "f0": g[f"{f0key}{i}"].tolist(),
+                                    "audio": nm}) + "\n")
+    cli = _load("dissc_sr_inference_cli3", "sr/inference.py")
+    cli.main(["--input_code_file", f"{td}/man_b.txt", "--data_path", f"{td}/data/wav", "--output_dir", f"{td}/out_b",
+              "--checkpoint_file", f"{td}/ckpt/", "--vc", "--target-speakers", "p231", "p225", "-n", "-1",
+              "--f0-stats", f"{td}/meta/tgt_f0_stats.pt", "--parts", "--unseen_speaker",
+              "--id_to_spkr", f"{td}/meta/id_to_spkr.pkl"])
+    _check_wavs(f"{td}/out_b", g, "srb/out/")
+    pairs = g["src/pairs"]
+    pd.DataFrame({"syn_sample": list(pairs[0]), "syn_trgt": list(pairs[1])}).to_csv(f"{td}/meta/pairs.csv")
+    cli.main(["--input_code_file", f"{td}/man_c.txt", "--data_path", f"{td}/data/wav", "--output_dir", f"{td}/out_c",
+              "--checkpoint_file", f"{td}/ckpt/", "--vc", "--target-speakers", "p231", "p225", "p226", "-n", "-1",
+              "--sample_df", f"{td}/meta/pairs.csv"])
+    _check_wavs(f"{td}/out_c", g, "src/out/")
+
+
 def test_sr_inference_cli_matches_reference(gpu, golden_dir, tmp_path):
     g = np.load(os.path.join(golden_dir, "sr_inference.npz"))
     td = str(tmp_path)
