@@ -233,6 +233,26 @@ def make_predictors():
                 d = _json.loads(ln)
                 out[f"lenonly/{fn}/{i}/units"] = np.array(d["units"], dtype=np.int64)
                 out[f"lenonly/{fn}/{i}/f0"] = np.array(d["f0"], dtype=np.float64)
+        # pitch-only conversion of listed pairs: --pred_pitch (base model) without --pred_len, F0 written
+        # in Hz (norm_pitch off = de-normalised with the target's statistics), --sample_df
+        import pandas as pd
+        os.makedirs(f"{td}/out3")
+        torch.save(synth.synth_pitch_state_dict("base", 100, n_spk), f"{td}/pitch/best_model.pth")
+        pairs = pd.DataFrame({"syn_sample": ["p226_001", "p231_100", "p231_100"], "syn_trgt": ["p225", "p231", "p225"]})
+        pairs.to_csv(f"{td}/in/pairs.csv")
+        a3 = argparse.Namespace(**{**vars(a), "pred_len": False, "pred_pitch": True, "f0_model_type": "base",
+                                   "norm_pitch": False, "sample_df": f"{td}/in/pairs.csv", "out_path": f"{td}/out3"})
+        ref_infer.args = a3
+        ref_infer.infer(a3.input_path, "cpu", a3)
+        out["pitchonly/pairs"] = np.array([list(pairs.syn_sample), list(pairs.syn_trgt)])
+        for fn in sorted(os.listdir(f"{td}/out3")):
+            lines3 = open(f"{td}/out3/{fn}").read().strip().split("\n")
+            out[f"pitchonly/{fn}/n"] = np.array(len(lines3))
+            for i, ln in enumerate(lines3):
+                d = _json.loads(ln)
+                out[f"pitchonly/{fn}/{i}/units"] = np.array(d["units"], dtype=np.int64)
+                out[f"pitchonly/{fn}/{i}/f0"] = np.array(d["f0"], dtype=np.float64)
+                out[f"pitchonly/{fn}/{i}/audio"] = np.array(d["audio"])
         import utils as ref_utils_root  # reference root utils.py (tensorflow stubbed)
         rs3 = np.random.RandomState(5)
         for j, (u, tl) in enumerate([([3, 3, 3, 7, 7, 1], [5, 1, 2]), ([4], [3]), ([1, 2, 2, 2, 2, 9, 9], [2, 2, 5]),

@@ -287,3 +287,37 @@ def test_infer_cli_rhythm_only_matches_reference(gpu, golden_dir, tmp_path):
             d = json.loads(ln)
             np.testing.assert_array_equal(d["units"], g[f"lenonly/{fn}/{i}/units"])
             assert np.abs(np.array(d["f0"]) - g[f"lenonly/{fn}/{i}/f0"]).max() <= 1e-5
+
+
+def test_infer_cli_pitch_only_pairs_in_hz_matches_reference(gpu, golden_dir, tmp_path):
+    """--pred_pitch without --pred_len, base pitch model, --norm_pitch given (store_false: F0 written
+    in Hz, de-normalised with the TARGET speaker's statistics), --sample_df (only the listed pairs,
+    no reconstruction file)."""
+    import pandas as pd
+    import synthdata as synth
+    g = np.load(os.path.join(golden_dir, "pred.npz"))
+    td = str(tmp_path)
+    for d in ("pitch", "out", "in"):
+        os.makedirs(f"{td}/{d}")
+    torch.save(synth.synth_pitch_state_dict("base", 100, 108), f"{td}/pitch/best_model.pth")
+    shutil.copy(os.path.join(golden_dir, "vctk_id_to_spkr.pkl"), f"{td}/in/id_to_spkr.pkl")
+    open(f"{td}/in/val.txt", "w").write(str(g["val/manifest"]))
+    pairs = g["pitchonly/pairs"]
+    pd.DataFrame({"syn_sample": list(pairs[0]), "syn_trgt": list(pairs[1])}).to_csv(f"{td}/in/pairs.csv")
+    infer = _load("dissc_infer_cli_pitch", "infer.py")
+    infer.main(["--input_path", f"{td}/in/val.txt", "-n", "3", "--out_path", f"{td}/out", "--pred_pitch",
+                "--f0_model", f"{td}/pitch/", "--f0_model_type", "base", "--norm_pitch",
+                "--f0_path", os.path.join(golden_dir, "vctk_f0_stats.pkl"), "--vc",
+                "--target_speakers", "p231", "p225", "--sample_df", f"{td}/in/pairs.csv"])
+    assert sorted(os.listdir(f"{td}/out")) == ["p225_val.txt", "p231_val.txt"]  # no reconstruction file
+    for fn in ("p225_val.txt", "p231_val.txt"):
+        lines = open(f"{td}/out/{fn}").read().strip().split("\n")
+        assert len(lines) == int(g[f"pitchonly/{fn}/n"])
+        for i, ln in enumerate(lines):
+            d = json.loads(ln)
+            assert d["audio"] == str(g[f"pitchonly/{fn}/{i}/audio"])
+            np.testing.assert_array_equal(d["units"], g[f"pitchonly/{fn}/{i}/units"])  # units pass through
+            want, got = g[f"pitchonly/{fn}/{i}/f0"], np.array(d["f0"])
+            flips = (got == 0) != (want == 0)
+            assert flips.sum() <= 1
+            assert np.abs(got[~flips] - want[~flips]).max() <= 2e-3  # Hz (normalised value x std ~ 30-50)
