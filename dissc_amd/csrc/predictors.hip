@@ -78,28 +78,64 @@ __global__ void pitch_head_kernel(const float* __restrict__ h, const float* __re
   out[(size_t)b * ldo + t] = (cls > 0.f ? 1.f : 0.f) * reg;
 }
 
-// run-length encode each row: one thread per sequence (T <= a few hundred; integer, exact)
-__global__ void dedup_kernel(const int64_t* __restrict__ units, const int32_t* __restrict__ lengths,
-                             int B, int T, int64_t* __restrict__ vals, int32_t* __restrict__ counts,
-                             int32_t* __restrict__ n_out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// inclusive prefix sum of one int per thread over a 256-thread workgroup (wave shuffles, then the
+// four wave totals through LDS); *total receives the workgroup sum
+constexpr int SEQ_NT = 256;
+__device__ __forceinline__ int block_scan_incl(int v, int* red, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(v, off);
+    if (lane >= off) v += y;
+  }
+  __syncthreads();  // red[] may still be read from the previous call
+  if (lane == 63) red[wave] = v;
+  __syncthreads();
+  int add = 0;
+#pragma unroll
+  for (int w = 0; w < SEQ_NT / 64; ++w) add += (w < wave) ? red[w] : 0;
+  *total = red[0] + red[1] + red[2] + red[3];
+  return v + add;
+}
+
+// run-length encode each row (integer, exact): one workgroup per sequence.  A frame is a run head
+// when it differs from its predecessor; a prefix sum over the head flags gives every run its output
+// slot, the run start goes to counts[] first and becomes the run length in a second sweep.
+__global__ void __launch_bounds__(SEQ_NT) dedup_kernel(const int64_t* __restrict__ units,
+                                                       const int32_t* __restrict__ lengths, int B, int T,
+                                                       int64_t* __restrict__ vals, int32_t* __restrict__ counts,
+                                                       int32_t* __restrict__ n_out) {
+  __shared__ int red[SEQ_NT / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int len = lengths ? lengths[b] : T;
   const int64_t* u = units + (size_t)b * T;
   int64_t* v = vals + (size_t)b * T;
   int32_t* c = counts + (size_t)b * T;
   int n = 0;
-  for (int t = 0; t < len; ++t) {
-    const int64_t x = u[t];
-    if (n > 0 && v[n - 1] == x) {
-      c[n - 1] += 1;
-    } else {
-      v[n] = x;
-      c[n] = 1;
-      ++n;
+  for (int t0 = 0; t0 < len; t0 += SEQ_NT) {
+    const int t = t0 + tid;
+    const int64_t x = t < len ? u[t] : 0;
+    const int head = (t < len && (t == 0 || u[t - 1] != x)) ? 1 : 0;
+    int total;
+    const int pos = block_scan_incl(head, red, &total);
+    if (head) {
+      v[n + pos - 1] = x;
+      c[n + pos - 1] = t;  // run start, turned into the run length below
     }
+    n += total;
   }
-  n_out[b] = n;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += SEQ_NT) {
+    const int i = i0 + tid;
+    int start = 0, next = 0;
+    if (i < n) {
+      start = c[i];
+      next = i + 1 < n ? c[i + 1] : len;
+    }
+    __syncthreads();  // every start of this sweep is read before any is overwritten
+    if (i < n) c[i] = next - start;
+  }
+  if (tid == 0) n_out[b] = n;
 }
 
 // error-diffusion rounding, sequential fp32 running sum exactly like the reference's loop
@@ -132,18 +168,27 @@ __global__ void carryover_kernel(const float* __restrict__ lens, const int32_t* 
   totals[b] = sum;
 }
 
-__global__ void expand_kernel(const int64_t* __restrict__ vals, const int32_t* __restrict__ lens,
-                              const int32_t* __restrict__ n_in, int B, int ld_in,
-                              int64_t* __restrict__ out, int ld_out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// run-length decode (repeat_interleave): one workgroup per sequence; a prefix sum of the run
+// lengths gives every run its first output position, each thread then writes its own run
+__global__ void __launch_bounds__(SEQ_NT) expand_kernel(const int64_t* __restrict__ vals,
+                                                        const int32_t* __restrict__ lens,
+                                                        const int32_t* __restrict__ n_in, int B, int ld_in,
+                                                        int64_t* __restrict__ out, int ld_out) {
+  __shared__ int red[SEQ_NT / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int n = n_in[b];
   int64_t* o = out + (size_t)b * ld_out;
-  int p = 0;
-  for (int i = 0; i < n; ++i) {
-    const int64_t v = vals[(size_t)b * ld_in + i];
-    const int r = lens[(size_t)b * ld_in + i];
-    for (int j = 0; j < r && p < ld_out; ++j) o[p++] = v;
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += SEQ_NT) {
+    const int i = i0 + tid;
+    const int r = (i < n) ? max(lens[(size_t)b * ld_in + i], 0) : 0;
+    int total;
+    const int end = base + block_scan_incl(r, red, &total);
+    if (r > 0) {
+      const int64_t v = vals[(size_t)b * ld_in + i];
+      for (int p = end - r; p < end && p < ld_out; ++p) o[p] = v;
+    }
+    base += total;
   }
 }
 
@@ -394,7 +439,7 @@ int dissc_dedup(const int64_t* units, const int32_t* lengths, int B, int Tmax, i
     set_error("dissc_dedup: bad argument");
     return DISSC_EINVAL;
   }
-  hipLaunchKernelGGL(dedup_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, units, lengths,
+  hipLaunchKernelGGL(dedup_kernel, dim3(B), dim3(SEQ_NT), 0, (hipStream_t)stream, units, lengths,
                      B, Tmax, vals, counts, n_out);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
@@ -418,7 +463,7 @@ int dissc_expand(const int64_t* vals, const int32_t* lens_int, const int32_t* n,
     set_error("dissc_expand: bad argument");
     return DISSC_EINVAL;
   }
-  hipLaunchKernelGGL(expand_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, vals, lens_int,
+  hipLaunchKernelGGL(expand_kernel, dim3(B), dim3(SEQ_NT), 0, (hipStream_t)stream, vals, lens_int,
                      n, B, ld_in, out, ld_out);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;

@@ -64,6 +64,45 @@ def test_integer_logic_is_bit_exact(env):
         np.testing.assert_array_equal(got[0].cpu().numpy(), g[f"carry_out{j}"])
 
 
+def test_dedup_expand_long_ragged_sequences(env):
+    """Run-length encode / decode across several 256-frame sweeps of the per-sequence workgroup:
+    ragged lengths around the sweep boundaries, runs that straddle them, zero-length runs."""
+    from oracle import predictors_ref as pr
+    P = env["P"]
+    rs = np.random.RandomState(9)
+    lengths = [1, 2, 255, 256, 257, 511, 513, 1500, 0, 1024]
+    T = max(lengths)
+    units = torch.full((len(lengths), T), 99, dtype=torch.int64)
+    seqs = []
+    for i, n in enumerate(lengths):
+        runs = rs.randint(1, 9, size=n + 1)                       # run lengths 1..8
+        s = np.repeat(rs.randint(0, 100, size=n + 1), runs)[:n]  # neighbouring runs may share a unit
+        if n >= 300:
+            s[250:262] = 42                                       # one run across the first sweep boundary
+        seqs.append(s)
+        units[i, :n] = torch.from_numpy(s)
+    vals, counts, nn = P.dedup(units.cuda(), torch.tensor(lengths, dtype=torch.int32).cuda())
+    for i, s in enumerate(seqs):
+        k = int(nn[i])
+        if len(s) == 0:
+            assert k == 0
+            continue
+        wv, wc = pr.dedup_seq(s)
+        np.testing.assert_array_equal(vals[i, :k].cpu().numpy(), np.asarray(wv))
+        np.testing.assert_array_equal(counts[i, :k].cpu().numpy(), np.asarray(wc))
+    L = int(nn.max())
+    li = torch.zeros(len(lengths), L, dtype=torch.int32)
+    for i in range(len(lengths)):
+        k = int(nn[i])
+        li[i, :k] = torch.from_numpy(rs.randint(0, 6, size=k).astype(np.int32))  # includes zero-length runs
+    tot = li.sum(1)
+    ex = P.expand(vals[:, :L].contiguous(), li.cuda(), nn, int(tot.max()))
+    for i in range(len(lengths)):
+        k = int(nn[i])
+        want = np.repeat(vals[i, :k].cpu().numpy(), li[i, :k].numpy())
+        np.testing.assert_array_equal(ex[i, :int(tot[i])].cpu().numpy(), want)
+
+
 def test_len_predictor_matches_reference(env):
     g, lm = env["g"], env["lm"]
     n = int(g["n_seqs"])
