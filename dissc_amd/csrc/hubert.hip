@@ -318,7 +318,9 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S
 // probabilities are already in MFMA B-operand position for O[d][query] += V[d][key] P^T[key][query]
 // (k-step s of the PV product uses key 4*g + s, i.e. register s of the same lane) -- no LDS
 // round trip for P, no HBM round trip for S.
-constexpr int AT_Q = 64;    // queries per block (4 waves x 16)
+constexpr int AT_NQ = 2;    // groups of 16 queries per wave
+constexpr int AT_Q = 64 * AT_NQ;  // queries per block (4 waves x AT_NQ x 16)
+constexpr int AT_LDQQ = AT_Q + 16;  // row stride of the Q tile (% 32 == 16: conflict-free fragment reads)
 constexpr int AT_K = 64;    // keys per LDS tile
 constexpr int AT_LDQ = 80;  // row stride of the Q / K tiles (80 % 32 == 16: conflict-free fragment reads)
 constexpr int AT_LDV = 65;  // row stride of the V tile (odd: lanes walk rows)
@@ -326,7 +328,7 @@ constexpr int AT_LDV = 65;  // row stride of the V tile (odd: lanes walk rows)
 __global__ void __launch_bounds__(256) attn_fused_kernel(const float* __restrict__ qkv,
                                                          const int32_t* __restrict__ lens, int D,
                                                          int hd, int ld, float* __restrict__ out) {
-  __shared__ float Qs[64 * AT_LDQ];
+  __shared__ float Qs[64 * AT_LDQQ];
   __shared__ float Ks[64 * AT_LDQ];
   __shared__ float Vs[64 * AT_LDV];
   const int b = blockIdx.z, h = blockIdx.y;
@@ -340,17 +342,26 @@ __global__ void __launch_bounds__(256) attn_fused_kernel(const float* __restrict
   const float* vb = qb + (size_t)2 * D * ld;
   // Q tile -> LDS (zero beyond T)
   for (int e = tid; e < 64 * AT_Q; e += 256) {
-    const int d = e >> 6, c = e & 63;
-    Qs[d * AT_LDQ + c] = (q0 + c < T) ? qb[(size_t)d * ld + q0 + c] : 0.f;
+    const int d = e / AT_Q, c = e - d * AT_Q;
+    Qs[d * AT_LDQQ + c] = (q0 + c < T) ? qb[(size_t)d * ld + q0 + c] : 0.f;
   }
   __syncthreads();
-  float qf[16];  // this wave's Q fragments: k-step ks -> Q[d = 4*ks + g][query = wave*16 + l15]
+  // this wave's AT_NQ groups of 16 queries: k-step ks -> Q[d = 4*ks + g][query = (wave*AT_NQ + j)*16 + l15].
+  // The groups share every K / V fragment read and give the matrix pipe independent accumulator chains.
+  float qf[AT_NQ][16];
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) qf[ks] = Qs[(4 * ks + g) * AT_LDQ + wave * 16 + l15];
-  f32x4 o[4];
+  for (int j = 0; j < AT_NQ; ++j)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, l = 0.f;
+    for (int ks = 0; ks < 16; ++ks) qf[j][ks] = Qs[(4 * ks + g) * AT_LDQQ + (wave * AT_NQ + j) * 16 + l15];
+  f32x4 o[AT_NQ][4];
+  float m[AT_NQ], l[AT_NQ];
+#pragma unroll
+  for (int j = 0; j < AT_NQ; ++j) {
+    m[j] = -INFINITY;
+    l[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   for (int k0 = 0; k0 < T; k0 += AT_K) {
     __syncthreads();  // previous tile fully consumed
     for (int e = tid; e < 64 * AT_K; e += 256) {
@@ -363,51 +374,67 @@ __global__ void __launch_bounds__(256) attn_fused_kernel(const float* __restrict
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       if (k0 + sub * 16 >= T) break;  // uniform
-      f32x4 sT = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 sT[AT_NQ];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks)
-        sT = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(4 * ks + g) * AT_LDQ + sub * 16 + l15], qf[ks], sT, 0, 0, 0);
-      // sT[r] = S[query l15][key k0 + sub*16 + 4g + r]
-      float mx = -INFINITY;
+      for (int j = 0; j < AT_NQ; ++j) sT[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (k0 + sub * 16 + 4 * g + r >= T) sT[r] = -INFINITY;
-        mx = fmaxf(mx, sT[r]);
+      for (int ks = 0; ks < 16; ++ks) {
+        const float kf = Ks[(4 * ks + g) * AT_LDQ + sub * 16 + l15];
+#pragma unroll
+        for (int j = 0; j < AT_NQ; ++j) sT[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, qf[j][ks], sT[j], 0, 0, 0);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float mn = fmaxf(m, mx);  // finite: the sub-tile has at least one valid key
-      const float alpha = expf(m - mn);
-      float p[4], ps = 0.f;
+      // sT[j][r] = S[query l15 of group j][key k0 + sub*16 + 4g + r]
+      float p[AT_NQ][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p[r] = expf(sT[r] - mn);
-        ps += p[r];
-      }
-      ps += __shfl_xor(ps, 16);
-      ps += __shfl_xor(ps, 32);
-      l = l * alpha + ps;
-      m = mn;
+      for (int j = 0; j < AT_NQ; ++j) {
+        float mx = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha;
+        for (int r = 0; r < 4; ++r) {
+          if (k0 + sub * 16 + 4 * g + r >= T) sT[j][r] = -INFINITY;
+          mx = fmaxf(mx, sT[j][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m[j], mx);  // finite: the sub-tile has at least one valid key
+        const float alpha = expf(m[j] - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[j][r] = expf(sT[j][r] - mn);
+          ps += p[j][r];
+        }
+        ps += __shfl_xor(ps, 16);
+        ps += __shfl_xor(ps, 32);
+        l[j] = l[j] * alpha + ps;
+        m[j] = mn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[j][i][0] *= alpha; o[j][i][1] *= alpha; o[j][i][2] *= alpha; o[j][i][3] *= alpha;
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
-          o[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(i * 16 + l15) * AT_LDV + sub * 16 + 4 * g + st], p[st], o[i], 0, 0, 0);
+        for (int st = 0; st < 4; ++st) {
+          const float vf = Vs[(i * 16 + l15) * AT_LDV + sub * 16 + 4 * g + st];
+#pragma unroll
+          for (int j = 0; j < AT_NQ; ++j)
+            o[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, p[j][st], o[j][i], 0, 0, 0);
+        }
     }
   }
-  // o[i][r] = O[d = i*16 + 4g + r][query = wave*16 + l15] (unnormalised)
-  const int q = q0 + wave * 16 + l15;
-  if (q < T) {
-    const float inv = 1.f / l;
-    float* ob = out + ((size_t)b * D + (size_t)h * hd) * ld + q;
+  // o[j][i][r] = O[d = i*16 + 4g + r][query = (wave*AT_NQ + j)*16 + l15] (unnormalised)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < AT_NQ; ++j) {
+    const int q = q0 + (wave * AT_NQ + j) * 16 + l15;
+    if (q < T) {
+      const float inv = 1.f / l[j];
+      float* ob = out + ((size_t)b * D + (size_t)h * hd) * ld + q;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ob[(size_t)(i * 16 + 4 * g + r) * ld] = o[i][r] * inv;
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ob[(size_t)(i * 16 + 4 * g + r) * ld] = o[j][i][r] * inv;
+    }
   }
 }
 
