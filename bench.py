@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 MFMA)
 HBM_PEAK_GBPS = 8000.0         # same guide: HBM3E ~8 TB/s
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 (no sparsity)
 
 
 def cpu_baseline(synth, sd, code, f0, spkr, budget_s=12.0, max_utts=400):
@@ -82,7 +83,7 @@ class _FakeEvent:
         return (other.t - self.t) * 1e3
 
 
-def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_sec_per_step):
+def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_sec_per_step, flops_step):
     """The opt-in split-bf16 ("bf16x3") arithmetic mode of the same generator, timed on the same
     batch right after the fp32 run and checked against the fp32 waveform (north_star bar: 1e-4 RMS).
     Reported next to the headline number, never instead of it."""
@@ -103,7 +104,11 @@ def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_se
     return {"arithmetic": "bf16 hi/lo operand split, 3 bf16 MFMAs per product, fp32 accumulate "
                           "(CodeGenerator(h, precision='split_bf16') / dissc_set_option('precision', 1); default is exact fp32)",
             "ms_per_step": round(dt * 1e3, 3), "value": round(audio_sec_per_step / dt, 1),
-            "unit": "audio-sec/sec", "rms_vs_fp32": float(err.pow(2).mean().sqrt()),
+            "unit": "audio-sec/sec",
+            # 3 bf16 MFMA products per algorithmic multiply-add, against the dense bf16 peak
+            "roofline": {"bound": "mfma", "achieved": round(3 * flops_step / dt / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s (bf16)", "frac": round(3 * flops_step / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)},
+            "rms_vs_fp32": float(err.pow(2).mean().sqrt()),
             "max_abs_vs_fp32": float(err.abs().max()), "tolerance_rms": 1e-4}
 
 
@@ -246,7 +251,7 @@ def main():
                                       "frac": round(gbps / HBM_PEAK_GBPS, 4)}
         if not a.no_split_bf16 and n_gpus == 1 and not fake:
             out["split_bf16"] = split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y, a.steps,
-                                               audio_sec_per_step)
+                                               audio_sec_per_step, flops_step)
         if not a.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(synth, sd, torch.from_numpy(code), torch.from_numpy(f0),
                                                torch.from_numpy(spkr))
