@@ -3,7 +3,7 @@
 of the HIP generator on 10 s x batch-32 utterances per GPU (BASELINE.json metric,
 configs[2] workload: "Batch-32 VCTK val-set resynthesis only").
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: spawns N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one pass of the generator over one batch of 32 synthetic 10 s utterances
@@ -28,35 +28,65 @@ HBM_PEAK_GBPS = 8000.0         # same guide: HBM3E ~8 TB/s
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 (no sparsity)
 
 
-def cpu_baseline(synth, sd, code, f0, spkr, budget_s=12.0, max_utts=400):
+def host_cpu_info():
+    """(physical cores usable by this process, logical CPUs usable, model name) from lscpu / the affinity mask."""
+    import subprocess
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    model, phys = "unknown", None
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=20).stdout
+        for ln in txt.splitlines():
+            if ln.startswith("Model name:"):
+                model = ln.split(":", 1)[1].strip()
+        # physical cores among the CPUs we may run on: distinct (socket, core) pairs
+        rows = subprocess.run(["lscpu", "-p=CPU,CORE,SOCKET"], capture_output=True, text=True, timeout=20).stdout
+        cores = set()
+        for ln in rows.splitlines():
+            if ln.startswith("#") or not ln.strip():
+                continue
+            cpu, core, sock = (ln.split(",") + ["0", "0"])[:3]
+            if int(cpu) in avail:
+                cores.add((sock, core))
+        phys = len(cores) or None
+    except Exception:
+        pass
+    return phys or len(avail), len(avail), model
+
+
+def cpu_baseline(synth, sd, code, f0, spkr, budget_s=14.0, max_utts=400):
     """The CPU oracle (kind='port': plain-PyTorch restatement pinned to the reference,
-    tests/test_oracle_golden.py) timed the way the reference runs: B=1 per utterance,
-    all host cores.  Bounded sample of the same workload."""
+    tests/test_oracle_golden.py) timed the way the reference runs: B=1 per utterance on the host
+    cores.  Bounded sample of the same workload: thread count picked by a probe on a full 10 s
+    utterance, then 3 warm-ups and >= 5 timed utterances; the value is 10 s / median time."""
     from oracle import generator_ref as gr
     w = gr.fold_state_dict(sd)
-    # Host cores actually usable (cgroup/affinity aware); oneDNN degrades badly when
-    # oversubscribed, so probe a few thread counts on a short utterance and keep the best.
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    phys, logical, model = host_cpu_info()
+    one = lambda b: gr.code_generator(w, synth.VCTK_CONFIG, code[b:b + 1], f0[b:b + 1], spkr[b:b + 1])
+    # oneDNN degrades when oversubscribed: probe the physical and the logical count (and a few below)
     best, threads = None, 1
-    for th in sorted({min(avail, c) for c in (8, 16, 32, 64, avail)}):
+    for th in sorted({min(logical, c) for c in (8, 16, 32, phys, logical)}):
         torch.set_num_threads(th)
-        gr.code_generator(w, synth.VCTK_CONFIG, code[:1, :60], f0[:1, :, :60], spkr[:1])  # warm-up
+        one(0)  # warm-up at this thread count
         t = time.perf_counter()
-        gr.code_generator(w, synth.VCTK_CONFIG, code[:1, :60], f0[:1, :, :60], spkr[:1])
+        one(0)
         t = time.perf_counter() - t
         if best is None or t < best:
             best, threads = t, th
     torch.set_num_threads(threads)
-    n, t0 = 0, time.perf_counter()
-    while n < max_utts and (time.perf_counter() - t0 < budget_s or n == 0):
-        b = n % code.shape[0]
-        gr.code_generator(w, synth.VCTK_CONFIG, code[b:b + 1], f0[b:b + 1], spkr[b:b + 1])
-        n += 1
-    dt = time.perf_counter() - t0
-    sec = n * code.shape[1] * 320 / 16000.0
-    return {"value": round(sec / dt, 2), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
-            "sample": f"{n} x 10 s utterances, B=1 each (reference style), torch CPU fp32, "
-                      f"{threads} threads (best of a probe; {avail} logical CPUs available), {dt:.1f} s wall"}
+    for b in range(3):
+        one(b % code.shape[0])
+    times, t0 = [], time.perf_counter()
+    while len(times) < max_utts and (len(times) < 5 or time.perf_counter() - t0 < budget_s):
+        t = time.perf_counter()
+        one(len(times) % code.shape[0])
+        times.append(time.perf_counter() - t)
+    sec = code.shape[1] * 320 / 16000.0
+    med = float(np.median(times))
+    return {"value": round(sec / med, 2), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
+            "physical_cores": phys, "logical_cpus": logical, "cpu_model": model,
+            "sample": f"{len(times)} x {sec:g} s utterances, B=1 each (reference style), torch CPU fp32, {threads} threads "
+                      f"(best of a probe on a full utterance), 3 warm-ups, median of {len(times)} "
+                      f"(mean rate {sec * len(times) / sum(times):.2f}), {sum(times):.1f} s of CPU work"}
 
 
 class _FakeGenerator:
@@ -137,6 +167,18 @@ def main():
     # DISSC_BENCH_FAKE=1: CPU/gloo dry run of the distributed bookkeeping only (tests/test_bench_dist.py);
     # it measures nothing and never replaces the HIP path in a real run.
     fake = os.environ.get("DISSC_BENCH_FAKE") == "1"
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec this same command under
+        # torch.distributed.run, one rank per GPU (the launch line the driver itself uses for N > 1).
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -158,6 +200,12 @@ def main():
             kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
             dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     n_gpus = world
+    if n_gpus != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N spawns them itself)")
+    if not fake and world > 1 and os.environ.get("DISSC_BENCH_BACKEND", "nccl") == "nccl" \
+            and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, {torch.cuda.device_count()} visible")
     import synthdata as synth  # deterministic synthetic checkpoints / inputs
     sd = synth.synth_generator_state_dict(seed=0)
     if fake:

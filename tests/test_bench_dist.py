@@ -29,3 +29,26 @@ def test_bench_two_ranks_gloo_dry_run():
     # whole-job aggregate: 2 ranks x 4 utterances x 20 frames x 20 ms per step
     assert abs(j["value"] * j["ms_per_step"] / 1e3 - 2 * 4 * 20 * 0.02) < 1e-3 * 2 * 4 * 20 * 0.02 + 1e-2
     assert "cpu_baseline" not in j and j["roofline"]["bound"] == "mfma"
+
+
+def test_bench_gpus_flag_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (how the driver runs N=1, and how a user would ask
+    for N GPUs) must spawn 2 ranks itself and report n_gpus == 2 -- never time one GPU silently."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DISSC_BENCH_FAKE"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--frames", "10"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2"
+
+
+def test_bench_refuses_world_size_mismatch():
+    env = dict(os.environ, DISSC_BENCH_FAKE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--batch", "1", "--frames", "10"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "--gpus 2" in (r.stdout + r.stderr)
