@@ -48,10 +48,13 @@ def collect_speaker_f0(data_path):
     return by_spk
 
 
-def calculate_pitch_stats(data_path, out_path, device="cuda:0"):
+def calculate_pitch_stats(data_path, out_path, device="cuda:0", allow_unvoiced=False):
     """{speaker: {'mean', 'std'}} of the voiced frames (f0 != 0), pickled to ``out_path``
-    (reference data/data_utils.py:33-46; np.float64 scalars, population std)."""
+    (reference data/data_utils.py:33-46; np.float64 scalars, population std).
+    A speaker without any voiced frame raises (nothing is written) unless ``allow_unvoiced``:
+    the reference would pickle NaN statistics that poison every later stage silently."""
     from dissc_amd.stats import pitch_stats
-    stats = pitch_stats(collect_speaker_f0(data_path), device=device)
+    stats = pitch_stats(collect_speaker_f0(data_path), device=device,
+                        on_unvoiced="nan" if allow_unvoiced else "raise")
     with open(out_path, "wb") as f_out:
         pickle.dump(stats, f_out)

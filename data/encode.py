@@ -6,11 +6,11 @@ data/encode.py:11-41): one line ``{"units": [...], "f0": [...], "durations": [..
 "audio": file}`` per wav in ``--base_dir`` (os.listdir order), appended to ``--out_file``.
 
 Differences in execution: files are encoded in length-sorted batches through the HIP encoder
-(per-utterance exact) instead of one B=1 call each, and written in listdir order afterwards.
+(per-utterance exact) instead of one B=1 call each; lines are appended batch by batch.
 Checkpoints are not downloaded (no network): ``--checkpoint_dir`` / $DISSC_CHECKPOINT_DIR must
 hold ``<model_name>.pt`` and ``<quantizer_name>_<vocab_size>.{npy,bin,pt}``.
-``f0`` is written as zeros: the YAAPT tracker is off the --pred_pitch path,
-where infer.py never reads it (reference infer.py:36-39,149-155).
+``--f0 zeros`` (explicit, with a warning) writes an all-unvoiced track, valid only for the
+--pred_pitch flows where infer.py never reads it (reference infer.py:36-39,149-155).
 """
 import argparse
 import json
@@ -43,6 +43,21 @@ def load_wav(path):
     return x, sr
 
 
+def wav_frames(path):
+    """sample count from the header (falls back to reading the file)"""
+    import wave
+    try:
+        with wave.open(path, "rb") as w:
+            return w.getnframes()
+    except (wave.Error, EOFError):
+        return len(load_wav(path)[0])
+
+
+def track_f0(wav, ns, frames, args):
+    """F0 per unit frame for a batch: list of lists, 0.0 = unvoiced."""
+    raise NotImplementedError("--f0 yaapt: the F0 tracker is not built yet")
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument('--model_name', default='hubert-base-ls960', help='Name for pretrained dense model name')
@@ -53,45 +68,55 @@ def main(argv=None):
     parser.add_argument('--device', default='cuda:0', help='Device to run on')
     parser.add_argument('--checkpoint_dir', default=None, help='local directory with the HuBERT / k-means files')
     parser.add_argument('--batch_seconds', default=640.0, type=float, help='audio seconds per GPU batch')
+    parser.add_argument('--f0', default='zeros', choices=['zeros', 'yaapt'],
+                        help="'yaapt': track F0 like the reference's encoder does; 'zeros': write an all-unvoiced "
+                             "track (only valid for the --pred_pitch flows, which never read it)")
     args = parser.parse_args(argv)
 
+    if args.f0 == 'zeros':
+        print("WARNING: data/encode.py --f0 zeros writes an all-zero (fully unvoiced) 'f0' track. It is only valid "
+              "as input to `infer.py --pred_pitch` (which predicts F0 and never reads it); data/prep_dataset.py "
+              "and resynthesis of the source pitch need --f0 yaapt.", file=sys.stderr)
     from dissc_amd.hubert import SpeechEncoder
     encoder = SpeechEncoder.by_name(dense_model_name=args.model_name, quantizer_model_name=args.quantizer_name,
                                     vocab_size=args.vocab_size, deduplicate=False,
                                     checkpoint_dir=args.checkpoint_dir).to(args.device)
     os.makedirs(Path(args.out_file).parent.absolute(), exist_ok=True)
     files = os.listdir(args.base_dir)
-    waves = {}
+    # Pass 1: sample counts only (wav headers), so the batches can be formed without holding every
+    # waveform in memory; pass 2 loads one batch at a time.
+    lengths = {}
     for f in files:
-        x, sr = load_wav(os.path.join(args.base_dir, f))
-        if len(x) < 400:
+        n = wav_frames(os.path.join(args.base_dir, f))
+        if n < 400:
             print(f"\nProblem encoding sample {f}: shorter than one HuBERT frame")
             continue
-        waves[f] = x
-    order = sorted(waves, key=lambda f: -len(waves[f]))
-    results = {}
+        lengths[f] = n
+    order = sorted(lengths, key=lambda f: (-lengths[f], f))
+    # Lines are appended per batch (a failure keeps what was already encoded, like the reference's
+    # per-file append), i.e. in length-sorted order rather than listdir order -- the file is a set of
+    # independent lines keyed by 'audio' for every consumer.
     i = 0
     while i < len(order):
-        n0 = len(waves[order[i]])
+        n0 = lengths[order[i]]
         bsz = max(1, int(args.batch_seconds * 16000 // n0))
         batch = order[i:i + bsz]
         i += len(batch)
         wav = np.zeros((len(batch), n0), dtype=np.float32)
         ns = np.zeros(len(batch), dtype=np.int32)
         for k, f in enumerate(batch):
-            wav[k, :len(waves[f])] = waves[f]
-            ns[k] = len(waves[f])
+            x, sr = load_wav(os.path.join(args.base_dir, f))
+            wav[k, :len(x)] = x
+            ns[k] = len(x)
         out = encoder.model(torch.from_numpy(wav), n_samples=torch.from_numpy(ns), want_dense=False)
         units = out["units"].cpu()
-        for k, f in enumerate(batch):
-            T = int(out["frames"][k])
-            results[f] = units[k, :T].tolist()
-    with open(args.out_file, 'a+') as fo:
-        for f in files:
-            if f not in results:
-                continue
-            u = results[f]
-            fo.write(json.dumps({"units": u, "f0": [0.0] * len(u), "durations": [1] * len(u), "audio": f}) + "\n")
+        f0s = track_f0(wav, ns, [int(t) for t in out["frames"]], args) if args.f0 == 'yaapt' else None
+        with open(args.out_file, 'a+') as fo:
+            for k, f in enumerate(batch):
+                T = int(out["frames"][k])
+                u = units[k, :T].tolist()
+                f0 = f0s[k] if f0s is not None else [0.0] * T
+                fo.write(json.dumps({"units": u, "f0": f0, "durations": [1] * T, "audio": f}) + "\n")
 
 
 if __name__ == '__main__':

@@ -27,6 +27,9 @@ def build_parser():
     ap.add_argument("--split_method", default=None,
                     help="'random' or 'paired_val'; omit to treat the whole file as training data")
     ap.add_argument("--device", default="cuda:0", help="GPU that reduces the statistics (extension)")
+    ap.add_argument("--allow_unvoiced", action="store_true",
+                    help="(extension) pickle NaN statistics for a speaker without voiced frames like the "
+                         "reference does, instead of failing")
     return ap
 
 
@@ -39,7 +42,7 @@ def main(argv=None):
     train_path = args.encoded_path
     if args.split_method:
         train_path, _ = data_split(args.encoded_path, split_method=args.split_method)
-    calculate_pitch_stats(train_path, args.stats_path, device=args.device)
+    calculate_pitch_stats(train_path, args.stats_path, device=args.device, allow_unvoiced=args.allow_unvoiced)
 
 
 if __name__ == "__main__":

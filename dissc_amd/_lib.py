@@ -75,7 +75,7 @@ def _load():
     L.dissc_pred_workspace_bytes.restype = ctypes.c_size_t
     L.dissc_len_set_norm.argtypes = [vp, ctypes.c_float, ctypes.c_float]
     L.dissc_len_forward.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, vp, ctypes.c_size_t, vp]
-    L.dissc_pitch_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp,
+    L.dissc_pitch_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, i32, vp,
                                       ctypes.c_size_t, vp]
     L.dissc_dedup.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     L.dissc_len_carryover.argtypes = [vp, vp, i32, i32, vp, vp, vp]
@@ -94,6 +94,9 @@ def _load():
     L.dissc_conv_bench.argtypes = [i32] * 9 + [ctypes.POINTER(ctypes.c_float)]
     L.dissc_wav_postprocess.argtypes = [vp, vp, i32, i32, vp]
     L.dissc_pitch_stats.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    i64 = ctypes.c_longlong
+    L.dissc_pack_waves.argtypes = [vp, i64, vp, vp, i32, vp, i64, i32, vp]
+    L.dissc_pack_empty_rows.argtypes = [vp, i64, i32, i32, vp]
     return L
 
 

@@ -32,6 +32,7 @@ __global__ void hubert_lengths_kernel(const int32_t* __restrict__ n_samples, int
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   int n = n_samples ? n_samples[b] : n_default;
+  n = n < 0 ? 0 : (n > n_default ? n_default : n);  // never read past the row (host validates and raises)
   for (int l = 0; l < NCONV; ++l) {
     n = n >= c_k[l] ? (n - c_k[l]) / c_s[l] + 1 : 0;
     lens[l * B + b] = n;

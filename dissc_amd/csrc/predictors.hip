@@ -49,8 +49,8 @@ __global__ void pitch_head_kernel(const float* __restrict__ h, const float* __re
                                   const float* __restrict__ wr, float bc, float br,
                                   const int32_t* __restrict__ lengths, const int64_t* __restrict__ spk,
                                   const float* __restrict__ id2mean, const float* __restrict__ id2std,
-                                  int norm, int T, int ld, int C, float slope, float* __restrict__ out,
-                                  int ldo) {
+                                  int n_stats, int norm, int T, int ld, int C, float slope,
+                                  float* __restrict__ out, int ldo) {
   const int b = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int len = lengths ? lengths[b] : T;
@@ -72,7 +72,8 @@ __global__ void pitch_head_kernel(const float* __restrict__ h, const float* __re
   cls += bc;
   reg += br;
   if (!norm) {
-    const long long s = spk[b];
+    long long s = spk[b];  // ids are validated on the host; clamp like the embedding lookups do
+    s = s < 0 ? 0 : (s >= n_stats ? n_stats - 1 : s);
     reg = id2mean[s] + reg * id2std[s];
   }
   out[(size_t)b * ldo + t] = (cls > 0.f ? 1.f : 0.f) * reg;
@@ -405,10 +406,10 @@ int dissc_len_set_norm(dissc_pred_t p, float mean, float std) {
 
 int dissc_pitch_forward(dissc_pred_t p, const int64_t* seq, const int64_t* spk,
                         const int32_t* lengths, int B, int Tmax, int norm, const float* id2mean,
-                        const float* id2std, float* out, int ldo, void* ws, size_t ws_bytes,
-                        void* stream_) {
+                        const float* id2std, int n_stats, float* out, int ldo, void* ws,
+                        size_t ws_bytes, void* stream_) {
   if (!p || p->kind == 0 || !seq || !spk || !out || !ws || B <= 0 || Tmax <= 0 || ldo < Tmax ||
-      (!norm && (!id2mean || !id2std))) {
+      (!norm && (!id2mean || !id2std || n_stats <= 0))) {
     set_error("dissc_pitch_forward: bad argument");
     return DISSC_EINVAL;
   }
@@ -428,7 +429,7 @@ int dissc_pitch_forward(dissc_pred_t p, const int64_t* seq, const int64_t* spk,
   if (rc) return rc;
   dim3 grid((Tmax + 127) / 128, B);
   hipLaunchKernelGGL(pitch_head_kernel, grid, dim3(128), 0, stream, heads, p->wc, p->wr, p->bc, p->br,
-                     lengths, spk, id2mean, id2std, norm, Tmax, ld, p->C, 0.01f, out, ldo);
+                     lengths, spk, id2mean, id2std, n_stats, norm, Tmax, ld, p->C, 0.01f, out, ldo);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }

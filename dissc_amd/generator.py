@@ -229,9 +229,22 @@ class CodeGenerator:
                 code = self._upsample(code.unsqueeze(1), f0.shape[-1]).squeeze(1)
             elif f0.shape[-1] != code.shape[-1]:
                 f0 = self._upsample(f0, code.shape[-1])
+            if f0.shape[-1] != code.shape[-1] or f0.shape[0] != code.shape[0] or f0.shape[1] != 1:
+                # the reference fails here too (torch.cat of mismatched lengths, sr/models.py:213-215);
+                # the kernels index f0[b*T + t] and must never see a shorter row
+                raise RuntimeError(f"Sizes of tensors must match: code {tuple(code.shape)} vs f0 {tuple(f0.shape)} "
+                                   "after conditioning upsample")
             f0 = f0.reshape(code.shape[0], -1).contiguous()
         code = code.contiguous()
         B, T = code.shape
+        for name, t, rows in (("code", kwargs["code"], int(self.h.num_embeddings)),
+                              ("spkr", kwargs.get("spkr") if self.multispkr else None, 200)):
+            # nn.Embedding raises IndexError on a bad id (reference sr/models.py:189,207); checked for
+            # host tensors (ids read from files), device-resident ids come from our own kernels
+            if t is not None and t.device.type == "cpu" and t.numel():
+                lo, hi = int(t.min()), int(t.max())
+                if lo < 0 or hi >= rows:
+                    raise IndexError(f"{name} id out of range: [{lo}, {hi}] not within [0, {rows})")
         spkr = None
         if self.multispkr:
             spkr = kwargs["spkr"].to(dev, torch.int64).reshape(-1).contiguous()

@@ -1,18 +1,22 @@
-"""Data-parallel resynthesis harness: shard jobs over ranks, batch them, and return every
-waveform to rank 0 with ONE all-gather.
+"""Data-parallel harness: shard jobs over ranks, batch them, and return every waveform to rank 0
+with ONE all-gather.
 
 Replaces the reference's ``multiprocessing.Pool(8)`` of B=1 workers writing their own files
 (reference sr/inference.py:288-292,351-354): one process per GPU (torchrun env), each rank
 batches its share through ``dissc_amd.CodeGenerator`` and the decoded waveforms of all ranks are
-exchanged with a single ``all_gather_into_tensor`` of a packed ``[n_max, 2 + L_max]`` buffer
-(col 0 = job id, col 1 = sample count -- int32 bit patterns in the fp32 buffer -- then samples).
-Utterances are independent, so there is no other collective on the data path.
+exchanged with a single ``all_gather_into_tensor`` of a packed ``[n_max, 4 + L_max]`` fp32 buffer
+(row = [job id | sample count | 0 | 0] as int32 bit patterns, then the samples; layout and the
+pack kernel: include/dissc_hip.h ``dissc_pack_waves``).  Utterances are independent, so there is
+no other collective on the data path.  The buffer is packed on the device by one kernel launch per
+generator batch; only the ranks that consume the result (rank 0 by default) copy it to the host.
 
-Everything here is host logic; it runs on CPU tensors with the gloo backend in the tests and on
-CUDA tensors over RCCL/xGMI in production.
+Everything here is host logic; it runs on CPU tensors with the gloo backend in the tests (there the
+rows are packed with torch copies) and on CUDA tensors over RCCL/xGMI in production.
 """
 import numpy as np
 import torch
+
+HDR = 4  # header floats per packed row (16 B: keeps the samples 16-byte aligned)
 
 
 def lpt_shard(lengths, world_size):
@@ -53,57 +57,152 @@ def pack_geometry(lengths, parts, hop):
     return n_max, l_max
 
 
+def row_floats(l_max):
+    return HDR + (int(l_max) + 3) // 4 * 4
+
+
+class WaveStore:
+    """The decoded waveforms of one rank, kept on the device as the generator produced them:
+    a list of batches (wav [B, ld], n_samples i32 [B], job ids i32 [B])."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.batches = []
+        self.n = 0
+
+    def add(self, wav, n_samples, job_ids):
+        """wav f32 [B,1,L] or [B,L]; n_samples int [B] (host or device); job_ids: ints [B]"""
+        w2 = wav.view(wav.shape[0], -1)
+        ns = torch.as_tensor(n_samples).to(self.device, torch.int32).contiguous()
+        ids = torch.as_tensor(np.asarray(job_ids, dtype=np.int32)).to(self.device)
+        assert ns.numel() == w2.shape[0] == ids.numel()
+        self.batches.append((w2, ns, ids))
+        self.n += w2.shape[0]
+
+    def add_empty(self, job_ids):
+        k = len(job_ids)
+        if k:
+            self.add(torch.zeros(k, 4, dtype=torch.float32, device=self.device), np.zeros(k, np.int32), job_ids)
+
+    def pack(self, n_max, l_max):
+        """-> f32 [n_max, 4 + l_max (rounded up to 4)] on the device."""
+        if self.n > n_max:
+            raise ValueError(f"{self.n} waveforms do not fit {n_max} rows")
+        ld = row_floats(l_max)
+        buf = torch.empty(max(n_max, 1), ld, dtype=torch.float32, device=self.device)[:n_max]
+        row = 0
+        if self.device.type == "cuda":
+            from ._lib import check, current_stream_ptr, lib
+            with torch.cuda.device(self.device):
+                st = current_stream_ptr(self.device)
+                for w2, ns, ids in self.batches:
+                    check(lib.dissc_pack_waves(w2.data_ptr(), w2.stride(0), ns.data_ptr(), ids.data_ptr(),
+                                               w2.shape[0], buf.data_ptr(), ld, row, st), "dissc_pack_waves")
+                    row += w2.shape[0]
+                check(lib.dissc_pack_empty_rows(buf.data_ptr(), ld, row, n_max - row, st), "dissc_pack_empty_rows")
+        else:  # gloo/CPU rehearsal of the same layout (tests)
+            buf.zero_()
+            hdr = buf.view(torch.int32)
+            hdr[:, 0] = -1
+            for w2, ns, ids in self.batches:
+                for k in range(w2.shape[0]):
+                    n = min(int(ns[k]), ld - HDR)
+                    hdr[row, 0] = int(ids[k])
+                    hdr[row, 1] = n
+                    buf[row, HDR:HDR + n] = w2[k, :n]
+                    row += 1
+        return buf
+
+
 def pack_waves(waves, job_ids, n_max, l_max, device):
-    """waves: list of 1-D float tensors (device); -> f32 [n_max, 2 + l_max]."""
-    buf = torch.zeros(n_max, 2 + l_max, dtype=torch.float32, device=device)
-    hdr = buf.view(torch.int32)
-    hdr[:, 0] = -1
-    for k, (w, j) in enumerate(zip(waves, job_ids)):
-        n = int(w.numel())
-        hdr[k, 0] = int(j)
-        hdr[k, 1] = n
-        buf[k, 2:2 + n] = w.reshape(-1)
-    return buf
+    """waves: list of 1-D float tensors; -> packed f32 [n_max, 4 + l_max] (one row per waveform)."""
+    st = WaveStore(device)
+    for w, j in zip(waves, job_ids):
+        w = w.reshape(1, -1).to(st.device, torch.float32)
+        n = w.shape[1]
+        if n == 0:
+            st.add_empty([j])
+        else:
+            st.add(w.contiguous(), [n], [j])
+    return st.pack(n_max, l_max)
 
 
-def unpack_waves(gathered, world_size, n_max):
-    """gathered f32 [world*n_max, 2+l_max] -> {job_id: 1-D float32 numpy array}"""
-    g = gathered.cpu()
-    hdr = g.view(torch.int32)
+def unpack_waves(gathered, copy=True):
+    """packed f32 [rows, 4+l_max] (any device) -> {job_id: 1-D float32 numpy array}.  One D2H copy
+    of the whole buffer (into pinned memory for a CUDA tensor), then per-row slices."""
+    if gathered.is_cuda:
+        host = torch.empty(gathered.shape, dtype=gathered.dtype, pin_memory=True)
+        host.copy_(gathered, non_blocking=False)
+    else:
+        host = gathered
+    g = host.numpy()
+    hdr = g.view(np.int32)[:, :2]
     out = {}
-    for r in range(world_size * n_max):
-        j = int(hdr[r, 0])
-        if j < 0:
-            continue
-        n = int(hdr[r, 1])
-        out[j] = g[r, 2:2 + n].numpy().copy()
+    for r in np.nonzero(hdr[:, 0] >= 0)[0]:
+        w = g[r, HDR:HDR + hdr[r, 1]]
+        out[int(hdr[r, 0])] = w.copy() if copy else w
     return out
 
 
-def gather_waves(local_waves, local_ids, lengths, parts, hop, rank, world_size, device, dist=None):
-    """The single collective of the path.  Returns {job_id: samples} (on every rank)."""
+def gather_store(store, n_max, l_max, rank, world_size, dist=None, unpack_ranks=(0,)):
+    """The single collective of the path.  Returns {job_id: samples} on the ranks in ``unpack_ranks``
+    (None = every rank), {} elsewhere -- only the consumers pay the device-to-host copy."""
+    buf = store.pack(n_max, l_max)
+    if world_size > 1:
+        out = torch.empty(world_size * n_max, buf.shape[1], dtype=torch.float32, device=buf.device)
+        dist.all_gather_into_tensor(out, buf)
+        buf = out
+    if unpack_ranks is not None and rank not in unpack_ranks:
+        return {}
+    return unpack_waves(buf)
+
+
+def gather_waves(local_waves, local_ids, lengths, parts, hop, rank, world_size, device, dist=None,
+                 unpack_ranks=None):
+    """List-of-tensors front end of gather_store (geometry from the global job list)."""
     n_max, l_max = pack_geometry(lengths, parts, hop)
-    buf = pack_waves(local_waves, local_ids, n_max, l_max, device)
+    st = WaveStore(device)
+    for w, j in zip(local_waves, local_ids):
+        if w.numel() == 0:
+            st.add_empty([j])
+        else:
+            st.add(w.reshape(1, -1).contiguous(), [w.numel()], [j])
+    return gather_store(st, n_max, l_max, rank, world_size, dist, unpack_ranks)
+
+
+def agree_geometry(n_local, l_local, world_size, device, dist=None):
+    """(n_max, l_max) over ranks when they cannot be derived from the job list (predicted durations
+    decide the output lengths): one 16-byte MAX all-reduce ahead of the waveform all-gather."""
     if world_size == 1:
-        return unpack_waves(buf, 1, n_max)
-    out = torch.empty(world_size * n_max, 2 + l_max, dtype=torch.float32, device=device)
-    dist.all_gather_into_tensor(out, buf)
-    return unpack_waves(out, world_size, n_max)
+        return int(n_local), int(l_local)
+    t = torch.tensor([int(n_local), int(l_local)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = t.cpu()
+    return int(t[0]), int(t[1])
 
 
 def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist=None, max_batch=32,
-                    max_frames=32 * 500, postprocess=None):
+                    max_frames=32 * 500, postprocess=None, unpack_ranks=(0,)):
     """jobs: list of dicts {code: int array [T], f0: float array [T], spkr: int}.
     Every rank runs its LPT share in length-bucketed batches; returns {job_id: float32 samples}
-    after the all-gather.  ``postprocess(wav[B,1,L], n_samples[B])`` runs on the GPU in place."""
+    after the all-gather (on ``unpack_ranks``; None = all).  ``postprocess(wav[B,1,L], n_samples[B])``
+    runs on the GPU in place."""
     lengths = [len(j["code"]) for j in jobs]
+    for j, job in enumerate(jobs):
+        if len(job["f0"]) != lengths[j]:
+            raise ValueError(f"job {j}: {lengths[j]} units but {len(job['f0'])} f0 values")
     parts = lpt_shard(lengths, world_size)
     mine = parts[rank]
     hop = int(np.prod(generator.h["upsample_rates"]))  # same on every rank, even one with no jobs
-    waves, ids = [], []
+    store = WaveStore(device)
     for batch in make_batches(mine, lengths, max_batch, max_frames):
         B = len(batch)
         T = max(lengths[i] for i in batch)
+        if T == 0:
+            # empty `units` lines: empty waveforms (the generator rejects T = 0).  Never abort one rank
+            # here -- the others would wait in the all-gather forever.
+            store.add_empty(batch)
+            continue
         code = np.zeros((B, T), dtype=np.int64)
         f0 = np.zeros((B, 1, T), dtype=np.float32)
         spkr = np.zeros((B, 1), dtype=np.int64)
@@ -117,9 +216,9 @@ def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist
         y = generator(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
                       lengths=torch.from_numpy(lens))
         assert y.shape[-1] == hop * T
+        ns = torch.from_numpy(lens * hop).to(store.device)
         if postprocess is not None:
-            postprocess(y, torch.from_numpy(lens * hop))
-        for k, i in enumerate(batch):
-            waves.append(y[k, 0, :lengths[i] * hop])
-            ids.append(i)
-    return gather_waves(waves, ids, lengths, parts, hop, rank, world_size, device, dist)
+            postprocess(y, ns)
+        store.add(y, ns, batch)
+    n_max, l_max = pack_geometry(lengths, parts, hop)
+    return gather_store(store, n_max, l_max, rank, world_size, dist, unpack_ranks)

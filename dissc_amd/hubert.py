@@ -145,7 +145,12 @@ class HubertEncoder:
         ldT = (T + 3) // 4 * 4
         ns = None
         if n_samples is not None:
-            ns = torch.as_tensor(n_samples).to(dev, torch.int32).contiguous()
+            ns = torch.as_tensor(n_samples)
+            if ns.numel() != B:
+                raise ValueError("n_samples must be [B]")
+            if ns.device.type == "cpu" and (int(ns.min()) < 0 or int(ns.max()) > N):
+                raise ValueError(f"n_samples must lie in [0, {N}] (row length of wav)")
+            ns = ns.to(dev, torch.int32).contiguous()
         with torch.cuda.device(dev):
             need = lib.dissc_hubert_workspace_bytes(self._handle, B, N)
             if self._ws is None or self._ws.numel() < need:

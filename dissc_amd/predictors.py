@@ -128,9 +128,24 @@ class _Predictor:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws, need
 
+    @staticmethod
+    def _check_ids(t, n_rows, what):
+        """nn.Embedding raises IndexError on an out-of-range id (the reference's behaviour for a
+        corrupt manifest / wrong speaker table); the kernels would clamp.  Checked for host tensors
+        (ids that come from files); device-resident ids come from our own kernels and are trusted."""
+        if t.device.type == "cpu" and t.numel():
+            lo, hi = int(t.min()), int(t.max())
+            if lo < 0 or hi >= n_rows:
+                raise IndexError(f"{what} id out of range: [{lo}, {hi}] not within [0, {n_rows})")
+
     def _prep(self, seq, spk_id, lengths):
         dev = self.device
-        seq = torch.as_tensor(seq).to(dev, torch.int64)
+        seq = torch.as_tensor(seq)
+        spk_id = torch.as_tensor(spk_id)
+        if lengths is None:
+            self._check_ids(seq, self._sd["token_emb.weight"].shape[0], "unit")
+        self._check_ids(spk_id, self._sd["spk_emb.weight"].shape[0], "speaker")
+        seq = seq.to(dev, torch.int64)
         if seq.dim() == 1:
             seq = seq.unsqueeze(0)
         seq = seq.contiguous()
@@ -201,6 +216,7 @@ class _PitchBase(_Predictor):
         if not norm:
             if self.id2pitch_mean is None:
                 raise ValueError("id2pitch_mean/std are needed for un-normalised pitch")
+            self._check_ids(torch.as_tensor(spk_id), len(self.id2pitch_mean), "speaker (id2pitch_mean)")
             if self._stats_dev is None:
                 self._stats_dev = (torch.as_tensor(self.id2pitch_mean).to(self.device, torch.float32).contiguous(),
                                    torch.as_tensor(self.id2pitch_std).to(self.device, torch.float32).contiguous())
@@ -212,7 +228,8 @@ class _PitchBase(_Predictor):
             check(lib.dissc_pitch_forward(self._handle, seq.data_ptr(), spk.data_ptr(),
                                           lengths.data_ptr() if lengths is not None else None, B, T,
                                           1 if norm else 0, mean.data_ptr() if mean is not None else None,
-                                          std.data_ptr() if std is not None else None, out.data_ptr(), ldo,
+                                          std.data_ptr() if std is not None else None,
+                                          int(mean.numel()) if mean is not None else 0, out.data_ptr(), ldo,
                                           ws.data_ptr(), need, _lib.current_stream_ptr(self.device)),
                   "dissc_pitch_forward")
         return out[:, :T]
@@ -288,9 +305,38 @@ def expand(vals, lens_int, n, t_out):
     return out
 
 
+def infer_batch(units, lengths, spk, len_model=None, pitch_model=None, norm_pitch=False):
+    """Device-resident ``_infer_sample`` for a ragged batch (reference infer.py:24-45): everything stays
+    in HBM, ONE host synchronisation (the expanded lengths, needed to size the outputs).
+
+    units i64 [B,T] (cuda; pad tokens already removed), lengths i32 [B] (cuda), spk i64 [B] or [B,1]
+    (cuda or host).  Returns a dict: ``units`` i64 [B,T'] / ``lengths`` i32 [B] (cuda) = the frame-rate
+    unit sequence after the rhythm model (the input when there is none), ``totals`` = the same lengths
+    on the host, ``f0`` f32 [B,T'] (cuda) or None, ``lens_int`` i32 [B,T] / ``n`` i32 [B] (cuda) = frames
+    per dedup'd unit or None."""
+    dev = units.device
+    B = units.shape[0]
+    spk = torch.as_tensor(spk).reshape(B, 1)
+    if len_model is not None:
+        vals, _, n = dedup(units, lengths)
+        lens = len_model(vals, spk, lengths=n)            # [B,T] (only the first n[b] are valid)
+        lens_int, totals = len_carryover_correction(lens.contiguous(), n)
+        tot = totals.cpu()                                # the one host sync of the batch
+        t_out = int(tot.max()) if B else 0
+        out_seq = expand(vals, lens_int, n, t_out)
+        out_len = totals
+    else:
+        out_seq, out_len, tot = units, lengths, lengths.cpu()
+        lens_int = n = None
+    f0 = None
+    if pitch_model is not None and B and int(tot.max()) > 0:
+        f0 = pitch_model.infer_freq(out_seq, spk, norm_pitch, lengths=out_len)
+    return {"units": out_seq, "lengths": out_len, "totals": tot, "f0": f0, "lens_int": lens_int, "n": n}
+
+
 def infer_samples(unit_seqs, spk_ids, len_model=None, pitch_model=None, norm_pitch=False, n_tokens=100,
                   device="cuda:0"):
-    """Batched ``_infer_sample`` for the --pred_len/--pred_pitch modes.
+    """Batched ``_infer_sample`` for the --pred_len/--pred_pitch modes (list front end of infer_batch).
 
     unit_seqs: list of 1-D int sequences (pad token n_tokens is dropped like infer.py:25);
     spk_ids: list of target speaker ids.  Returns a list of
@@ -302,30 +348,23 @@ def infer_samples(unit_seqs, spk_ids, len_model=None, pitch_model=None, norm_pit
     B = len(seqs)
     if B == 0:
         return []
+    for m in (len_model, pitch_model):
+        if m is not None and m._sd is not None:
+            for s in seqs:
+                m._check_ids(s, m._sd["token_emb.weight"].shape[0], "unit")
+            m._check_ids(torch.as_tensor(spk_ids), m._sd["spk_emb.weight"].shape[0], "speaker")
     lengths = torch.tensor([len(s) for s in seqs], dtype=torch.int32)
     T = max(int(lengths.max()), 1)
     units = torch.full((B, T), 0, dtype=torch.int64)
     for i, s in enumerate(seqs):
         units[i, :len(s)] = s
-    units, lengths = units.to(dev), lengths.to(dev)
-    spk = torch.as_tensor(spk_ids, dtype=torch.int64).reshape(B, 1).to(dev)
-    if len_model is not None:
-        vals, _, n = dedup(units, lengths)
-        lens = len_model(vals, spk, lengths=n)            # [B,T] (only the first n[b] are valid)
-        lens_int, totals = len_carryover_correction(lens.contiguous(), n)
-        tot = totals.cpu()                                # the one host sync of the batch
-        t_out = int(tot.max())
-        out_seq = expand(vals, lens_int, n, t_out)
-        out_len = totals
-    else:
-        out_seq, out_len, tot = units, lengths, lengths.cpu()
-        lens_int = n = None
-    f0 = None
-    if pitch_model is not None and int(tot.max()) > 0:
-        f0 = pitch_model.infer_freq(out_seq, spk, norm_pitch, lengths=out_len).cpu()
-    out_seq_c = out_seq.cpu()
-    lens_c = lens_int.cpu() if lens_int is not None else None
-    n_c = n.cpu() if n is not None else None
+    spk = torch.as_tensor(spk_ids, dtype=torch.int64).reshape(B, 1)
+    r = infer_batch(units.to(dev), lengths.to(dev), spk, len_model, pitch_model, norm_pitch)
+    tot = r["totals"]
+    out_seq_c = r["units"].cpu()
+    f0 = r["f0"].cpu() if r["f0"] is not None else None
+    lens_c = r["lens_int"].cpu() if r["lens_int"] is not None else None
+    n_c = r["n"].cpu() if r["n"] is not None else None
     res = []
     for i in range(B):
         k = int(tot[i])

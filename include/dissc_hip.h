@@ -178,10 +178,12 @@ int dissc_len_forward(dissc_pred_t p, const int64_t* seq, const int64_t* spk, co
                       int B, int Lmax, float* out, int ldo, void* workspace, size_t workspace_bytes,
                       void* stream);
 /* seq i64 [B,Tmax] frame-rate units -> out f32 [B,ldo]: (class_logit > 0) * f0; norm != 0 keeps
- * the speaker-normalised value, else f0*id2std[spk] + id2mean[spk] (device arrays). */
+ * the speaker-normalised value, else f0*id2std[spk] + id2mean[spk] (device arrays of n_stats
+ * entries; ids are clamped into them -- the Python wrapper raises IndexError first, like
+ * nn.Embedding does in the reference). */
 int dissc_pitch_forward(dissc_pred_t p, const int64_t* seq, const int64_t* spk,
                         const int32_t* lengths, int B, int Tmax, int norm, const float* id2mean,
-                        const float* id2std, float* out, int ldo, void* workspace,
+                        const float* id2std, int n_stats, float* out, int ldo, void* workspace,
                         size_t workspace_bytes, void* stream);
 /* Per-speaker F0 statistics over VOICED (non-zero) frames, fp64 (replaces reference
  * data/data_utils.py:33-46 calculate_pitch_stats, the step between data/encode.py and infer.py).
@@ -243,6 +245,20 @@ int dissc_pipe_overlap(int mfma_iters, int valu_iters, float* ms);
  * wav f32 [B,ld] (in place), lengths in SAMPLES per utterance.
  * ------------------------------------------------------------------------- */
 int dissc_wav_postprocess(float* wav, const int32_t* n_samples, int B, int ld, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Waveform exchange buffer (the payload of the path's single all-gather).
+ * Replaces: the per-worker file writes of the reference's Pool(8) (sr/inference.py:205-207,
+ * 249-251,288-292,351-354): every rank packs its decoded waveforms into rows of one
+ * f32 [n_rows, ld_buf] buffer, row = [job id (int32 bits) | sample count (int32 bits) | 0 | 0 |
+ * samples ... zero fill]; ld_buf = 4 + L_max rounded up to a multiple of 4.
+ * dissc_pack_waves copies the B utterances of one generator batch (wav f32 [B, ld_wav],
+ * n_samples/job_ids i32 [B], all device) into rows row0 .. row0+B-1; dissc_pack_empty_rows marks
+ * rows without a job (id -1).
+ * ------------------------------------------------------------------------- */
+int dissc_pack_waves(const float* wav, long long ld_wav, const int32_t* n_samples, const int32_t* job_ids,
+                     int B, float* buf, long long ld_buf, int row0, void* stream);
+int dissc_pack_empty_rows(float* buf, long long ld_buf, int row0, int rows, void* stream);
 
 #ifdef __cplusplus
 }

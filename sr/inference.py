@@ -47,13 +47,18 @@ def peak_normalize(x):
     return x / peak if peak >= np.finfo(np.float32).tiny else x
 
 
-def load_gt(path, code_len, pad=None):
-    """Ground-truth audio exactly as CodeDataset.__getitem__ prepares it in eval mode
-    (reference sr/dataset.py:221-264,199-219): int16 -> /32768 -> peak*0.95 -> trim to a whole
-    number of hops.  None when the wav is missing (the reference would crash)."""
+def load_gt(path, code_len, pad=None, sampling_rate=16000, code_hop_size=None):
+    """Ground-truth audio exactly as CodeDataset.__getitem__ prepares it (reference
+    sr/dataset.py:221-264,199-219): int16 -> /32768 -> peak*0.95 -> [eval_mode False only: trim to
+    min(len//code_hop_size, code_len) hops] -> trim to a whole number of hops.  None when the wav is
+    missing (the reference would crash).  A sample-rate mismatch raises: the reference resamples
+    with resampy (sr/dataset.py:225-227), which is not available to pin against."""
     if not os.path.isfile(path):
         return None
     sr, audio = wavfile.read(path)
+    if sr != sampling_rate:
+        raise ValueError(f"{path}: sample rate {sr} != {sampling_rate}; resample first "
+                         "(data/preprocess.py), the reference would resample with resampy here")
     if audio.dtype != np.int16:
         audio = (np.clip(audio, -1, 1) * 32767).astype(np.int16) if audio.dtype.kind == 'f' else audio.astype(np.int16)
     if audio.ndim > 1:
@@ -64,6 +69,9 @@ def load_gt(path, code_len, pad=None):
     peak = np.max(np.abs(audio))
     audio = (audio / peak if peak >= np.finfo(audio.dtype).tiny else audio) * 0.95
     audio = audio.astype(np.float32)
+    if code_hop_size:  # eval_mode False (reference sr/dataset.py:246-253)
+        code_len = min(audio.shape[0] // code_hop_size, code_len)
+        audio = audio[:code_len * code_hop_size]
     n = audio.shape[0]
     if code_len > 0 and n >= code_len:
         hop = n // code_len
@@ -110,6 +118,17 @@ def build_jobs(a, h, samples, id_to_spkr, f0_stats_cfg, target_f0_stats):
             stem = audio_path.stem
         code = np.asarray(s['units'], dtype=np.int64)
         f0 = np.asarray(s.get('f0', np.zeros(len(code))), dtype=np.float32).copy()
+        if len(f0) != len(code):
+            raise ValueError(f"{s['audio']}: {len(code)} units but {len(f0)} f0 values")
+        if not a.eval_mode:
+            # --eval_mode is store_false: when given, code and pitch are clipped to the ground-truth
+            # audio (reference sr/dataset.py:243-251); needs the wav like the reference does
+            hop = int(h.code_hop_size)
+            gt = load_gt(str(audio_path), len(code), a.pad, h.sampling_rate, hop)
+            if gt is None:
+                raise FileNotFoundError(f"--eval_mode needs the ground-truth audio {audio_path}")
+            code_len = min(len(gt) // hop, len(code))
+            code, f0 = code[:code_len], f0[:code_len]
         src_name = formats.speaker_of(str(audio_path))
         if h.get('f0_normalize', False) and f0_stats_cfg is not None:
             st = f0_stats_cfg.get(src_name, None)
@@ -243,7 +262,8 @@ def main(argv=None):
             wavfile.write(os.path.join(a.output_dir, job['out']), h.sampling_rate, waves[j])
         if a.sample_df is None:
             for stem, audio_path, code_len in items:
-                gt = load_gt(str(audio_path), code_len, a.pad)
+                gt = load_gt(str(audio_path), code_len, a.pad, h.sampling_rate,
+                             None if a.eval_mode else int(h.code_hop_size))
                 if gt is not None:
                     wavfile.write(os.path.join(a.output_dir, stem + '_gt.wav'), h.sampling_rate,
                                   peak_normalize(gt))

@@ -1,0 +1,270 @@
+"""BASELINE.json configs[1], [3], [4] on the GPU, checked against the ORACLE chain (not against this
+repo's own CLIs): the full encode -> predict -> resynthesise pipeline on 8 x 10 s utterances, a
+256-utterance ragged many-to-many sweep through the resynthesis harness, and the rank-sharded
+pipeline (2 ranks sharing this box's GPU over gloo) against the 1-rank run and the file-based chain.
+"""
+import importlib.util
+import json
+import os
+import shutil
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from scipy.io import wavfile
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, rel))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def models():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import synthdata as synth
+    import dissc_amd
+    from dissc_amd import predictors as P
+    from dissc_amd.hubert import HubertEncoder
+    m = {"hsd": synth.synth_hubert_state_dict(6), "centers": synth.synth_kmeans_centers(),
+         "lsd": synth.synth_len_state_dict(100, 108), "lstats": synth.synth_len_norm_stats(),
+         "psd": synth.synth_pitch_state_dict("new", 100, 108), "gsd": synth.synth_generator_state_dict(seed=0)}
+    m["enc"] = HubertEncoder(m["hsd"], m["centers"], 6).to(DEV)
+    lm = P.LenPredictor(100, 108).to(DEV)
+    lm.load_state_dict(m["lsd"])
+    lm.norm_mean, lm.norm_std = m["lstats"]
+    pm = P.PitchPredictor(100, 108).to(DEV)
+    pm.load_state_dict(m["psd"])
+    g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to(DEV)
+    g.load_state_dict(m["gsd"])
+    g.eval().remove_weight_norm()
+    m.update(lm=lm, pm=pm, g=g)
+    return m
+
+
+def _near_tie_frames(dense, centers, margin):
+    d = ((dense[:, None, :] - centers[None]) ** 2).sum(-1)
+    top2 = torch.topk(d, 2, largest=False).values
+    return ((top2[:, 1] - top2[:, 0]) <= margin).numpy()
+
+
+def test_cfg2_full_pipeline_8x10s_against_oracle_chain(models):
+    """configs[1]: 8 x 10 s utterances, encode -> (--pred_len --pred_pitch, target p231) -> resynth on
+    one GPU.  Stage by stage against oracle.hubert_ref.encode -> predictors_ref.infer_sample ->
+    generator_ref.code_generator on 2 utterances (each stage of the oracle is fed the HIP output of
+    the stage before, so that a legitimate k-means near-tie cannot hide a later difference); size-
+    independent properties and bitwise batch-independence on all 8."""
+    import synthdata as synth
+    from oracle import generator_ref as gr, hubert_ref as hr, predictors_ref as pr
+    from dissc_amd import predictors as P
+    from dissc_amd.pipeline import Converter
+    m = models
+    N, tgt = 160000, 6  # p231
+    waves = [synth.synth_waveform(N, seed=100 + i) for i in range(8)]
+    conv = Converter(m["enc"], m["lm"], m["pm"], m["g"])
+    raw = Converter(m["enc"], m["lm"], m["pm"], m["g"], postprocess=False)(waves, [tgt])
+    out = conv(waves, [tgt])
+    assert sorted(out) == [(i, tgt) for i in range(8)] == sorted(raw)
+
+    # stage outputs of the HIP path, utterance by utterance (the reference's B=1 mode)
+    enc = m["enc"](torch.from_numpy(np.stack(waves)), want_dense=True)
+    units_hip = enc["units"].cpu()
+    assert units_hip.shape == (8, 499)
+    gw = gr.fold_state_dict(m["gsd"])
+    for i in (0, 5):
+        # (1) units: every frame where HIP and the oracle disagree is a k-means near-tie of the oracle
+        u_ref, dense_ref = hr.encode(m["hsd"], m["centers"], torch.from_numpy(waves[i])[None])
+        rel = float((enc["dense"][i].cpu() - dense_ref).norm() / dense_ref.norm())
+        assert rel <= 5e-4, rel
+        mism = (units_hip[i] != u_ref).numpy()
+        near = _near_tie_frames(dense_ref, m["centers"], 0.02)
+        print(f"utt {i}: {int(mism.sum())} unit mismatches, {int(near.sum())} near-tie frames of 499, dense rel {rel:.2e}")
+        assert not (mism & ~near).any(), np.nonzero(mism & ~near)[0]
+        # (2) rhythm + pitch on the HIP units: units/durations exact, F0 within fp32 noise
+        ou, of0 = pr.infer_sample(units_hip[i].numpy(), tgt, m["lsd"], m["lstats"], m["psd"], "new", True)
+        hu, hf0, _ = P.infer_samples([units_hip[i]], [tgt], m["lm"], m["pm"], norm_pitch=True, device=DEV)[0]
+        assert hu == ou
+        of0, hf0 = np.asarray(of0, np.float32), np.asarray(hf0, np.float32)
+        flips = (of0 == 0) != (hf0 == 0)
+        assert flips.sum() <= 1 and np.abs(of0[~flips] - hf0[~flips]).max() <= 2e-5
+        # (3) generator on the HIP units/F0: waveform within the north-star tolerance (1e-4 RMS)
+        code = torch.tensor(hu)[None]
+        ref = gr.code_generator(gw, synth.VCTK_CONFIG, code, torch.from_numpy(hf0)[None, None], torch.tensor([[tgt]]))
+        got = raw[(i, tgt)]
+        assert got.shape == (320 * len(hu),)
+        err = got.astype(np.float64) - ref[0, 0].numpy()
+        rms, ref_rms = np.sqrt(np.mean(err ** 2)), float(ref.double().pow(2).mean().sqrt())
+        assert rms <= 1e-4 and rms <= 1e-3 * ref_rms, (rms, ref_rms)
+    # properties on all 8
+    for i in range(8):
+        r, o = raw[(i, tgt)], out[(i, tgt)]
+        assert r.shape == o.shape and r.size % 320 == 0 and r.size > 0 and np.isfinite(r).all()
+        # the post-processing of the pipeline == the oracle's int16-truncate + peak-normalise of the raw wave
+        np.testing.assert_array_equal(o, gr.wav_postprocess(torch.from_numpy(r)).numpy())
+        assert np.abs(o).max() == 1.0
+        # batch independence: the utterance converted on its own (B=1 through every stage) is bit-identical
+        alone = conv([waves[i]], [tgt])[(0, tgt)]
+        np.testing.assert_array_equal(alone, o)
+
+
+def _sweep_jobs(n_utts, targets, seed=3):
+    import synthdata as synth
+    rs = np.random.RandomState(seed)
+    jobs = []
+    for u in range(n_utts):
+        T = int(rs.randint(100, 251))
+        code, f0, _, _ = synth.synth_generator_inputs(1, T, seed=5000 + u)
+        for t in targets:
+            jobs.append(dict(code=code[0], f0=f0[0, 0], spkr=t))
+    return jobs
+
+
+def test_cfg4_ragged_sweep_256_utterances_one_gpu(models):
+    """configs[3]/[4]-shaped: 256 ragged utterances (T 100-250 frames) x 2 targets through
+    harness.run_resynthesis: the oracle on a sample, batch-independence on ALL jobs (a different
+    batching and, on a sample, B=1 must reproduce every waveform bit for bit)."""
+    import synthdata as synth
+    from oracle import generator_ref as gr
+    from dissc_amd import harness
+    jobs = _sweep_jobs(256, [6, 57])
+    g = models["g"]
+    waves = harness.run_resynthesis(g, jobs, device=DEV)
+    assert sorted(waves) == list(range(512))
+    other = harness.run_resynthesis(g, jobs, device=DEV, max_batch=7, max_frames=7 * 251)
+    for j in range(512):
+        assert waves[j].shape == (320 * len(jobs[j]["code"]),)
+        np.testing.assert_array_equal(waves[j], other[j])
+    rs = np.random.RandomState(0)
+    gw = gr.fold_state_dict(models["gsd"])
+    for j in rs.choice(512, 16, replace=False):
+        j = int(j)
+        one = harness.run_resynthesis(g, [jobs[j]], device=DEV)[0]
+        np.testing.assert_array_equal(one, waves[j])
+    for j in rs.choice(512, 4, replace=False):
+        j = int(j)
+        job = jobs[j]
+        ref = gr.code_generator(gw, synth.VCTK_CONFIG, torch.from_numpy(job["code"])[None],
+                                torch.from_numpy(job["f0"])[None, None], torch.tensor([[job["spkr"]]]))
+        err = waves[j].astype(np.float64) - ref[0, 0].numpy()
+        assert np.sqrt(np.mean(err ** 2)) <= 1e-4
+
+
+def _write_models(td, models, golden_dir):
+    import synthdata as synth
+    for d in ("hub", "len", "pitch", "ckpt", "meta"):
+        os.makedirs(f"{td}/{d}")
+    torch.save({"model": models["hsd"]}, f"{td}/hub/hubert-base-ls960.pt")
+    np.save(f"{td}/hub/kmeans_100.npy", models["centers"].numpy())
+    torch.save(models["lsd"], f"{td}/len/best_model.pth")
+    torch.save(models["lstats"], f"{td}/len/len_norm_stats.pth")
+    torch.save(models["psd"], f"{td}/pitch/best_model.pth")
+    shutil.copy(os.path.join(golden_dir, "vctk_id_to_spkr.pkl"), f"{td}/meta/id_to_spkr.pkl")
+    cfg = dict(synth.VCTK_CONFIG, input_training_file=f"{td}/meta/train.txt", f0_normalize=False, f0_stats=None)
+    json.dump(cfg, open(f"{td}/ckpt/config.json", "w"))
+    torch.save({"generator": models["gsd"]}, f"{td}/ckpt/g_00000001")
+
+
+def _write_wavs(wav_dir, n, seed=7, lo=1.0, hi=4.0):
+    import synthdata as synth
+    os.makedirs(wav_dir)
+    rs = np.random.RandomState(seed)
+    names = []
+    for i in range(n):
+        ns = int(rs.uniform(lo, hi) * 16000)
+        x = synth.synth_waveform(ns, seed=300 + i)
+        nm = f"src{i % 5}_{i:03d}.wav"
+        wavfile.write(os.path.join(wav_dir, nm), 16000, np.round(x * 32767).astype(np.int16))
+        names.append(nm)
+    return names
+
+
+def test_sharded_full_pipeline_two_ranks_equal_one_rank_and_file_chain(models, golden_dir, tmp_path):
+    """convert.py (the rank-sharded encode -> predict -> resynthesise entry): 2 ranks (sharing this
+    GPU, gloo instead of RCCL) must write byte-identical WAVs to the 1-rank run on 40 utterances x 2
+    targets; and the 1-rank files equal the reference-style three-script chain through JSONL files."""
+    td = str(tmp_path)
+    _write_models(td, models, golden_dir)
+    names = _write_wavs(f"{td}/wav", 40)
+    common = ["--base_dir", f"{td}/wav", "--hubert_dir", f"{td}/hub", "--len_model", f"{td}/len/", "--f0_model",
+              f"{td}/pitch/", "--checkpoint_file", f"{td}/ckpt/", "--id_to_spkr", f"{td}/meta/id_to_spkr.pkl",
+              "--target_speakers", "p231", "p225"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "convert.py")] + common + ["--output_dir", f"{td}/out1"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=td)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    env2 = dict(env, DISSC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "convert.py")] + common + ["--output_dir", f"{td}/out2"],
+                       env=env2, capture_output=True, text=True, timeout=900, cwd=td)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    files = sorted(os.listdir(f"{td}/out1"))
+    assert len(files) == 80 and sorted(os.listdir(f"{td}/out2")) == files
+    for fn in files:
+        assert open(f"{td}/out1/{fn}", "rb").read() == open(f"{td}/out2/{fn}", "rb").read(), fn
+    # the same conversion through the three file-based entry points
+    os.makedirs(f"{td}/enc")
+    shutil.copy(f"{td}/meta/id_to_spkr.pkl", f"{td}/enc/id_to_spkr.pkl")
+    _load("enc_cli_p", "data/encode.py").main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/enc/val.txt",
+                                               "--checkpoint_dir", f"{td}/hub", "--f0", "zeros"])
+    _load("infer_cli_p", "infer.py").main(["--input_path", f"{td}/enc/val.txt", "--out_path", f"{td}/pred",
+                                           "--pred_len", "--pred_pitch", "--len_model", f"{td}/len/", "--f0_model",
+                                           f"{td}/pitch/", "--wild_sample", "--id_to_spkr", f"{td}/meta/id_to_spkr.pkl",
+                                           "--f0_path", os.path.join(golden_dir, "vctk_f0_stats.pkl"), "--vc",
+                                           "--target_speakers", "p231", "p225"])
+    sr_cli = _load("sr_cli_p", "sr/inference.py")
+    for t in ("p231", "p225"):
+        sr_cli.main(["--input_code_file", f"{td}/pred/{t}_val.txt", "--data_path", f"{td}/wav", "--output_dir",
+                     f"{td}/out3", "--checkpoint_file", f"{td}/ckpt/", "--vc", "--target-speakers", t,
+                     "--unseen_speaker", "--id_to_spkr", f"{td}/meta/id_to_spkr.pkl", "-n", "-1"])
+    got3 = sorted(f for f in os.listdir(f"{td}/out3") if f.endswith("_gen.wav"))
+    assert got3 == files
+    for fn in files:
+        _, a = wavfile.read(f"{td}/out1/{fn}")
+        _, b = wavfile.read(f"{td}/out3/{fn}")
+        np.testing.assert_array_equal(a, b)
+
+
+def test_sr_inference_256_utterances_two_ranks(models, golden_dir, tmp_path):
+    """The resynthesis-only entry on a configs[3]-sized manifest: 256 ragged utterances x 2 targets,
+    2 gloo ranks on this GPU == 1 rank, file for file."""
+    td = str(tmp_path)
+    _write_models(td, models, golden_dir)
+    jobs = _sweep_jobs(256, [0])
+    with open(f"{td}/man.txt", "w") as f:
+        for u, j in enumerate(jobs):
+            f.write(json.dumps({"units": j["code"].tolist(), "f0": [float(v) for v in j["f0"]],
+                                "audio": f"p{225 + u % 7}_{u:03d}.wav"}) + "\n")
+    args = ["--input_code_file", f"{td}/man.txt", "--data_path", f"{td}/nowav", "--checkpoint_file", f"{td}/ckpt/",
+            "--vc", "--target-speakers", "p231", "p225", "--unseen_speaker", "--id_to_spkr",
+            f"{td}/meta/id_to_spkr.pkl", "-n", "-1"]
+    _load("sr_cli_256", "sr/inference.py").main(args + ["--output_dir", f"{td}/o1"])
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")},
+               DISSC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "sr", "inference.py")] + args + ["--output_dir", f"{td}/o2"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=td)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    files = sorted(os.listdir(f"{td}/o1"))
+    assert len(files) == 512 and sorted(os.listdir(f"{td}/o2")) == files
+    for fn in files:
+        assert open(f"{td}/o1/{fn}", "rb").read() == open(f"{td}/o2/{fn}", "rb").read(), fn

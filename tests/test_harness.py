@@ -39,7 +39,8 @@ def test_make_batches_limits():
 def test_pack_unpack_roundtrip():
     waves = [torch.arange(5, dtype=torch.float32), torch.zeros(0), torch.full((9,), -2.5)]
     buf = harness.pack_waves(waves, [7, 3, 100000], n_max=4, l_max=9, device="cpu")
-    out = harness.unpack_waves(buf, 1, 4)
+    assert buf.shape == (4, harness.HDR + 12)  # rows padded to a multiple of 4 floats
+    out = harness.unpack_waves(buf)
     assert sorted(out) == [3, 7, 100000]
     np.testing.assert_array_equal(out[7], np.arange(5, dtype=np.float32))
     assert out[3].shape == (0,)
@@ -68,6 +69,8 @@ def _jobs(n=23, seed=3):
         T = int(rs.randint(1, 40))
         jobs.append(dict(code=rs.randint(0, 100, T), f0=rs.standard_normal(T).astype(np.float32),
                          spkr=int(rs.randint(0, 9))))
+    for _ in range(2):  # empty `units` lines must come back as empty waveforms, not abort a rank
+        jobs.append(dict(code=np.zeros(0, np.int64), f0=np.zeros(0, np.float32), spkr=1))
     return jobs
 
 
@@ -77,7 +80,10 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     out = harness.run_resynthesis(_FakeGenerator(), _jobs(), rank, world, "cpu", dist, max_batch=4,
-                                  max_frames=100)
+                                  max_frames=100, unpack_ranks=None)
+    only0 = harness.run_resynthesis(_FakeGenerator(), _jobs(), rank, world, "cpu", dist, max_batch=4,
+                                    max_frames=100)  # default: only rank 0 unpacks
+    assert (len(only0) == 25) == (rank == 0)
     q.put((rank, {k: v.tolist() for k, v in out.items()}))
     dist.barrier()
     dist.destroy_process_group()
@@ -86,7 +92,7 @@ def _worker(rank, world, port, q):
 def test_two_rank_gloo_matches_single_process():
     single = harness.run_resynthesis(_FakeGenerator(), _jobs(), 0, 1, "cpu", None, max_batch=4,
                                      max_frames=100)
-    assert sorted(single) == list(range(23))
+    assert sorted(single) == list(range(25)) and single[23].shape == (0,) and single[24].shape == (0,)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -101,6 +107,6 @@ def test_two_rank_gloo_matches_single_process():
         p.join(60)
         assert p.exitcode == 0
     for r in range(2):  # every rank holds every waveform after the one all-gather
-        assert sorted(got[r]) == list(range(23))
-        for j in range(23):
+        assert sorted(got[r]) == list(range(25))
+        for j in range(25):
             np.testing.assert_array_equal(np.array(got[r][j], dtype=np.float32), single[j])

@@ -1,5 +1,6 @@
 """data/prep_dataset.py path: per-speaker F0 statistics and the train/val split,
 against outputs of the reference's own data/data_utils.py (tests/golden/prep_expected.pkl)."""
+import json
 import os
 import pickle
 import shutil
@@ -90,3 +91,22 @@ def test_prep_dataset_cli(golden, golden_dir, tmp_path):
     for k in want:
         assert abs(got[k]["mean"] - want[k]["mean"]) <= 1e-12 * abs(want[k]["mean"])
         assert abs(got[k]["std"] - want[k]["std"]) <= 1e-11 * abs(want[k]["std"])
+
+
+@pytest.mark.gpu
+def test_all_unvoiced_speaker_fails_loudly(tmp_path):
+    """An all-zero F0 track (what `data/encode.py --f0 zeros` writes) must not become NaN statistics
+    silently: the CLI fails and writes nothing; --allow_unvoiced restores the reference's NaN pickle."""
+    man = tmp_path / "train.txt"
+    man.write_text(json.dumps({"units": [1, 2, 3], "f0": [0.0, 0.0, 0.0], "audio": "p1_001.wav"}) + "\n" +
+                   json.dumps({"units": [1, 2], "f0": [0.0, 120.0], "audio": "p2_001.wav"}) + "\n")
+    stats = tmp_path / "f0_stats.pkl"
+    cmd = [sys.executable, os.path.join(ROOT, "data", "prep_dataset.py"), "--encoded_path", str(man),
+           "--stats_path", str(stats)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode != 0 and "no voiced F0 frame" in r.stderr and "p1" in r.stderr
+    assert not stats.exists()
+    r = subprocess.run(cmd + ["--allow_unvoiced"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    got = pickle.load(open(stats, "rb"))
+    assert np.isnan(got["p1"]["mean"]) and got["p2"]["mean"] == 120.0
