@@ -54,8 +54,38 @@ def test_out_of_range_ids_are_clamped_not_read_out_of_bounds(env):
     code[0, 3] = 10 ** 9
     code[0, 4] = -5
     spkr[0, 0] = 9999
-    y = g(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr)).cpu()
+    # ids handed over from the host (files) raise like nn.Embedding does in the reference ...
+    with pytest.raises(IndexError):
+        g(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr))
+    good = code.copy()
+    good[0, 3] = good[0, 4] = 0
+    with pytest.raises(IndexError):
+        g(code=torch.from_numpy(good), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr))  # speaker 9999
+    # ... device-resident ids (not inspected: no sync) are clamped by the kernels, never read out of bounds
+    y = g(code=torch.from_numpy(code).cuda(), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr).cuda()).cpu()
     assert torch.isfinite(y).all()
+
+
+def test_predictor_ids_and_f0_length_are_validated(env):
+    import synthdata as synth
+    from dissc_amd import predictors as P
+    lm = P.LenPredictor(100, 108).to("cuda:0")
+    lm.load_state_dict(synth.synth_len_state_dict(100, 108))
+    with pytest.raises(IndexError):
+        lm(torch.tensor([[1, 2, 500]]), torch.tensor([[3]]))
+    with pytest.raises(IndexError):
+        lm(torch.tensor([[1, 2, 3]]), torch.tensor([[108]]))
+    pm = P.PitchPredictorBase(100, 108, id2pitch_mean=torch.zeros(10), id2pitch_std=torch.ones(10)).to("cuda:0")
+    pm.load_state_dict(synth.synth_pitch_state_dict("base", 100, 108))
+    with pytest.raises(IndexError):  # speaker 50 exists in the embedding but not in the 10-entry statistics
+        pm.infer_freq(torch.tensor([[1, 2, 3]]), torch.tensor([[50]]), norm=False)
+    y = pm.infer_freq(torch.tensor([[1, 2, 3]]).cuda(), torch.tensor([[50]]).cuda(), norm=False)  # clamped on device
+    assert torch.isfinite(y).all()
+    # non-divisible code / f0 lengths: the reference fails in torch.cat; we must not read OOB
+    g = env["g"]
+    code, f0, spkr, _ = env["synth"].synth_generator_inputs(2, 101, seed=3)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        g(code=torch.from_numpy(code), f0=torch.from_numpy(f0[:, :, :50]), spkr=torch.from_numpy(spkr))
 
 
 def test_abi_error_paths_return_codes_and_messages(env):
