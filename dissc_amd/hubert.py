@@ -130,6 +130,10 @@ class HubertEncoder:
         except Exception:
             pass
 
+    # textless' HubertFeatureReader feeds the model at most this many samples at a time and
+    # concatenates the features of the chunks (100 s at 16 kHz) [3P-unverified, from memory]
+    MAX_CHUNK = 1600000
+
     def forward(self, wav, n_samples=None, want_dense=True):
         """wav f32 [B,N] -> dict(units i64 [B,T], dense f32 [B,T,768], frames i32 [B])"""
         self._ensure()
@@ -137,6 +141,8 @@ class HubertEncoder:
         wav = torch.as_tensor(wav).to(dev, torch.float32)
         if wav.dim() == 1:
             wav = wav.unsqueeze(0)
+        if wav.shape[1] > self.MAX_CHUNK:
+            return self._forward_chunked(wav, n_samples, want_dense)
         wav = wav.contiguous()
         B, N = wav.shape
         T = lib.dissc_hubert_frames(N)
@@ -172,6 +178,36 @@ class HubertEncoder:
             out["units"] = units
         if dense is not None:
             out["dense"] = dense[:, :, :T].transpose(1, 2)
+        return out
+
+    def _forward_chunked(self, wav, n_samples, want_dense):
+        """Inputs longer than MAX_CHUNK: every chunk is encoded on its own and the frames are
+        concatenated, as the reference's feature reader does (the frames next to a chunk boundary
+        therefore differ from a single pass, on purpose).  A trailing piece shorter than one frame
+        (< 400 samples) yields nothing."""
+        B, N = wav.shape
+        ns = torch.full((B,), N, dtype=torch.int64) if n_samples is None else torch.as_tensor(n_samples).cpu().long()
+        parts = []
+        for start in range(0, N, self.MAX_CHUNK):
+            piece = wav[:, start:start + self.MAX_CHUNK]
+            n_c = (ns - start).clamp(0, piece.shape[1])
+            if piece.shape[1] < 400 or int(n_c.max()) < 400:
+                continue
+            parts.append(self.forward(piece.contiguous(), n_samples=n_c.to(torch.int32), want_dense=want_dense))
+        frames = torch.stack([p["frames"] for p in parts]).sum(0).to(torch.int32)
+        T = int(frames.max())
+        out = {"frames": frames}
+        for key, shape, dt in (("units", (B, T), torch.int64), ("dense", (B, T, 768), torch.float32)):
+            if key not in parts[0]:
+                continue
+            full = torch.zeros(shape, dtype=dt, device=self.device)
+            for b in range(B):
+                pos = 0
+                for p in parts:
+                    f = int(p["frames"][b])
+                    full[b, pos:pos + f] = p[key][b, :f]
+                    pos += f
+            out[key] = full
         return out
 
     __call__ = forward

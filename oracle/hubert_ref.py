@@ -19,6 +19,28 @@ Published algorithm restated (fairseq hubert.py / wav2vec2.py, HuBERT-base confi
   kmeans_assign           argmin_k ||x - c_k||^2 (lowest index on ties)
 
 Weight names follow the fairseq checkpoint (``model`` dict of hubert_base_ls960.pt).
+
+What textlesslib does around the model [3P-unverified: written down from memory of
+textless/data/{speech_encoder,hubert_feature_reader,kmeans_quantizer}.py, source absent]:
+  * HubertFeatureReader: loads the fairseq checkpoint, ``model.eval()``; the waveform is NOT
+    normalised for hubert-base-ls960 (``task.cfg.normalize == False``; only *_large models
+    layer-norm the input); inputs longer than ``max_chunk = 1 600 000`` samples are cut into
+    chunks that are encoded independently with
+    ``extract_features(source=chunk, padding_mask=None, mask=False, output_layer=6)`` and the
+    chunk features concatenated along time  -> dissc_amd.hubert.HubertEncoder.MAX_CHUNK;
+  * KMeansQuantizer.forward: ``kmeans_model.predict(dense.cpu().numpy())`` on a joblib-pickled
+    sklearn ``MiniBatchKMeans(n_clusters=100)``; dense is float32, so sklearn works in float32
+    (``cluster_centers_`` are cast to the dtype of X).  sklearn's dense predict
+    (``_lloyd_iter_chunked_dense``, chunks of 256 rows) evaluates, per row x and centre c_k,
+        d_k = ||c_k||^2 + (-2) * <x, c_k>           (one sgemm with alpha=-2, beta=1 onto a matrix
+                                                     pre-filled with the squared centre norms;
+                                                     ||x||^2 is omitted: constant per row)
+    and takes the FIRST minimum (strict ``<`` while scanning k = 0..K-1).  ``kmeans_assign`` below
+    and the HIP ``kmeans_argmin_kernel`` use exactly this expression, order and tie rule; the
+    squared centre norms are fp32 sums (summation order inside sklearn's einsum / our loop differs
+    by <= 1 ulp-level noise, far below any margin that is not itself a tie);
+  * durations: with ``deduplicate=False`` every unit has duration 1; ``f0``: YAAPT, see
+    oracle/yaapt_ref.py.
 """
 import torch
 import torch.nn.functional as F
@@ -79,9 +101,18 @@ def encoder(sd, feats, n_layers=6, n_heads=12):
 
 
 def kmeans_assign(x, centers):
-    """x [T,D], centers [K,D] -> int64 [T]: argmin ||x-c||^2 = argmin (||c||^2 - 2 x.c)"""
+    """x [T,D], centers [K,D] -> int64 [T]: first minimum over k of ||c_k||^2 - 2 <x, c_k>, fp32
+    (the expression sklearn's dense predict evaluates; see the module docstring)."""
     d = (centers * centers).sum(1)[None, :] - 2.0 * (x @ centers.t())
-    return torch.argmin(d, dim=1)
+    return torch.argmin(d, dim=1)  # torch.argmin returns the first index of the minimum
+
+
+def kmeans_margin(x, centers):
+    """per frame: gap between the best and the second-best value of the expression above (what decides
+    whether an fp32-level difference in x may legitimately flip the unit)"""
+    d = (centers * centers).sum(1)[None, :] - 2.0 * (x @ centers.t())
+    top2 = torch.topk(d, 2, dim=1, largest=False).values
+    return top2[:, 1] - top2[:, 0]
 
 
 @torch.no_grad()

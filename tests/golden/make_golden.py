@@ -1,6 +1,9 @@
 """Generate golden vectors by running the REFERENCE itself (this container only).
 
-    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz (every target, one
+                                                  # interpreter each: the reference's root and sr/
+                                                  # trees both define modules named utils/models/dataset)
+    python tests/golden/make_golden.py hubert     # one target
 
 Imports the reference modules unmodified from /root/reference (which does not
 exist on the GPU box -- only the .npz outputs travel).  Weights/inputs come
@@ -22,7 +25,10 @@ warnings.filterwarnings("ignore")
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
-sys.path.insert(0, ROOT)
+OUT = os.environ.get("DISSC_GOLDEN_OUT", HERE)  # where the fixtures are written (tests regenerate into a temp dir)
+os.makedirs(OUT, exist_ok=True)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import synthdata as synth  # noqa: E402
 
@@ -86,7 +92,7 @@ def make_generator():
             y, _ = run(code[b:b + 1, :n], f0[b:b + 1, :, :n], spkr[b:b + 1], False)
             out[f"s{seed}/ragged/wav{b}"] = y.numpy()
         out[f"s{seed}/ragged/lengths"] = lengths
-    np.savez_compressed(os.path.join(HERE, "gen_vctk.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "gen_vctk.npz"), **out)
     print("gen_vctk.npz", len(out), "arrays")
 
 
@@ -260,7 +266,7 @@ def make_predictors():
             pitch = rs3.rand(len(u)) * 100
             out[f"morph/{j}/units"], out[f"morph/{j}/pitch"], out[f"morph/{j}/lens"] = np.array(u), pitch, np.array(tl)
             out[f"morph/{j}/out"] = np.asarray(ref_utils_root.morph_seq_len(np.array(u), pitch, np.array(tl)), dtype=np.float64)
-    np.savez_compressed(os.path.join(HERE, "pred.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "pred.npz"), **out)
     print("pred.npz", len(out), "arrays")
 
 
@@ -398,7 +404,7 @@ def make_sr_inference():
             out[f"src/out/{fn}"] = wavfile.read(f"{td}/out_c/{fn}")[1]
         out["src/pairs"] = np.array([list(df.syn_sample), list(df.syn_trgt)])
         out["src/names"] = np.array(names_c)
-    np.savez_compressed(os.path.join(HERE, "sr_inference.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "sr_inference.npz"), **out)
     print("sr_inference.npz", sorted(k for k in out if k.startswith("sr/out")))
 
 
@@ -428,7 +434,7 @@ def make_hubert():
         if n <= 4000:
             out[f"n{n}/cnn"] = feats.numpy()
             out[f"n{n}/h0"] = o.hidden_states[0][0].numpy()
-    np.savez_compressed(os.path.join(HERE, "hubert.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "hubert.npz"), **out)
     print("hubert.npz", {k: v.shape for k, v in out.items() if k.endswith("units")})
 
 
@@ -459,7 +465,7 @@ def make_prep_dataset():
     sys.path.insert(0, os.path.join(REF, "data"))
     import data_utils as ref_du
     lines = synth_units_jsonl()
-    with open(os.path.join(HERE, "prep_units.txt"), "w") as f:
+    with open(os.path.join(OUT, "prep_units.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     out = {}
     with tempfile.TemporaryDirectory() as td:
@@ -473,21 +479,23 @@ def make_prep_dataset():
         out["random"] = (open(tr).read(), open(va).read())
         tr, va = ref_du.data_split(man, "paired_val")
         out["paired_val"] = (open(tr).read(), open(va).read())
-    with open(os.path.join(HERE, "prep_expected.pkl"), "wb") as f:
+    with open(os.path.join(OUT, "prep_expected.pkl"), "wb") as f:
         pickle.dump({"stats": {k: {"mean": float(v["mean"]), "std": float(v["std"])} for k, v in stats.items()},
                      "split": out}, f)
     print("prep_expected.pkl", {k: (round(v["mean"], 3), round(v["std"], 3)) for k, v in stats.items()})
 
 
+TARGETS = {"prep_dataset": make_prep_dataset, "hubert": make_hubert, "sr_inference": make_sr_inference,
+           "generator": make_generator, "predictors": make_predictors}
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["generator", "predictors", "sr_inference", "hubert", "prep_dataset"]
-    if "prep_dataset" in which:
-        make_prep_dataset()
-    if "hubert" in which:
-        make_hubert()
-    if "sr_inference" in which:
-        make_sr_inference()
-    if "generator" in which:
-        make_generator()
-    if "predictors" in which:
-        make_predictors()
+    which = sys.argv[1:] or list(TARGETS)
+    unknown = [w for w in which if w not in TARGETS]
+    if unknown:
+        sys.exit(f"unknown target(s) {unknown}; choose from {list(TARGETS)}")
+    if len(which) == 1:
+        TARGETS[which[0]]()
+    else:
+        import subprocess
+        for w in which:  # a fresh interpreter per target keeps sys.path / sys.modules clean
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), w])

@@ -138,7 +138,7 @@ def test_generator_ragged_batch_matches_reference_golden(env, golden_dir):
 
 
 def test_generator_full_size_properties(env):
-    """BASELINE config: B=32 x T=500.  Oracle on 2 utterances + batch-independence
+    """BASELINE config: B=32 x T=500.  Oracle on 8 of the 32 utterances + batch-independence
     (an utterance's samples do not depend on what it is batched with)."""
     g, gr, synth = env["g"], env["gr"], env["synth"]
     code, f0, spkr, _ = synth.synth_generator_inputs(32, 500, seed=1234)
@@ -146,12 +146,16 @@ def test_generator_full_size_properties(env):
     y = g(code=tc, f0=tf, spkr=ts).cpu()
     assert tuple(y.shape) == (32, 1, 160000)
     assert torch.isfinite(y).all() and y.abs().max() <= 1.0
-    for b in (0, 31):
+    worst = 0.0
+    for b in (0, 3, 8, 13, 17, 22, 26, 31):  # the oracle on 8 of the 32 utterances (~1-2 s of CPU each)
         ref = gr.code_generator(env["folded"], synth.VCTK_CONFIG, code[b:b + 1], f0[b:b + 1], spkr[b:b + 1])
         e = (y[b:b + 1] - ref).numpy()
-        assert _rms(e) <= 1e-4 and _rms(e) <= 1e-3 * _rms(ref.numpy())
-    y1 = g(code=tc[7:8], f0=tf[7:8], spkr=ts[7:8]).cpu()
-    assert torch.equal(y1[0], y[7])
+        assert _rms(e) <= 1e-4 and _rms(e) <= 1e-3 * _rms(ref.numpy()), (b, _rms(e))
+        worst = max(worst, _rms(e))
+    print(f"B=32 x T=500: worst RMS error vs the oracle over 8 utterances = {worst:.3e}")
+    for b in (7, 19, 30):  # batch independence: an utterance on its own is bit-identical
+        y1 = g(code=tc[b:b + 1], f0=tf[b:b + 1], spkr=ts[b:b + 1]).cpu()
+        assert torch.equal(y1[0], y[b])
     # determinism: same launch twice -> identical bits
     y2 = g(code=tc, f0=tf, spkr=ts).cpu()
     assert torch.equal(y, y2)

@@ -1,4 +1,9 @@
-"""GPU parity of the HuBERT unit encoder vs the HF/sklearn goldens and the CPU oracle."""
+"""GPU parity of the HuBERT unit encoder vs the HF/sklearn goldens and the CPU oracle.
+
+PARITY UNPINNED against fairseq/textless themselves (sources and weights absent, see
+oracle/hubert_ref.py); what is asserted here: dense features within 5e-4 (relative to the feature
+scale) of HF ``HubertModel`` / the oracle, and unit indices equal EXCEPT on frames that are k-means
+near-ties of the reference features -- as a set inclusion, with both counts printed."""
 import os
 
 import numpy as np
@@ -6,6 +11,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+NEAR = 0.02  # margin of ||c||^2 - 2<x,c> below which fp32-level feature noise may flip the unit
 
 
 @pytest.fixture(scope="module")
@@ -22,12 +28,15 @@ def env(golden_dir):
                 g=np.load(os.path.join(golden_dir, "hubert.npz")))
 
 
-def _check_units(units, dense_ref, centers, want):
-    d = ((torch.from_numpy(dense_ref)[:, None, :] - centers[None]) ** 2).sum(-1)
-    top2 = torch.topk(d, 2, largest=False).values
-    safe = ((top2[:, 1] - top2[:, 0]) > 0.02).numpy()
-    np.testing.assert_array_equal(units[safe], want[safe])
-    return int((~safe).sum()), int((units != want).sum())
+def _check_units(hr, units, dense_ref, centers, want, tag=""):
+    """every frame where ``units`` differs from the reference's must be a near-tie frame"""
+    margin = hr.kmeans_margin(torch.as_tensor(dense_ref), centers).numpy()
+    near = margin <= NEAR
+    mism = np.asarray(units) != np.asarray(want)
+    print(f"{tag}: {int(mism.sum())} mismatching frames, {int(near.sum())} near-tie frames of {len(near)}")
+    outside = mism & ~near
+    assert not outside.any(), f"{tag}: frames {np.nonzero(outside)[0][:10]} differ with margins {margin[outside][:10]}"
+    return int(near.sum()), int(mism.sum())
 
 
 @pytest.mark.parametrize("n", [400, 719, 4000, 16000, 32000])
@@ -40,8 +49,7 @@ def test_hubert_matches_hf_golden(env, n):
     assert dense.shape == want.shape
     err = np.abs(dense - want).max()
     assert err <= 5e-4 * max(1.0, np.abs(want).max()), err
-    near, diff = _check_units(out["units"][0].cpu().numpy(), want, env["centers"], g[f"n{n}/units"])
-    assert diff <= near  # indices may differ only at near-ties
+    _check_units(env["hr"], out["units"][0].cpu().numpy(), want, env["centers"], g[f"n{n}/units"], f"n={n}")
 
 
 def test_hubert_ragged_batch_is_per_utterance_exact(env):
@@ -72,5 +80,113 @@ def test_hubert_10s_against_oracle(env):
     units_ref, dense_ref = env["hr"].encode(env["sd"], env["centers"], wav)
     err = np.abs(out["dense"][0].cpu().numpy() - dense_ref.numpy()).max()
     assert err <= 5e-4 * max(1.0, float(dense_ref.abs().max())), err
-    near, diff = _check_units(out["units"][0].cpu().numpy(), dense_ref.numpy(), env["centers"], units_ref.numpy())
-    assert diff <= near
+    _check_units(env["hr"], out["units"][0].cpu().numpy(), dense_ref.numpy(), env["centers"], units_ref.numpy(), "10 s")
+
+
+def test_hubert_batch32_ragged_2_to_10s_against_oracle(env):
+    """The encode shape the pipeline runs (B=32, ragged 2-10 s, NaN in the padding): the oracle on 4
+    utterances (longest, shortest, two in between), B=1 equality of the units on all 32."""
+    hr, synth = env["hr"], env["synth"]
+    rs = np.random.RandomState(11)
+    ns = [160000] + [int(v) for v in rs.randint(32000, 160001, size=30)] + [32000]
+    wav = torch.full((32, 160000), float("nan"))
+    for i, n in enumerate(ns):
+        wav[i, :n] = torch.from_numpy(synth.synth_waveform(n, seed=700 + i))
+    out = env["enc"](wav, n_samples=torch.tensor(ns))
+    units = out["units"].cpu().numpy()
+    dense = out["dense"].cpu()
+    order = np.argsort(ns)
+    for i in (0, 31, int(order[10]), int(order[21])):
+        T = hr.num_frames(ns[i])
+        assert int(out["frames"][i]) == T
+        u_ref, d_ref = hr.encode(env["sd"], env["centers"], wav[i:i + 1, :ns[i]])
+        err = float((dense[i, :T] - d_ref).abs().max())
+        assert err <= 5e-4 * max(1.0, float(d_ref.abs().max())), (i, err)
+        _check_units(hr, units[i, :T], d_ref, env["centers"], u_ref.numpy(), f"utt {i} ({ns[i]} samples)")
+    for i in range(32):
+        T = int(out["frames"][i])
+        one = env["enc"](wav[i:i + 1, :ns[i]], want_dense=False)
+        np.testing.assert_array_equal(one["units"][0].cpu().numpy(), units[i, :T])
+
+
+def test_units_differ_from_the_oracle_only_at_constructed_near_ties(env):
+    """Centres built so that many frames sit (almost) exactly between two centres: the HIP units may
+    then differ from the oracle's -- but only on those frames.  (With the random synthetic centres no
+    frame is ever near a tie, so the inclusion above would be vacuous without this case.)"""
+    from dissc_amd.hubert import HubertEncoder
+    hr, synth = env["hr"], env["synth"]
+    wav = torch.from_numpy(synth.synth_waveform(48000, seed=5))[None]
+    _, dense_ref = hr.encode(env["sd"], env["centers"], wav)
+    T = dense_ref.shape[0]
+    rs = np.random.RandomState(2)
+    centers = env["centers"].clone()
+    picks = rs.choice(T, 50, replace=False)
+    for j, t in enumerate(picks):  # centres 2j, 2j+1 = frame t -+ a tiny step: frame t is equidistant
+        v = torch.from_numpy(rs.standard_normal(768).astype(np.float32))
+        v = v / v.norm() * 1e-3
+        centers[2 * j] = dense_ref[t] - v
+        centers[2 * j + 1] = dense_ref[t] + v
+    u_ref = hr.kmeans_assign(dense_ref, centers).numpy()
+    enc = HubertEncoder(env["sd"], centers, n_layers=6).to("cuda:0")
+    out = enc(wav)
+    near, mism = _check_units(hr, out["units"][0].cpu().numpy(), dense_ref, centers, u_ref, "constructed ties")
+    assert near >= 50
+    # and on the HIP features themselves the argmin is bit-exact against the oracle's expression order
+    dense_hip = out["dense"][0].cpu()
+    margin = hr.kmeans_margin(dense_hip, centers).numpy()
+    u_hip_ref = hr.kmeans_assign(dense_hip, centers).numpy()
+    clear = margin > 1e-4
+    np.testing.assert_array_equal(out["units"][0].cpu().numpy()[clear], u_hip_ref[clear])
+
+
+def test_fairseq_structured_checkpoint_loads_through_speech_encoder(env, tmp_path):
+    """A checkpoint laid out like fairseq's hubert_base_ls960.pt -- {'args', 'cfg', 'model', ...} with
+    the pre-training extras (mask_emb, final_proj, label_embs_concat), 12 encoder layers and the
+    [1,1,128] weight_g -- plus a joblib k-means file: SpeechEncoder.from_files (what data/encode.py
+    uses) must encode exactly like a HubertEncoder built from the bare 6-layer state dict."""
+    import joblib
+    from sklearn.cluster import MiniBatchKMeans
+    from dissc_amd.hubert import SpeechEncoder
+    synth = env["synth"]
+    sd = dict(synth.synth_hubert_state_dict(12))
+    assert tuple(sd["encoder.pos_conv.0.weight_g"].shape) == (1, 1, 128)
+    for k in [k for k in sd if k.startswith("encoder.layers.") and int(k.split(".")[2]) < 6]:
+        sd[k] = env["sd"][k]  # same first six layers as the reference encoder of this module
+    for k in [k for k in env["sd"] if not k.startswith("encoder.layers.")]:
+        sd[k] = env["sd"][k]
+    g = torch.Generator().manual_seed(0)
+    sd["mask_emb"] = torch.rand(768, generator=g)
+    sd["final_proj.weight"] = torch.randn(256, 768, generator=g)
+    sd["final_proj.bias"] = torch.randn(256, generator=g)
+    sd["label_embs_concat"] = torch.randn(504, 256, generator=g)
+    ckpt = {"args": None, "cfg": {"model": {"_name": "hubert", "encoder_layers": 12}, "task": {"normalize": False}},
+            "model": sd, "criterion": {}, "optimizer_history": [], "task_state": {}, "extra_state": {},
+            "last_optimizer_state": None}
+    torch.save(ckpt, tmp_path / "hubert_base_ls960.pt")
+    km = MiniBatchKMeans(n_clusters=100, n_init=1)
+    km.cluster_centers_ = env["centers"].numpy().astype(np.float64)  # old pickles hold float64 centres
+    km.n_features_in_ = 768
+    joblib.dump(km, tmp_path / "km100.bin")
+    se = SpeechEncoder.from_files(str(tmp_path / "hubert_base_ls960.pt"), str(tmp_path / "km100.bin"), layer=6).to("cuda:0")
+    wav = torch.from_numpy(synth.synth_waveform(32000, seed=32000))[None]
+    got = se(wav)
+    want = env["enc"](wav)
+    assert set(got) == {"units", "dense", "durations", "f0"}
+    np.testing.assert_array_equal(got["units"].cpu().numpy(), want["units"][0].cpu().numpy())
+    np.testing.assert_array_equal(got["dense"].cpu().numpy(), want["dense"][0].cpu().numpy())
+    assert got["durations"].tolist() == [1] * 99
+
+
+def test_long_input_is_chunked_like_textless(env, monkeypatch):
+    """> MAX_CHUNK samples: chunks are encoded independently and concatenated (textless'
+    HubertFeatureReader); exercised with a small MAX_CHUNK."""
+    from dissc_amd.hubert import HubertEncoder
+    enc = env["enc"]
+    monkeypatch.setattr(HubertEncoder, "MAX_CHUNK", 16000)
+    wav = torch.from_numpy(env["synth"].synth_waveform(40000, seed=9))[None]
+    out = enc(wav, want_dense=False)
+    monkeypatch.setattr(HubertEncoder, "MAX_CHUNK", 1600000)
+    pieces = [enc(wav[:, s:s + 16000], want_dense=False)["units"][0] for s in (0, 16000, 32000)]
+    want = torch.cat(pieces)
+    assert int(out["frames"][0]) == want.numel() == 49 + 49 + 24
+    np.testing.assert_array_equal(out["units"][0].cpu().numpy(), want.cpu().numpy())

@@ -68,3 +68,27 @@ def test_infer_cli_argument_contract():
         infer.main(["--input_path", "x.txt"])
     with pytest.raises(AssertionError):  # wild samples need both (reference infer.py:198)
         infer.main(["--input_path", "x.txt", "--wild_sample", "--pred_len"])
+
+
+def test_hubert_loader_accepts_fairseq_and_hf_layouts():
+    """Checkpoint plumbing of the unit encoder on the host: a fairseq-structured checkpoint with the
+    pre-training extras and 12 layers, and the HuggingFace key layout, select the same 6-layer tensors."""
+    import torch
+    import synthdata as synth
+    from dissc_amd.hubert import HubertEncoder
+    from oracle import hubert_ref as hr
+    sd6 = synth.synth_hubert_state_dict(6)
+    sd = dict(synth.synth_hubert_state_dict(12))
+    sd.update({k: v for k, v in sd6.items()})
+    sd["mask_emb"] = torch.zeros(768)
+    sd["final_proj.weight"] = torch.zeros(256, 768)
+    sd["label_embs_concat"] = torch.zeros(504, 256)
+    a = HubertEncoder({"args": None, "cfg": {}, "model": sd}, None, n_layers=6)._tensors()
+    b = HubertEncoder(sd6, None, n_layers=6)._tensors()
+    c = HubertEncoder(hr.fairseq_to_hf(sd6), None, n_layers=6)._tensors()
+    assert sorted(a) == sorted(b) == sorted(c)
+    assert not any(k.startswith(("mask_emb", "final_proj", "label_embs")) for k in a)
+    assert max(int(k.split(".")[2]) for k in a if k.startswith("encoder.layers.")) == 5
+    assert tuple(a["encoder.pos_conv.0.weight"].shape) == (768, 48, 128)
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k

@@ -230,3 +230,23 @@ def test_c_oracle_postprocess_and_kmeans(coracle, hgold):
     coracle.oracle_kmeans_assign(dense.ctypes.data_as(ctypes.c_void_p), len(dense), 768,
                                  centers.ctypes.data_as(ctypes.c_void_p), 100, units.ctypes.data_as(ctypes.c_void_p))
     np.testing.assert_array_equal(units, hgold["n16000/units"])  # == sklearn KMeans.predict
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
+def test_golden_fixtures_regenerate_bit_identically(tmp_path):
+    """tests/golden/make_golden.py must still run against the reference and reproduce the committed
+    fixtures (two cheap targets here; the recipe for all of them is `python tests/golden/make_golden.py`)."""
+    import subprocess
+    import sys
+    GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    env = dict(os.environ, DISSC_GOLDEN_OUT=str(tmp_path))
+    script = os.path.join(GOLDEN, "make_golden.py")
+    r = subprocess.run([sys.executable, script, "prep_dataset", "generator"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for fn in ("prep_units.txt", "prep_expected.pkl"):
+        assert open(tmp_path / fn, "rb").read() == open(os.path.join(GOLDEN, fn), "rb").read(), fn
+    a, b = np.load(tmp_path / "gen_vctk.npz"), np.load(os.path.join(GOLDEN, "gen_vctk.npz"))
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
