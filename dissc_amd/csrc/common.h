@@ -166,6 +166,13 @@ int launch_resblock_fused(int C, const float* x, float* acc, const float* wpack,
                           int B, int Lmax, int ld, float slope, int epi, float mrf_div,
                           hipStream_t stream);
 
+// one residual pair y = x + conv_1(lrelu(conv_d(lrelu(x)))) per launch, exact fp32 (respair.hip)
+extern int g_pair_max_c;  // "pair_max_c" option: widest stage run this way (0 = off)
+bool respair_supported(int C, int KS, int dil);
+int launch_respair(const DevConv& c1, const DevConv& c2, const float* x, float* out, float* acc,
+                   const int32_t* lengths, int len_default, int len_mul, int B, int Lmax, int ld, float slope,
+                   int epi, float mrf_div, hipStream_t stream);
+
 // the same block in split-bf16 arithmetic ("precision" = 1 only; resblock_bf3.hip)
 bool resblock_bf3_supported(int C, int KS, const int* dil);
 void resblock_bf3_set_variant(int v);

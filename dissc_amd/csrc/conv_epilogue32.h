@@ -25,6 +25,30 @@ __device__ __forceinline__ void conv_epilogue32(const ConvArgs& a, f32x16 (&acc)
   if (a.up != 1) {
     // ConvTranspose pixel shuffle straight from registers: row = co*np + pi -> out[co][t*up + p0 + pi]
     const int tbase = t0 + wn * (32 * NI) + l31;
+    if ((a.up_np & 1) == 0 && (a.up & 1) == 0 && (a.up_p0 & 1) == 0 && (a.M & 1) == 0) {
+      // two adjacent phases of one output channel sit in registers r, r+1 of the same lane (rows 2i, 2i+1):
+      // one 8-byte store per pair, contiguous across the wave's lanes when up == 2
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int row = (ms0 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;  // even
+          if (row >= a.M) continue;
+          const float bz0 = a.bias[row], bz1 = a.bias[row + 1];
+          const int co = row / a.up_np;
+          const int p = a.up_p0 + row - co * a.up_np;
+          const size_t rowoff = ob + (size_t)co * a.ldo + p;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const int t = tbase + ni * 32;
+            if (t < olen)
+              *reinterpret_cast<float2*>(a.out + rowoff + (size_t)t * a.up) =
+                  make_float2(acc[mi][ni][r] + bz0, acc[mi][ni][r + 1] + bz1);
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll

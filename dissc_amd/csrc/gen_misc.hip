@@ -89,9 +89,68 @@ __global__ void __launch_bounds__(256) conv_post_kernel(const float* __restrict_
   }
 }
 
+// The same tail for KS == 7, HBM-bound form: one thread = 4 consecutive samples, the 12-sample
+// window of every channel comes straight from global memory as three aligned 16-byte loads (neighbouring
+// threads share them through L1/L2), no LDS, no barrier.  Accumulation order as above (channels outer,
+// taps inner) -> identical bits.
+__global__ void __launch_bounds__(256) conv_post7_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         const int32_t* __restrict__ lengths, int len_mul, int C,
+                                                         int L, int ldx, long long x_bstride, float slope,
+                                                         float* __restrict__ wav, int ldw) {
+  const int b = blockIdx.y;
+  const int t = 4 * (blockIdx.x * 256 + threadIdx.x);
+  if (t >= L) return;
+  const int len = lengths ? lengths[b] * len_mul : L;
+  float* wb = wav + (size_t)b * ldw + t;
+  if (t >= len) {
+    for (int e = 0; e < 4 && t + e < L; ++e) wb[e] = 0.f;
+    return;
+  }
+  const float* xb = x + (size_t)b * x_bstride;
+  const float bz = bias[0];
+  float s[4] = {bz, bz, bz, bz};
+  for (int ci = 0; ci < C; ++ci) {
+    const float* row = xb + (size_t)ci * ldx;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 q0 = t >= 4 ? *reinterpret_cast<const f32x4*>(row + t - 4) : zero;
+    const f32x4 q1 = *reinterpret_cast<const f32x4*>(row + t);
+    const f32x4 q2 = t + 8 <= ldx ? *reinterpret_cast<const f32x4*>(row + t + 4) : zero;
+    float v[12];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = q0[e]; v[4 + e] = q1[e]; v[8 + e] = q2[e]; }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+      const int pos = t - 4 + e;
+      const float u = v[e] > 0.f ? v[e] : v[e] * slope;
+      v[e] = (pos >= 0 && pos < len) ? u : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const float wj = w[ci * 7 + j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = fmaf(wj, v[e + j + 1], s[e]);
+    }
+  }
+  if (t + 4 <= L && ((ldw & 3) == 0)) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (t + e < len) ? tanhf(s[e]) : 0.f;
+    *reinterpret_cast<f32x4*>(wb) = o;
+  } else {
+    for (int e = 0; e < 4 && t + e < L; ++e) wb[e] = (t + e < len) ? tanhf(s[e]) : 0.f;
+  }
+}
+
 void launch_conv_post(const float* x, const float* w, const float* bias, const int32_t* lengths,
                       int len_mul, int B, int C, int KS, int L, int ldx, long long x_bstride,
                       float slope, float* wav, int ldw, hipStream_t stream) {
+  if (KS == 7 && (ldx & 3) == 0 && (x_bstride & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)wav & 15) == 0) {
+    dim3 grid((L + 1023) / 1024, B);
+    hipLaunchKernelGGL(conv_post7_kernel, grid, dim3(256), 0, stream, x, w, bias, lengths, len_mul, C, L, ldx,
+                       x_bstride, slope, wav, ldw);
+    return;
+  }
   dim3 grid((L + POST_TILE - 1) / POST_TILE, B);
   const size_t lds = (size_t)C * (POST_TILE + KS - 1) * sizeof(float);
   hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), lds, stream, x, w, bias, lengths, len_mul,

@@ -422,6 +422,30 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
       }
       float* TMPc = multi ? TMPj[j] : TMPj[0];
       float* XKc = multi ? XKj[j] : XKj[0];
+      {
+        // narrow stages in exact fp32: each residual pair is ONE launch (respair.hip), ping-ponging
+        // X -> XK -> TMP -> MRF update of ACC (a pair cannot run in place: neighbours read its halo)
+        const size_t i0 = ((size_t)i * nk + j) * 3;
+        bool pairs = !g->rb1[i0].prec && g->rb1[i0].m32 == (ch >= 32 ? 1 : 0);
+        for (int m = 0; m < 3 && pairs; ++m)
+          pairs = respair_supported(ch, g->rb1[i0 + m].KS, g->rb1[i0 + m].dil);
+        if (pairs) {
+          const float* src[3] = {X, XKc, TMPc};
+          float* dst[3] = {XKc, TMPc, nullptr};
+          for (int m = 0; m < 3; ++m) {
+            int epi = EPI_RES;
+            if (m == 2) {
+              epi = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET) : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
+              if (multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));
+            }
+            if ((rc = launch_respair(g->rb1[i0 + m], g->rb2[i0 + m], src[m], dst[m], ACC, lengths, L, mul, B, L,
+                                     ld, 0.1f, epi, (float)nk, sj)))
+              return rc;
+          }
+          if (multi) DISSC_HIP_CHECK(hipEventRecord(g->ev_fin[j], sj));
+          continue;
+        }
+      }
       for (int m = 0; m < 3; ++m) {
         const size_t idx = ((size_t)i * nk + j) * 3 + m;
         const float* xin = (m == 0) ? X : XKc;
@@ -508,6 +532,7 @@ int dissc_get_option(const char* key, int* value) {
   if (strcmp(key, "multistream") == 0) { *value = g_multistream; return DISSC_OK; }
   if (strcmp(key, "stream_prio") == 0) { *value = g_stream_prio; return DISSC_OK; }
   if (strcmp(key, "par_ups") == 0) { *value = g_par_ups; return DISSC_OK; }
+  if (strcmp(key, "pair_max_c") == 0) { *value = g_pair_max_c; return DISSC_OK; }
   set_error("dissc_get_option: '%s' cannot be read back", key);
   return DISSC_EINVAL;
 }
@@ -543,6 +568,7 @@ int dissc_set_option(const char* key, int value) {
     return DISSC_OK;
   }
   if (strcmp(key, "fused_max_c") == 0) { fused_set_option(2, value); return DISSC_OK; }
+  if (strcmp(key, "pair_max_c") == 0) { g_pair_max_c = value; return DISSC_OK; }
   if (strcmp(key, "fused_variant") == 0) {
     fused_set_option(3, value);
     resblock_bf3_set_variant(value);

@@ -133,6 +133,8 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   small_grid (1)       launches with fewer than value x 256 workgroups step down to smaller conv tiles (0 = never)
  *   lin_tile (2)         1x1 convs: 16-channel chunks staged per barrier (2 or 4)
  *   cpb2 (0)             k <= value convs stage 32 channels per barrier
+ *   pair_max_c (32)      widest fp32 stage whose residual pairs (conv_d -> conv_1 -> +x) run as ONE launch each
+ *                        (respair.hip; 0 = every conv its own launch; results are bit-identical either way)
  *   fused_max_c (0)      widest ResBlock run as ONE fused launch (experimental: 16 or 32)
  *   bf3_pairs (-1)       split-bf16 fused ResBlocks as three launches of one residual pair each: -1 = for >= 64
  *                        channels only, 0 = never, 1 = always
@@ -143,7 +145,7 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   mfast (0)            M-fastest block order for convs with many M tiles
  * Unknown keys return DISSC_EINVAL. */
 int dissc_set_option(const char* key, int value);
-/* Read back one of: precision, multistream, stream_prio, par_ups (so that a wrapper can set an option
+/* Read back one of: precision, multistream, stream_prio, par_ups, pair_max_c (so that a wrapper can set an option
  * around the creation of one handle and restore it). */
 int dissc_get_option(const char* key, int* value);
 

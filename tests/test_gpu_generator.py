@@ -279,3 +279,28 @@ def test_precision_option_leaves_predictors_and_units_exact():
                         os.path.join(root, "tests", "test_gpu_hubert.py")],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_fused_residual_pairs_are_bit_identical_to_separate_launches(env):
+    """respair.hip (one launch per residual pair of the narrow stages) against the same generator with
+    every conv as its own launch ("pair_max_c" = 0): identical bits, for a ragged batch (window edges,
+    utterance ends inside a window, a 1-frame utterance) and at the BASELINE size."""
+    lib, g, synth = env["lib"], env["g"], env["synth"]
+    cur = ctypes.c_int(0)
+    assert lib.dissc_get_option(b"pair_max_c", ctypes.byref(cur)) == 0 and cur.value >= 16
+    cases = [synth.synth_generator_inputs(6, 41, seed=21, ragged=True), synth.synth_generator_inputs(32, 500, seed=1234)]
+    code, f0, spkr, lengths = cases[0]
+    lengths = lengths.copy()
+    lengths[1], lengths[2] = 1, 41
+    cases[0] = (code, f0, spkr, lengths)
+    for code, f0, spkr, lengths in cases:
+        kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
+                  lengths=torch.from_numpy(lengths))
+        y_pair = g(**kw).cpu()
+        try:
+            assert lib.dissc_set_option(b"pair_max_c", 0) == 0
+            y_sep = g(**kw).cpu()
+        finally:
+            lib.dissc_set_option(b"pair_max_c", cur.value)
+        assert torch.isfinite(y_pair).all()
+        assert torch.equal(y_pair, y_sep)
