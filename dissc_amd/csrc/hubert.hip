@@ -49,61 +49,88 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// pass 1: partial sums of x and x^2 per (b, tile, c) -> part[b][tile][c][2] (double)
-__global__ void __launch_bounds__(256) conv0_stats_kernel(const float* __restrict__ wav, int ldw,
-                                                          const float* __restrict__ w,
-                                                          const int32_t* __restrict__ len0, int ntile,
-                                                          double* __restrict__ part) {
-  __shared__ float red[4][2];
+// pass 1: GroupNorm statistics WITHOUT evaluating the 512 channels.  conv0 has one input channel, so
+// channel c's output is x_c[t] = sum_j w[c][j] * s[5t + j] and its moments are linear / quadratic forms of
+// the waveform's own lag moments:
+//     sum_t x_c     = sum_j   w_cj       * S_j ,   S_j  = sum_t s[5t+j]                (10 numbers)
+//     sum_t x_c^2   = sum_jk  w_cj w_ck  * R_jk,   R_jk = sum_t s[5t+j] * s[5t+k]      (55 numbers, j <= k)
+// One light pass over the 1-channel waveform (65 fp64 partial sums per 1024-frame tile, fixed reduction
+// order -> deterministic), then 512 tiny quadratic forms per utterance.  All in double: more accurate than
+// summing fp32 outputs, and 512x less arithmetic than a pass that evaluates the channels.
+constexpr int C0_NM = 65;  // 10 + 55
+
+__global__ void __launch_bounds__(256) conv0_moments_kernel(const float* __restrict__ wav, int ldw,
+                                                            const int32_t* __restrict__ len0, int ntile,
+                                                            double* __restrict__ part) {
+  __shared__ double red[4][C0_NM];
   const int b = blockIdx.y, tile = blockIdx.x;
   const int T0 = len0[b];
   const int t = tile * C0_TILE + threadIdx.x * 4;
-  double* pb = part + ((size_t)b * ntile + tile) * C0_CH * 2;
-  float s[25];
   const float* wb = wav + (size_t)b * ldw;
+  double acc[C0_NM];
+#pragma unroll
+  for (int i = 0; i < C0_NM; ++i) acc[i] = 0.0;
+  float s[25];
   const bool any = t < T0;
 #pragma unroll
   for (int i = 0; i < 25; ++i) s[i] = (any && (5 * t + i) < 5 * (T0 - 1) + 10) ? wb[5 * t + i] : 0.f;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int c = 0; c < C0_CH; ++c) {
-    float sum = 0.f, sq = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float x = 0.f;
+  for (int e = 0; e < 4; ++e) {
+    if (t + e < T0) {
+      int idx = 10;
 #pragma unroll
-      for (int j = 0; j < 10; ++j) x = fmaf(w[c * 10 + j], s[5 * e + j], x);
-      if (t + e < T0) {
-        sum += x;
-        sq = fmaf(x, x, sq);
+      for (int j = 0; j < 10; ++j) {
+        const double sj = (double)s[5 * e + j];
+        acc[j] += sj;
+#pragma unroll
+        for (int k = j; k < 10; ++k) { acc[idx] = fma(sj, (double)s[5 * e + k], acc[idx]); ++idx; }
       }
     }
-    sum = wave_sum(sum);
-    sq = wave_sum(sq);
-    if (lane == 0) {
-      red[wv][0] = sum;
-      red[wv][1] = sq;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      pb[c * 2] = (double)red[0][0] + red[1][0] + red[2][0] + red[3][0];
-      pb[c * 2 + 1] = (double)red[0][1] + red[1][1] + red[2][1] + red[3][1];
-    }
-    __syncthreads();
   }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < C0_NM; ++i) {
+    double v = acc[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) red[wv][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < C0_NM)
+    part[((size_t)b * ntile + tile) * C0_NM + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-// reduce the tile partials in a fixed order -> mean / rstd per (b, c)
-__global__ void conv0_finalize_kernel(const double* __restrict__ part, const int32_t* __restrict__ len0,
-                                      int ntile, float eps, float* __restrict__ stats) {
+// tile partials (fixed order) -> mean / rstd per (b, c)
+__global__ void __launch_bounds__(128) conv0_finalize_kernel(const double* __restrict__ part,
+                                                             const float* __restrict__ w,
+                                                             const int32_t* __restrict__ len0, int ntile, float eps,
+                                                             float* __restrict__ stats) {
+  __shared__ double M[C0_NM];
   const int b = blockIdx.y;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C0_CH) return;
   const int T0 = len0[b];
   const int nt = (T0 + C0_TILE - 1) / C0_TILE;
-  double s = 0, q = 0;
-  for (int i = 0; i < nt; ++i) {
-    s += part[(((size_t)b * ntile + i) * C0_CH + c) * 2];
-    q += part[(((size_t)b * ntile + i) * C0_CH + c) * 2 + 1];
+  if (threadIdx.x < C0_NM) {
+    double v = 0.0;
+    for (int i = 0; i < nt; ++i) v += part[((size_t)b * ntile + i) * C0_NM + threadIdx.x];
+    M[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (c >= C0_CH) return;
+  double wj[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) wj[j] = (double)w[c * 10 + j];
+  double s = 0.0, q = 0.0;
+  int idx = 10;
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    s += wj[j] * M[j];
+#pragma unroll
+    for (int k = j; k < 10; ++k) {
+      const double term = wj[j] * wj[k] * M[idx++];
+      q += (k == j) ? term : 2.0 * term;
+    }
   }
   const double n = T0 > 0 ? (double)T0 : 1.0;
   const double mean = s / n;
@@ -342,9 +369,14 @@ __global__ void __launch_bounds__(256) attn_fused_kernel(const float* __restrict
   const float* kb = qb + (size_t)D * ld;
   const float* vb = qb + (size_t)2 * D * ld;
   // Q tile -> LDS (zero beyond T)
-  for (int e = tid; e < 64 * AT_Q; e += 256) {
-    const int d = e / AT_Q, c = e - d * AT_Q;
-    Qs[d * AT_LDQQ + c] = (q0 + c < T) ? qb[(size_t)d * ld + q0 + c] : 0.f;
+  for (int e = tid; e < 64 * (AT_Q / 4); e += 256) {
+    const int d = e / (AT_Q / 4), c = (e - d * (AT_Q / 4)) * 4;
+    int col = q0 + c;
+    col = col > ld - 4 ? ld - 4 : col;
+    f32x4 v = *reinterpret_cast<const f32x4*>(qb + (size_t)d * ld + col);
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) v[e2] = (q0 + c + e2 < T) ? v[e2] : 0.f;
+    *reinterpret_cast<f32x4*>(Qs + d * AT_LDQQ + c) = v;
   }
   __syncthreads();
   // this wave's AT_NQ groups of 16 queries: k-step ks -> Q[d = 4*ks + g][query = (wave*AT_NQ + j)*16 + l15].
@@ -363,56 +395,100 @@ __global__ void __launch_bounds__(256) attn_fused_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // K / V tiles of 64 keys: the NEXT tile is fetched into registers (16 B per lane, clamped in-bounds
+  // loads) while the current one is on the matrix pipe, and written to LDS between the two barriers.
+  f32x4 kr[4], vr[4];
+  auto tile_load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      const int d = e >> 4, c = (e & 15) * 4;
+      int col = k0 + c;
+      col = col > ld - 4 ? ld - 4 : col;  // beyond the row: every key of this slot is >= T and masked below
+      kr[i] = *reinterpret_cast<const f32x4*>(kb + (size_t)d * ld + col);
+      vr[i] = *reinterpret_cast<const f32x4*>(vb + (size_t)d * ld + col);
+    }
+  };
+  auto tile_store = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      const int d = e >> 4, c = (e & 15) * 4;
+      f32x4 kv = kr[i], vv = vr[i];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const bool ok = k0 + c + e2 < T;  // V must be 0 beyond T: p = 0 there, and 0 * garbage may be NaN
+        kv[e2] = ok ? kv[e2] : 0.f;
+        vv[e2] = ok ? vv[e2] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(Ks + d * AT_LDQ + c) = kv;
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) Vs[d * AT_LDV + c + e2] = vv[e2];
+    }
+  };
+  tile_load(0);
   for (int k0 = 0; k0 < T; k0 += AT_K) {
     __syncthreads();  // previous tile fully consumed
-    for (int e = tid; e < 64 * AT_K; e += 256) {
-      const int d = e >> 6, c = e & 63;
-      const bool ok = k0 + c < T;
-      Ks[d * AT_LDQ + c] = ok ? kb[(size_t)d * ld + k0 + c] : 0.f;
-      Vs[d * AT_LDV + c] = ok ? vb[(size_t)d * ld + k0 + c] : 0.f;
-    }
+    tile_store(k0);
     __syncthreads();
+    if (k0 + AT_K < T) tile_load(k0 + AT_K);
+    __builtin_amdgcn_sched_barrier(0);
+    // S^T for all 64 keys of the tile: sT[j][sub][r] = S[query l15 of group j][key k0 + sub*16 + 4g + r]
+    f32x4 sT[AT_NQ][4];
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-      if (k0 + sub * 16 >= T) break;  // uniform
-      f32x4 sT[AT_NQ];
+    for (int j = 0; j < AT_NQ; ++j)
 #pragma unroll
-      for (int j = 0; j < AT_NQ; ++j) sT[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int sub = 0; sub < 4; ++sub) sT[j][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const float kf = Ks[(4 * ks + g) * AT_LDQ + sub * 16 + l15];
 #pragma unroll
-        for (int j = 0; j < AT_NQ; ++j) sT[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, qf[j][ks], sT[j], 0, 0, 0);
+        for (int j = 0; j < AT_NQ; ++j)
+          sT[j][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, qf[j][ks], sT[j][sub], 0, 0, 0);
       }
-      // sT[j][r] = S[query l15 of group j][key k0 + sub*16 + 4g + r]
-      float p[AT_NQ][4];
+    if (k0 + AT_K > T) {  // uniform: only the last tile has keys beyond T
 #pragma unroll
-      for (int j = 0; j < AT_NQ; ++j) {
-        float mx = -INFINITY;
+      for (int j = 0; j < AT_NQ; ++j)
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + sub * 16 + 4 * g + r >= T) sT[j][sub][r] = -INFINITY;
+    }
+    // one online-softmax step per 64 keys (exp through v_exp_f32: e^x = 2^(x log2 e))
+#pragma unroll
+    for (int j = 0; j < AT_NQ; ++j) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sT[j][sub][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mn = fmaxf(m[j], mx);  // finite: the tile has at least one valid key
+      const float alpha = __expf(m[j] - mn);
+      float ps = 0.f;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (k0 + sub * 16 + 4 * g + r >= T) sT[j][r] = -INFINITY;
-          mx = fmaxf(mx, sT[j][r]);
+          sT[j][sub][r] = __expf(sT[j][sub][r] - mn);
+          ps += sT[j][sub][r];
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mn = fmaxf(m[j], mx);  // finite: the sub-tile has at least one valid key
-        const float alpha = expf(m[j] - mn);
-        float ps = 0.f;
+      ps += __shfl_xor(ps, 16);
+      ps += __shfl_xor(ps, 32);
+      l[j] = l[j] * alpha + ps;
+      m[j] = mn;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          p[j][r] = expf(sT[j][r] - mn);
-          ps += p[j][r];
-        }
-        ps += __shfl_xor(ps, 16);
-        ps += __shfl_xor(ps, 32);
-        l[j] = l[j] * alpha + ps;
-        m[j] = mn;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          o[j][i][0] *= alpha; o[j][i][1] *= alpha; o[j][i][2] *= alpha; o[j][i][3] *= alpha;
-        }
+      for (int i = 0; i < 4; ++i) {
+        o[j][i][0] *= alpha; o[j][i][1] *= alpha; o[j][i][2] *= alpha; o[j][i][3] *= alpha;
       }
+    }
+    // O += V P^T: k-step st of sub-tile sub uses key sub*16 + 4g + st = register st of the same lane
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -420,9 +496,8 @@ __global__ void __launch_bounds__(256) attn_fused_kernel(const float* __restrict
           const float vf = Vs[(i * 16 + l15) * AT_LDV + sub * 16 + 4 * g + st];
 #pragma unroll
           for (int j = 0; j < AT_NQ; ++j)
-            o[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, p[j][st], o[j][i], 0, 0, 0);
+            o[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, sT[j][sub][st], o[j][i], 0, 0, 0);
         }
-    }
   }
   // o[j][i][r] = O[d = i*16 + 4g + r][query = (wave*AT_NQ + j)*16 + l15] (unnormalised)
 #pragma unroll
@@ -629,7 +704,7 @@ void dissc_hubert_destroy(dissc_hubert_t m) { delete m; }
 // workspace carve-up (floats unless noted)
 struct HubertWs {
   int32_t* lens;     // [7][B]
-  double* part;      // [B][ntile][512][2]
+  double* part;      // [B][ntile][65] lag moments of the waveform
   float* stats;      // [B][512][2]
   float* f[2];       // ping-pong feature buffers, each B*512*ld0 floats
   float *x, *y, *t1; // [B][768][ldT]
@@ -653,7 +728,7 @@ static HubertWs carve(const dissc_hubert* m, int B, int Nmax, void* base_) {
     return r;
   };
   w.lens = (int32_t*)take((size_t)NCONV * B * 4);
-  w.part = (double*)take((size_t)B * ntile * C0_CH * 2 * 8);
+  w.part = (double*)take((size_t)B * ntile * C0_NM * 8);
   w.stats = (float*)take((size_t)B * C0_CH * 2 * 4);
   w.f[0] = (float*)take((size_t)B * 512 * ld0 * 4);
   const size_t ld1 = rup(frames_after(Nmax, 1) > 0 ? frames_after(Nmax, 1) : 1, 4);
@@ -701,8 +776,8 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
   hipLaunchKernelGGL(hubert_lengths_kernel, dim3((B + 63) / 64), dim3(64), 0, st, n_samples, B, Nmax, w.lens);
   // conv0 + GroupNorm + GELU
   dim3 g0((T0 + C0_TILE - 1) / C0_TILE, B);
-  hipLaunchKernelGGL(conv0_stats_kernel, g0, dim3(256), 0, st, wav, Nmax, m->w0, w.lens, ntile, w.part);
-  hipLaunchKernelGGL(conv0_finalize_kernel, dim3(C0_CH / 128, B), dim3(128), 0, st, w.part, w.lens, ntile,
+  hipLaunchKernelGGL(conv0_moments_kernel, g0, dim3(256), 0, st, wav, Nmax, w.lens, ntile, w.part);
+  hipLaunchKernelGGL(conv0_finalize_kernel, dim3(C0_CH / 128, B), dim3(128), 0, st, w.part, m->w0, w.lens, ntile,
                      1e-5f, w.stats);
   hipLaunchKernelGGL(conv0_apply_kernel, g0, dim3(256), 0, st, wav, Nmax, m->w0, m->gn_g, m->gn_b, w.stats,
                      w.lens, w.f[0], ld0);
