@@ -143,14 +143,20 @@ def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_se
 
 
 def hbm_traffic(B, T):
-    """HBM bytes per step from the committed PMC capture (profiles/r01/hbm_traffic.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950
-    correction applied); only valid for the shape it was captured on."""
-    try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")))
-        return j["bytes_per_step_B32_T500"] if (B, T) == (32, 500) else None
-    except Exception:
-        return None
+    """HBM bytes per step from the latest committed PMC capture of these kernels (profiles/rNN/hbm_traffic.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 correction applied,
+    tools/capture_profiles.sh + tools/prof_tables.py); only valid for the shape it was captured on.
+    PMC counters cannot be read from inside the timed run, so this is a committed measurement, named in
+    the output (`traffic_source`)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+            if (B, T) == (32, 500):
+                return j["bytes_per_step_B32_T500"], os.path.relpath(path, ROOT) + ": " + j.get("kernel_version", "")
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -288,8 +294,8 @@ def main():
                        "collective": "1 all_gather of waveforms per step" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": hbm_traffic(B, T),
-                         "kernel": "conv_mfma32_kernel family (all generator convs; fp32 v_mfma_f32_32x32x2, 16x16x4 on the 16-channel stage)",
+                         "traffic": hbm_traffic(B, T)[0], "traffic_source": hbm_traffic(B, T)[1],
+                         "kernel": "all generator convs: conv_mfma32_kernel (fp32 v_mfma_f32_32x32x2) on the C >= 64 stages, respair32/respair16 fused residual pairs (32x32x2 / 16x16x4) on the C = 32 / 16 stages",
                          "flops_per_step": flops_step, "kernel_ms_per_step": round(kern_s * 1e3, 3)},
         }
         traffic = out["roofline"]["traffic"]
