@@ -9,8 +9,9 @@ Differences in execution: files are encoded in length-sorted batches through the
 (per-utterance exact) instead of one B=1 call each; lines are appended batch by batch.
 Checkpoints are not downloaded (no network): ``--checkpoint_dir`` / $DISSC_CHECKPOINT_DIR must
 hold ``<model_name>.pt`` and ``<quantizer_name>_<vocab_size>.{npy,bin,pt}``.
-``--f0 zeros`` (explicit, with a warning) writes an all-unvoiced track, valid only for the
---pred_pitch flows where infer.py never reads it (reference infer.py:36-39,149-155).
+``f0`` is tracked with YAAPT on the GPU (dissc_amd/f0.py; parity with amfm_decompy unpinned, see
+oracle/yaapt_ref.py); ``--f0 zeros`` (explicit, with a warning) skips it and writes an all-unvoiced track, valid
+only for the --pred_pitch flows where infer.py never reads it (reference infer.py:36-39,149-155).
 """
 import argparse
 import json
@@ -53,9 +54,17 @@ def wav_frames(path):
         return len(load_wav(path)[0])
 
 
+_TRACKER = {}
+
+
 def track_f0(wav, ns, frames, args):
-    """F0 per unit frame for a batch: list of lists, 0.0 = unvoiced."""
-    raise NotImplementedError("--f0 yaapt: the F0 tracker is not built yet")
+    """F0 per unit frame for a batch: YAAPT at a 5 ms hop on the GPU (dissc_amd/f0.py), then the
+    mean of the voiced values of each 20 ms unit -- list of lists of Hz, 0.0 = unvoiced."""
+    from dissc_amd.f0 import YaaptTracker, f0_per_unit
+    if args.device not in _TRACKER:
+        _TRACKER[args.device] = YaaptTracker(device=args.device)
+    tracks = _TRACKER[args.device]([wav[k, :int(ns[k])] for k in range(len(ns))])
+    return [[float(v) for v in f0_per_unit(t, int(T)).astype(np.float32)] for t, T in zip(tracks, frames)]
 
 
 def main(argv=None):
@@ -68,7 +77,7 @@ def main(argv=None):
     parser.add_argument('--device', default='cuda:0', help='Device to run on')
     parser.add_argument('--checkpoint_dir', default=None, help='local directory with the HuBERT / k-means files')
     parser.add_argument('--batch_seconds', default=640.0, type=float, help='audio seconds per GPU batch')
-    parser.add_argument('--f0', default='zeros', choices=['zeros', 'yaapt'],
+    parser.add_argument('--f0', default='yaapt', choices=['yaapt', 'zeros'],
                         help="'yaapt': track F0 like the reference's encoder does; 'zeros': write an all-unvoiced "
                              "track (only valid for the --pred_pitch flows, which never read it)")
     args = parser.parse_args(argv)

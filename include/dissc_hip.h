@@ -262,6 +262,52 @@ int dissc_pack_waves(const float* wav, long long ld_wav, const int32_t* n_sample
                      int B, float* buf, long long ld_buf, int row0, void* stream);
 int dissc_pack_empty_rows(float* buf, long long ld_buf, int row0, int rows, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * YAAPT F0 tracker, device front end.
+ * Replaces the numerically heavy stages of amfm_decompy.pYAAPT.yaapt as the reference calls it
+ *   (get_yaapt_f0, reference sr/dataset.py:27-43; eval.py:26-33; inside textless' SpeechEncoder for
+ *   data/encode.py:32): band-pass FIR of the signal and of its square, the per-frame spectra behind NLFER and
+ *   the spectral-harmonics-correlation candidates, and the NCCF candidates.  amfm_decompy is an un-vendored
+ *   third party that is absent offline: the algorithm is restated in oracle/yaapt_ref.py, PARITY UNPINNED.
+ *   The short sequential stages (median smoothing, dynamic programming) are host logic in dissc_amd/f0.py.
+ * fir: HOST f32 [n_taps] band-pass coefficients (scipy.signal.firwin in the caller, like amfm_decompy).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  int32_t fs;            /* 16000 */
+  int32_t frame_len;     /* samples: frame_length 20 ms -> 320 */
+  int32_t frame_hop;     /* frame_space 5 ms -> 80 */
+  int32_t tda_len;       /* tda_frame_length 25 ms -> 400 */
+  int32_t nfft;          /* fft_length 8192 */
+  float f0_min, f0_max;  /* 60, 400 */
+  int32_t shc_numharms;  /* 3 */
+  float shc_window_hz, shc_pwidth_hz, shc_thresh1, shc_thresh2, f0_double, f0_half; /* 40, 50, 5, 1.25, 150, 150 */
+  float nccf_thresh1, nccf_thresh2; /* 0.25 (reference override), 0.9 */
+  int32_t nccf_pwidth;   /* 5 */
+} DisscYaaptConfig;
+typedef struct dissc_yaapt* dissc_yaapt_t;
+int dissc_yaapt_create(const float* fir, int n_taps, const DisscYaaptConfig* cfg, dissc_yaapt_t* out);
+void dissc_yaapt_destroy(dissc_yaapt_t y);
+/* frames of the spectral stages / of the time-domain stage for n_samples input samples; SHC bins per frame */
+int dissc_yaapt_frames(dissc_yaapt_t y, int n_samples);
+int dissc_yaapt_tda_frames(dissc_yaapt_t y, int n_samples);
+int dissc_yaapt_shc_bins(dissc_yaapt_t y);
+size_t dissc_yaapt_workspace_bytes(dissc_yaapt_t y, int B, int Nmax);
+/* wav f32 [B,Nmax] (already zero-padded by frame_len/2 at both ends, as the reference does), n_samples i32 [B]
+ * (NULL = Nmax), F = dissc_yaapt_frames(Nmax) ->
+ *   filt, nlfilt f32 [B,Nmax]   band-passed signal / squared signal
+ *   energy f32 [B,F]            NLFER band sums (un-normalised; 0 beyond an utterance's frames)
+ *   cand_pitch, cand_merit f32 [B,F,4]   SHC peak candidates per frame (pitch 0 / merit 1 = no candidate)
+ *   shc_out f32 [B,F,shc_bins]  optional (NULL): the SHC itself, for tests */
+int dissc_yaapt_spectral(dissc_yaapt_t y, const float* wav, const int32_t* n_samples, int B, int Nmax, float* filt,
+                         float* nlfilt, float* energy, float* cand_pitch, float* cand_merit, float* shc_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* NCCF candidates of `sig` (filt or nlfilt): frame f = sig[f*hop : f*hop + tda_len], lags lag_min[b,f] <= lag <
+ * lag_max[b,f] (i32 [B,F], from the spectral track) -> pitch, merit f32 [B,F,3]; phi_out f32 [B,F,tda_len]
+ * optional (NULL).  Frames beyond dissc_yaapt_tda_frames(n_samples[b]) give pitch 0 / merit 0.001. */
+int dissc_yaapt_nccf(dissc_yaapt_t y, const float* sig, const int32_t* n_samples, const int32_t* lag_min,
+                     const int32_t* lag_max, int B, int Nmax, int F, float* pitch, float* merit, float* phi_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,153 @@
+"""YAAPT F0 tracker on the GPU (dissc_amd/f0.py + csrc/yaapt.hip through the C ABI) against the CPU restatement
+(oracle/yaapt_ref.py) stage by stage, against known-F0 signals, and through data/encode.py --f0 yaapt.
+PARITY UNPINNED against amfm_decompy (absent offline)."""
+import importlib.util
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from scipy.io import wavfile
+
+from test_yaapt import CASES, FS, check_track, pulse_train, voiced
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def trk():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from dissc_amd.f0 import YaaptTracker
+    return YaaptTracker(device="cuda:0")
+
+
+def _signals():
+    rs = np.random.RandomState(5)
+    a = np.concatenate([voiced(np.linspace(110, 180, 16000)), 0.002 * rs.standard_normal(4000), voiced(np.full(12000, 240.0))])
+    b = voiced(180 + 15 * np.sin(2 * np.pi * 5 * np.arange(20000) / FS)) + 0.001 * rs.standard_normal(20000)
+    return [a, b]
+
+
+def test_front_end_stages_match_the_oracle(trk):
+    """ragged batch of 2 (NaN in the padding): band-pass, NLFER energy, SHC, SHC candidates, NCCF, NCCF candidates"""
+    from oracle import yaapt_ref as yr
+    sigs = [np.pad(x, (160, 160)) for x in _signals()]
+    lens = [len(s) for s in sigs]
+    N = (max(lens) + 3) // 4 * 4
+    wav = torch.full((2, N), float("nan"))
+    for i, s in enumerate(sigs):
+        wav[i, :lens[i]] = torch.from_numpy(s.astype(np.float32))
+    out = trk.spectral(wav, torch.tensor(lens, dtype=torch.int32), want_shc=True)
+    F = out["F"]
+    for i, s in enumerate(sigs):
+        s32 = s.astype(np.float32).astype(np.float64)
+        filt, nl = yr.bandpass(s32, FS), yr.bandpass(s32 * s32, FS)
+        n = lens[i]
+        for got, want in ((out["filt"][i, :n].cpu().numpy(), filt), (out["nlfilt"][i, :n].cpu().numpy(), nl)):
+            assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+        nframe, njump, samples = yr.frame_geometry(n, FS)
+        f = len(samples)
+        assert trk.spectral.__self__ is trk and f <= F
+        # raw NLFER band sums
+        win = yr.hann(nframe + 2)[1:-1]
+        spec = np.fft.rfft(yr.stride_matrix(filt, f, nframe, njump) * win, 8192)
+        raw = np.abs(spec[:, 60:205]).sum(axis=1)
+        got = out["energy"][i, :f].cpu().numpy()
+        assert np.abs(got - raw).max() <= 1e-4 * raw.max()
+        assert not out["energy"][i, f:].cpu().numpy().any()
+        # SHC + candidates on a sample of voiced frames
+        energy, vuv = yr.nlfer(filt, FS)
+        data = np.append(nl, np.zeros(2 * nframe + (f - 1) * njump - n))
+        kw = yr.kaiser(2 * nframe, 0.5)
+        shc_g = out["shc"][i].cpu().numpy()
+        cp, cm = out["cand_pitch"][i].cpu().numpy(), out["cand_merit"][i].cpu().numpy()
+        same = tot = 0
+        for fr in np.nonzero(vuv)[0][::7]:
+            sl = data[fr * njump:fr * njump + 2 * nframe] * kw
+            shc = yr.shc_of_magnitude(np.abs(np.fft.rfft(sl - sl.mean(), 8192)), FS)
+            assert np.abs(shc_g[fr] - shc).max() <= 2e-3 * shc.max(), fr
+            p, m = yr.peaks(shc, FS / 8192.0, 4)
+            tot += 1
+            same += int(np.allclose(cp[fr], p, rtol=1e-5, atol=1e-3) and np.allclose(cm[fr], m, rtol=2e-3, atol=2e-3))
+        assert tot > 20 and same >= 0.97 * tot, (same, tot)
+        # NCCF inside the oracle's lag ranges
+        cand_p = np.where(vuv[None, :], cp[:f].T, 0.0)
+        cand_m = np.where(vuv[None, :], cm[:f].T, 1.0)
+        sp, std, _ = yr.spec_track_from_candidates(cand_p.astype(np.float64), cand_m.astype(np.float64))
+        tda, hop, nfr = yr.tda_geometry(n, FS, f)
+        lo, hi = yr.lag_ranges(sp[:nfr], std, FS)
+        lmin, lmax = np.ones((2, F), np.int32), np.full((2, F), 2, np.int32)
+        lmin[i, :nfr], lmax[i, :nfr] = lo, hi
+        pit, mer, phi = trk.nccf(out["filt"], out["n_samples"], lmin, lmax, want_phi=True)
+        pit, mer, phi = pit[i].cpu().numpy(), mer[i].cpu().numpy(), phi[i].cpu().numpy()
+        same = 0
+        for fr in range(0, nfr, 5):
+            want = yr.crs_corr(filt[fr * hop:fr * hop + tda], int(lo[fr]), int(hi[fr]))
+            assert np.abs(phi[fr] - want).max() <= 5e-4, fr
+            p, m = yr.cmp_rate(want, FS, 3, int(lo[fr]), int(hi[fr]))
+            same += int(np.allclose(pit[fr], p, rtol=1e-5) and np.allclose(mer[fr], m, atol=1e-3))
+        assert same >= 0.97 * len(range(0, nfr, 5))
+        assert np.all(pit[nfr:] == 0) and np.allclose(mer[nfr:], 0.001)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_tracker_on_known_f0(trk, name):
+    f0 = trk([voiced(CASES[name])])[0]
+    assert f0.dtype == np.float32 and len(f0) == 300
+    check_track(f0.astype(np.float64), CASES[name])
+
+
+def test_tracker_agrees_with_the_oracle_and_is_batch_independent(trk):
+    from oracle import yaapt_ref as yr
+    sigs = _signals() + [pulse_train(140.0, 24000), np.zeros(8000), 0.1 * np.random.RandomState(0).standard_normal(24000)]
+    got = trk(sigs)
+    for i, x in enumerate(sigs):
+        want = yr.get_yaapt_f0(x.astype(np.float32))
+        assert len(got[i]) == len(want)
+        both = (got[i] > 0) & (want > 0)
+        agree_v = ((got[i] > 0) == (want > 0)).mean()
+        assert agree_v >= 0.97, (i, agree_v)
+        if both.any():
+            rel = np.abs(got[i][both] - want[both]) / want[both]
+            assert (rel <= 5e-3).mean() >= 0.97, (i, np.percentile(rel, 97))
+        alone = trk([x])[0]  # an utterance on its own == the same utterance in the batch
+        np.testing.assert_array_equal(alone, got[i])
+    assert not got[3].any() and (got[4] > 0).mean() <= 0.1
+
+
+def test_encode_cli_writes_yaapt_f0_and_prep_dataset_accepts_it(trk, tmp_path):
+    """data/encode.py (default --f0 yaapt) -> per-unit F0 in Hz -> data/prep_dataset.py statistics: the chain the
+    ADVICE of round 1 found broken (all-zero f0 -> NaN statistics)."""
+    import synthdata as synth
+    td = str(tmp_path)
+    os.makedirs(f"{td}/ckpt")
+    os.makedirs(f"{td}/wav")
+    torch.save({"model": synth.synth_hubert_state_dict(6)}, f"{td}/ckpt/hubert-base-ls960.pt")
+    np.save(f"{td}/ckpt/kmeans_100.npy", synth.synth_kmeans_centers().numpy())
+    f0s = {"spk1_001.wav": 120.0, "spk1_002.wav": 130.0, "spk2_001.wav": 210.0}
+    for nm, f in f0s.items():
+        x = voiced(np.full(24000, f))
+        wavfile.write(f"{td}/wav/{nm}", FS, np.round(x / np.abs(x).max() * 20000).astype(np.int16))
+    spec = importlib.util.spec_from_file_location("enc_cli_yaapt", os.path.join(ROOT, "data", "encode.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    cli.main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/enc/train.txt", "--checkpoint_dir", f"{td}/ckpt"])
+    lines = [json.loads(x) for x in open(f"{td}/enc/train.txt").read().strip().split("\n")]
+    assert sorted(d["audio"] for d in lines) == sorted(f0s)
+    for d in lines:
+        f0 = np.array(d["f0"])
+        assert len(f0) == len(d["units"]) == 74  # (24000 - 400) // 320 + 1
+        v = f0[3:-3]
+        assert (v > 0).all() and np.abs(v - f0s[d["audio"]]).max() <= 0.02 * f0s[d["audio"]]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "data", "prep_dataset.py"), "--encoded_path",
+                        f"{td}/enc/train.txt", "--stats_path", f"{td}/enc/f0_stats.pkl"],
+                       capture_output=True, text=True, timeout=600, cwd=td)
+    assert r.returncode == 0, r.stderr
+    stats = pickle.load(open(f"{td}/enc/f0_stats.pkl", "rb"))
+    assert abs(stats["spk1"]["mean"] - 125.0) < 2.5 and abs(stats["spk2"]["mean"] - 210.0) < 4.2
