@@ -96,3 +96,56 @@ extern "C" int dissc_pack_empty_rows(float* buf, long long ld_buf, int row0, int
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
+
+// ---- band-limited sinc resampling (the step before the path: reference data/preprocess.py:19-23) --------
+// y[t] = sum_i w(frac + i) x[n - i] + sum_k w(1 - frac + k) x[n + 1 + k], n = floor(t / ratio): resampy's
+// resample_f [3P-unverified, restated in oracle/preprocess_ref.py] with its Kaiser-windowed sinc table
+// (interp_win, linearly interpolated with interp_delta).  fp64 like the reference; one thread per output sample.
+namespace dissc {
+__global__ void __launch_bounds__(256) resample_kernel(const double* __restrict__ x, int n_orig, double* __restrict__ y,
+                                                       int n_out, double ratio, const double* __restrict__ win,
+                                                       const double* __restrict__ delta, int nwin, int num_table) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_out) return;
+  const double scale = ratio < 1.0 ? ratio : 1.0;
+  const int index_step = (int)(scale * num_table);
+  const double time_register = (double)t * (1.0 / ratio);
+  const int n = (int)time_register;
+  double frac = scale * (time_register - n);
+  double index_frac = frac * num_table;
+  int offset = (int)index_frac;
+  double eta = index_frac - offset;
+  double acc = 0.0;
+  int i_max = (nwin - offset) / index_step;
+  i_max = i_max < n + 1 ? i_max : n + 1;
+  for (int i = 0; i < i_max; ++i) {
+    const int j = offset + i * index_step;
+    acc += (win[j] + eta * delta[j]) * x[n - i];
+  }
+  frac = scale - frac;
+  index_frac = frac * num_table;
+  offset = (int)index_frac;
+  eta = index_frac - offset;
+  int k_max = (nwin - offset) / index_step;
+  k_max = k_max < n_orig - n - 1 ? k_max : n_orig - n - 1;
+  for (int k = 0; k < k_max; ++k) {
+    const int j = offset + k * index_step;
+    acc += (win[j] + eta * delta[j]) * x[n + k + 1];
+  }
+  y[t] = acc;
+}
+}  // namespace dissc
+
+extern "C" int dissc_resample(const double* x, int n_orig, double* y, int n_out, double ratio, const double* win,
+                              const double* delta, int nwin, int num_table, void* stream) {
+  if (!x || !y || !win || !delta || n_orig <= 0 || n_out < 0 || ratio <= 0.0 || nwin < 2 || num_table < 1 ||
+      (int)((ratio < 1.0 ? ratio : 1.0) * num_table) < 1) {
+    set_error("dissc_resample: bad argument");
+    return DISSC_EINVAL;
+  }
+  if (n_out == 0) return DISSC_OK;
+  hipLaunchKernelGGL(resample_kernel, dim3((n_out + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, n_orig, y, n_out,
+                     ratio, win, delta, nwin, num_table);
+  DISSC_HIP_CHECK(hipGetLastError());
+  return DISSC_OK;
+}

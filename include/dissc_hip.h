@@ -308,6 +308,17 @@ int dissc_yaapt_nccf(dissc_yaapt_t y, const float* sig, const int32_t* n_samples
                      const int32_t* lag_max, int B, int Nmax, int F, float* pitch, float* merit, float* phi_out,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Band-limited sinc resampling.
+ * Replaces: resampy.resample(data, sr, 16000) at reference data/preprocess.py:22 (and sr/dataset.py:226) --
+ * an un-vendored third party; algorithm (Kaiser-windowed sinc table, linear table interpolation) restated in
+ * oracle/preprocess_ref.py, PARITY UNPINNED.  All arrays fp64 on the device: x [n_orig] -> y [n_out],
+ * ratio = sr_new / sr_orig, win / delta [nwin] = the (already ratio-scaled) filter table and its differences,
+ * num_table = table entries per zero crossing (2^precision).
+ * ------------------------------------------------------------------------- */
+int dissc_resample(const double* x, int n_orig, double* y, int n_out, double ratio, const double* win,
+                   const double* delta, int nwin, int num_table, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,18 +51,20 @@ def load_gt(path, code_len, pad=None, sampling_rate=16000, code_hop_size=None):
     """Ground-truth audio exactly as CodeDataset.__getitem__ prepares it (reference
     sr/dataset.py:221-264,199-219): int16 -> /32768 -> peak*0.95 -> [eval_mode False only: trim to
     min(len//code_hop_size, code_len) hops] -> trim to a whole number of hops.  None when the wav is
-    missing (the reference would crash).  A sample-rate mismatch raises: the reference resamples
-    with resampy (sr/dataset.py:225-227), which is not available to pin against."""
+    missing (the reference would crash).  A wav at another rate is resampled like the reference does
+    (sr/dataset.py:225-227; resampy restated, parity unpinned)."""
     if not os.path.isfile(path):
         return None
     sr, audio = wavfile.read(path)
-    if sr != sampling_rate:
-        raise ValueError(f"{path}: sample rate {sr} != {sampling_rate}; resample first "
-                         "(data/preprocess.py), the reference would resample with resampy here")
-    if audio.dtype != np.int16:
-        audio = (np.clip(audio, -1, 1) * 32767).astype(np.int16) if audio.dtype.kind == 'f' else audio.astype(np.int16)
     if audio.ndim > 1:
         audio = audio[:, 0]
+    if audio.dtype != np.int16:  # the reference reads with dtype='int16' (sr/dataset.py:97-105)
+        audio = (np.clip(audio, -1, 1) * 32767).astype(np.int16) if audio.dtype.kind == 'f' else audio.astype(np.int16)
+    if sr != sampling_rate:
+        # reference sr/dataset.py:225-227 (resampy.resample of the int16-valued samples -> float64): same kernel
+        # as data/preprocess.py (dissc_amd.audio.resample; parity with resampy unpinned)
+        from dissc_amd import audio as _audio
+        audio = _audio.resample(audio.astype(np.float64), sr, sampling_rate)
     if pad:
         audio = np.pad(audio, (0, pad - (audio.shape[-1] % pad)), "constant")
     audio = audio / MAX_WAV_VALUE
