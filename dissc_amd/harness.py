@@ -127,18 +127,14 @@ def pack_waves(waves, job_ids, n_max, l_max, device):
     return st.pack(n_max, l_max)
 
 
-def unpack_waves(gathered, copy=True):
-    """packed f32 [rows, 4+l_max] (any device) -> {job_id: 1-D float32 numpy array}.  One D2H copy
-    of the whole buffer (into pinned memory for a CUDA tensor), then per-row slices."""
-    if gathered.is_cuda:
-        host = torch.empty(gathered.shape, dtype=gathered.dtype, pin_memory=True)
-        host.copy_(gathered, non_blocking=False)
-    else:
-        host = gathered
-    g = host.numpy()
+def unpack_waves(gathered, copy=False):
+    """packed f32 [rows, 4+l_max] (any device) -> {job_id: 1-D float32 numpy array}.  ONE device-to-host copy of
+    the whole buffer; the per-job arrays are views into that host copy (every call owns a fresh one), so nothing
+    is copied a second time unless ``copy`` asks for it."""
+    g = (gathered.cpu() if gathered.is_cuda else gathered).numpy()
     hdr = g.view(np.int32)[:, :2]
     out = {}
-    for r in np.nonzero(hdr[:, 0] >= 0)[0]:
+    for r in np.flatnonzero(hdr[:, 0] >= 0):
         w = g[r, HDR:HDR + hdr[r, 1]]
         out[int(hdr[r, 0])] = w.copy() if copy else w
     return out

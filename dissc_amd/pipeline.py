@@ -35,6 +35,14 @@ class Converter:
         self.norm_pitch, self.n_tokens, self.postprocess = norm_pitch, n_tokens, postprocess
         self.max_batch, self.max_frames, self.encode_seconds = max_batch, max_frames, encode_seconds
 
+    def _staging(self, b, n):
+        """pinned host staging buffer for one encode batch (page-locking is expensive: allocated once, reused; the
+        H2D copy below is synchronous with respect to the host, so reuse across batches is safe)"""
+        need = b * n
+        if getattr(self, "_pin", None) is None or self._pin.numel() < need:
+            self._pin = torch.empty(need, dtype=torch.float32, pin_memory=True)
+        return self._pin[:need].view(b, n)  # rows are filled (and their tails zeroed) by the caller
+
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def _run_local(self, waves, target_ids, store):
@@ -58,13 +66,19 @@ class Converter:
             batch = order[pos:pos + bsz]
             pos += len(batch)
             b = len(batch)
-            wav = torch.zeros(b, n0, dtype=torch.float32, pin_memory=True)
-            ns = np.zeros(b, dtype=np.int32)
-            for k, j in enumerate(batch):
-                w = np.asarray(waves[j], dtype=np.float32).reshape(-1)
-                wav[k, :len(w)] = torch.from_numpy(w)
-                ns[k] = len(w)
-            enc = self.encoder(wav.to(dev, non_blocking=True), n_samples=torch.from_numpy(ns), want_dense=False)
+            ns = np.array([len(waves[j]) for j in batch], dtype=np.int32)
+            if all(torch.is_tensor(waves[j]) and waves[j].is_cuda for j in batch):
+                # audio already resident in HBM (e.g. handed over by a device-side loader): pad on the device
+                wav_dev = torch.zeros(b, n0, dtype=torch.float32, device=dev)
+                for k, j in enumerate(batch):
+                    wav_dev[k, :int(ns[k])] = waves[j].reshape(-1)
+            else:
+                wav = self._staging(b, n0)
+                for k, j in enumerate(batch):
+                    wav[k, :int(ns[k])] = torch.as_tensor(np.asarray(waves[j], dtype=np.float32).reshape(-1))
+                    wav[k, int(ns[k]):] = 0.0
+                wav_dev = wav.to(dev)
+            enc = self.encoder(wav_dev, n_samples=torch.from_numpy(ns), want_dense=False)
             units = enc["units"]                       # i64 [b,T] on the device
             frames = enc["frames"].to(dev)             # i32 [b] (computed from n_samples on the host)
             # every utterance x every target, target fastest: row = k*nt + slot
