@@ -99,7 +99,9 @@ def make_generator():
 def _import_ref_root():
     """reference infer.py imports root utils.py -> `from tensorflow import summary`
     (reference utils.py:2); tensorflow is not installed, a stub module is enough."""
+    import importlib.machinery
     tf = types.ModuleType("tensorflow")
+    tf.__spec__ = importlib.machinery.ModuleSpec("tensorflow", None)  # torch._dynamo probes find_spec()
     tf.summary = None
     sys.modules.setdefault("tensorflow", tf)
     for m in ("utils", "models", "dataset"):
@@ -485,7 +487,113 @@ def make_prep_dataset():
     print("prep_expected.pkl", {k: (round(v["mean"], 3), round(v["std"], 3)) for k, v in stats.items()})
 
 
-TARGETS = {"prep_dataset": make_prep_dataset, "hubert": make_hubert, "sr_inference": make_sr_inference,
+def synth_train_batch(kind, B=5, L=23, seed=11, n_spk=108):
+    """a padded training batch the way the reference datasets build it (dataset/len_dataset.py:23-32,
+    dataset/pitch_dataset.py:23-42): every row padded to the longest, pad token = n_tokens, pad label -1 / -100"""
+    rs = np.random.RandomState(seed)
+    lens_ = [L] + [int(v) for v in rs.randint(3, L, size=B - 1)]
+    seq = np.full((B, L), 100, dtype=np.int64)
+    pad = -1.0 if kind == "len" else -100.0
+    tgt = np.full((B, L), pad, dtype=np.float32)
+    for b, n in enumerate(lens_):
+        seq[b, :n] = rs.randint(0, 100, size=n)
+        if kind == "len":
+            tgt[b, :n] = rs.randint(1, 9, size=n).astype(np.float32)
+        else:
+            f = rs.standard_normal(n).astype(np.float32)
+            f[rs.rand(n) < 0.35] = 0.0
+            tgt[b, :n] = f
+    spk = rs.randint(0, n_spk, size=(B, 1)).astype(np.int64)
+    keep = (rs.rand(B, L) <= (0.8 if kind == "len" else 0.6)).astype(np.float32)  # mask = uniform > keep_rate
+    return seq, tgt, spk, keep
+
+
+def compact(a):
+    """small tensors whole; large ones as [sum, sum|.|, sum(.^2)] + every (numel // 509)-th element (fixtures stay small)"""
+    a = np.asarray(a)
+    if a.size <= 4096:
+        return a.copy()
+    f = a.reshape(-1).astype(np.float64)
+    return np.concatenate([[f.sum(), np.abs(f).sum(), (f * f).sum()], f[::max(1, f.size // 509)]])
+
+
+def make_train():
+    """Two optimisation steps of the REFERENCE models in train() mode on CPU (reference train_len_predictor.py:57-68,
+    train_f0_predictor.py:58-66) with the random masks injected: torch.cuda.FloatTensor(...).uniform_() is replaced
+    by a tensor holding chosen uniforms, nn.Dropout draws from the seeded CPU generator."""
+    ref_infer, LenPredictor, PitchPredictor, PitchPredictorBase = _import_ref_root()
+    sys.path.insert(0, REF)
+    from loss.len_loss import LenSumLoss
+    from loss.pitch_loss import PitchLoss
+    out = {}
+    n_spk = 108
+    rs = np.random.RandomState(7)
+    id2mean = torch.from_numpy((150 + 60 * rs.rand(n_spk)).astype(np.float32))
+    id2std = torch.from_numpy((20 + 20 * rs.rand(n_spk)).astype(np.float32))
+    out["id2pitch_mean"], out["id2pitch_std"] = id2mean.numpy(), id2std.numpy()
+
+    class _FakeCudaFloat:
+        """what `torch.cuda.FloatTensor(B, L).uniform_()` returns: uniforms u with (u > keep_rate) == masked"""
+        queue = []
+
+        def __init__(self, *shape):
+            self.shape = shape
+
+        def uniform_(self):
+            keep, keep_rate = _FakeCudaFloat.queue.pop(0)
+            assert tuple(keep.shape) == tuple(self.shape)
+            return torch.where(keep > 0, torch.full_like(keep, keep_rate * 0.5), torch.full_like(keep, 0.5 + keep_rate * 0.5))
+
+    real = torch.cuda.FloatTensor
+    torch.cuda.FloatTensor = _FakeCudaFloat
+    try:
+        for kind in ("len", "new", "base"):
+            if kind == "len":
+                model = LenPredictor(n_tokens=100, n_speakers=n_spk, norm_mean=torch.tensor(3.3), norm_std=torch.tensor(2.1))
+                model.load_state_dict(synth.synth_len_state_dict(100, n_spk), strict=True)
+                crit = LenSumLoss(pad_idx=-1)
+                lr = 3e-4
+            else:
+                cls = PitchPredictorBase if kind == "base" else PitchPredictor
+                model = cls(100, n_spk, id2pitch_mean=id2mean, id2pitch_std=id2std)
+                model.load_state_dict(synth.synth_pitch_state_dict(kind, 100, n_spk), strict=True)
+                crit = PitchLoss(id2mean, id2std, pad_idx=-100)
+                lr = 1e-3
+            model.train()
+            opt = torch.optim.Adam(model.parameters(), lr=lr)
+            out[f"{kind}/lr"] = np.array(lr)
+            for step in range(2):
+                seq, tgt, spk, keep = synth_train_batch("len" if kind == "len" else "pitch", seed=11 + step)
+                for nm, arr in (("seq", seq), ("tgt", tgt), ("spk", spk), ("keep", keep)):
+                    out[f"{kind}/s{step}/{nm}"] = arr
+                _FakeCudaFloat.queue.append((torch.from_numpy(keep), model.keep_rate))
+                if kind == "new":  # PositionalEncoding dropout(p = 0.4): first consumer of the CPU generator
+                    torch.manual_seed(100 + step)
+                    mult = torch.nn.functional.dropout(torch.ones(seq.shape[0], seq.shape[1], 32), 0.4, True)
+                    out[f"{kind}/s{step}/pe_mult"] = mult.numpy()
+                    torch.manual_seed(100 + step)
+                opt.zero_grad()
+                if kind == "len":
+                    preds = model(torch.from_numpy(seq).int(), torch.from_numpy(spk).int())
+                    loss = crit(preds, torch.from_numpy(tgt))
+                else:
+                    c, r = model(torch.from_numpy(seq).int(), torch.from_numpy(spk).int())
+                    loss = crit(c, r, torch.from_numpy(tgt), torch.from_numpy(spk).int())
+                loss.backward()
+                out[f"{kind}/s{step}/loss"] = np.array(loss.item())
+                for k, prm in model.named_parameters():
+                    out[f"{kind}/s{step}/grad/{k}"] = compact((prm.grad if prm.grad is not None else torch.zeros_like(prm)).numpy())
+                opt.step()
+                for k, v in model.state_dict().items():
+                    out[f"{kind}/s{step}/after/{k}"] = compact(v.numpy())
+            assert not _FakeCudaFloat.queue
+    finally:
+        torch.cuda.FloatTensor = real
+    np.savez_compressed(os.path.join(OUT, "train.npz"), **out)
+    print("train.npz", len(out), "arrays")
+
+
+TARGETS = {"train": make_train, "prep_dataset": make_prep_dataset, "hubert": make_hubert, "sr_inference": make_sr_inference,
            "generator": make_generator, "predictors": make_predictors}
 
 if __name__ == "__main__":
