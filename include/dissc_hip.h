@@ -319,6 +319,37 @@ int dissc_yaapt_nccf(dissc_yaapt_t y, const float* sig, const int32_t* n_samples
 int dissc_resample(const double* x, int n_orig, double* y, int n_out, double ratio, const double* win,
                    const double* delta, int nwin, int num_table, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Predictor training.
+ * Replaces one iteration of the training loops: model.train() forward, LenSumLoss / PitchLoss, loss.backward(),
+ *   torch.optim.Adam.step() -- reference train_len_predictor.py:57-68, train_f0_predictor.py:58-66,
+ *   loss/len_loss.py:16-30, loss/pitch_loss.py:6-27, model/len_predictor.py:35-52, model/pitch_predictor.py:72-94,145-166.
+ * kind: 0 LenPredictor, 1 PitchPredictor ("new"), 2 PitchPredictorBase.  tensors: the model's state_dict by name
+ *   (HOST fp32, incl. the BatchNorm running statistics and "pe.pe"; num_batches_tracked is kept by the caller).
+ * The random masks of train() mode are inputs: keep f32 [B,L] (1 = token embedding kept; NULL = all kept),
+ *   pe_mult f32 [B,L,32] (PositionalEncoding dropout multipliers 0 or 1/(1-p); kind 1 only; NULL = none).
+ * One step: seq i64 [B,L] (pad token = n_tokens), spk i64 [B], target f32 [B,L] (pad_value marks padding) -- device
+ *   pointers; loss_out: device f32[1]; parameters, Adam moments and running statistics live in the handle.
+ * ------------------------------------------------------------------------- */
+typedef struct dissc_trainer* dissc_trainer_t;
+int dissc_train_create(int kind, const DisscTensor* tensors, size_t n, dissc_trainer_t* out);
+void dissc_train_destroy(dissc_trainer_t t);
+int dissc_train_set_len_norm(dissc_trainer_t t, float mean, float std);          /* LenPredictor.norm_mean / norm_std */
+int dissc_train_set_pitch_stats(dissc_trainer_t t, const float* id2mean, const float* id2std, int n);  /* host arrays */
+size_t dissc_train_workspace_bytes(dissc_trainer_t t, int B, int L);
+int dissc_train_step(dissc_trainer_t t, const int64_t* seq, const int64_t* spk, const float* target, const float* keep,
+                     const float* pe_mult, int B, int L, float pad_value, float lr, float* loss_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* state access: tensors in a fixed order (trainable ones first); which = 0 value, 1 gradient of the last step */
+int dissc_train_num_tensors(dissc_trainer_t t);
+const char* dissc_train_tensor_name(dissc_trainer_t t, int i);
+long long dissc_train_tensor_numel(dissc_trainer_t t, int i);
+long long dissc_train_steps(dissc_trainer_t t);
+int dissc_train_read(dissc_trainer_t t, int i, int which, float* host_out, void* stream);
+/* diagnostics: an activation buffer of the last step ([B][C][ld], ld = L rounded up to 4): which 0 conv output,
+ * 1 activation, 2 gradient w.r.t. the activation, 3 gradient w.r.t. the conv output; layer -1 = the embedding */
+int dissc_train_debug_read(dissc_trainer_t t, int layer, int which, float* host_out, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
