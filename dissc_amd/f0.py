@@ -45,8 +45,20 @@ class _Cfg(ctypes.Structure):
                 ("nccf_thresh2", ctypes.c_float), ("nccf_pwidth", ctypes.c_int32)]
 
 
+class _TrackCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in ("nlfer_thresh1", "nlfer_thresh2", "dp5_k1", "merit_boost", "merit_pivot",
+                                                "merit_extra", "dp_w1", "dp_w2", "dp_w3", "dp_w4", "spec_pitch_min_std",
+                                                "f0_min", "f0_max")] + \
+               [(n, ctypes.c_int32) for n in ("median_value", "nccf_pwidth", "fs", "reserved")]
+
+
 def _bind():
     vp, i32 = ctypes.c_void_p, ctypes.c_int
+    lib.dissc_yaapt_track_workspace_bytes.argtypes = [i32, i32]
+    lib.dissc_yaapt_track_workspace_bytes.restype = ctypes.c_size_t
+    lib.dissc_yaapt_spec_track.argtypes = [ctypes.POINTER(_TrackCfg)] + [vp] * 5 + [i32, i32] + [vp] * 7 + \
+                                          [ctypes.c_size_t, vp]
+    lib.dissc_yaapt_final_track.argtypes = [ctypes.POINTER(_TrackCfg)] + [vp] * 9 + [i32, i32, vp, vp, ctypes.c_size_t, vp]
     lib.dissc_yaapt_create.argtypes = [vp, i32, ctypes.POINTER(_Cfg), ctypes.POINTER(vp)]
     lib.dissc_yaapt_destroy.argtypes = [vp]
     lib.dissc_yaapt_destroy.restype = None
@@ -210,6 +222,10 @@ class YaaptTracker:
                   "dissc_yaapt_create")
         self._h = h
         self._ws = None
+        self._tws = None
+        self._tcfg = _TrackCfg(p["nlfer_thresh1"], p["nlfer_thresh2"], p["dp5_k1"], p["merit_boost"], p["merit_pivot"],
+                               p["merit_extra"], p["dp_w1"], p["dp_w2"], p["dp_w3"], p["dp_w4"], p["spec_pitch_min_std"],
+                               p["f0_min"], p["f0_max"], int(p["median_value"]), int(p["nccf_pwidth"]), self.fs, 0)
 
     def __del__(self):
         try:
@@ -268,11 +284,57 @@ class YaaptTracker:
                                        _lib.current_stream_ptr(dev)), "dissc_yaapt_nccf")
         return (pitch, merit, phi) if want_phi else (pitch, merit)
 
+    def spec_track(self, s, n_frames, n_tda):
+        """device spec_track: the outputs of `spectral` + frame counts (int32 [B]) -> dict of device tensors
+        (en_norm f64 [B,F], vuv u8 [B,F], spec f64 [B,F], spec_std f64 [B], lag_min / lag_max i32 [B,F])"""
+        dev = self.device
+        B, F = s["energy"].shape
+        nf = torch.as_tensor(n_frames).to(dev, torch.int32).contiguous()
+        nt = torch.as_tensor(n_tda).to(dev, torch.int32).contiguous()
+        out = {"en_norm": torch.empty(B, F, dtype=torch.float64, device=dev),
+               "vuv": torch.empty(B, F, dtype=torch.uint8, device=dev),
+               "spec": torch.empty(B, F, dtype=torch.float64, device=dev),
+               "spec_std": torch.empty(B, dtype=torch.float64, device=dev),
+               "lag_min": torch.empty(B, F, dtype=torch.int32, device=dev),
+               "lag_max": torch.empty(B, F, dtype=torch.int32, device=dev), "n_frames": nf, "n_tda": nt}
+        with torch.cuda.device(dev):
+            ws, need = self._track_workspace(B, F)
+            check(lib.dissc_yaapt_spec_track(ctypes.byref(self._tcfg), s["energy"].data_ptr(), s["cand_pitch"].data_ptr(),
+                                             s["cand_merit"].data_ptr(), nf.data_ptr(), nt.data_ptr(), B, F,
+                                             out["en_norm"].data_ptr(), out["vuv"].data_ptr(), out["spec"].data_ptr(),
+                                             out["spec_std"].data_ptr(), out["lag_min"].data_ptr(),
+                                             out["lag_max"].data_ptr(), ws.data_ptr(), need,
+                                             _lib.current_stream_ptr(dev)), "dissc_yaapt_spec_track")
+        return out
+
+    def final_track_device(self, st, c1, c2):
+        """device merge + final dynamic programming: st = spec_track's dict, c1 / c2 = (pitch, merit) of the two NCCF
+        passes -> f0 f32 [B,F] (device)"""
+        dev = self.device
+        B, F = st["spec"].shape
+        f0 = torch.empty(B, F, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws, need = self._track_workspace(B, F)
+            check(lib.dissc_yaapt_final_track(ctypes.byref(self._tcfg), c1[0].data_ptr(), c1[1].data_ptr(),
+                                              c2[0].data_ptr(), c2[1].data_ptr(), st["en_norm"].data_ptr(),
+                                              st["vuv"].data_ptr(), st["spec"].data_ptr(), st["spec_std"].data_ptr(),
+                                              st["n_tda"].data_ptr(), B, F, f0.data_ptr(), ws.data_ptr(), need,
+                                              _lib.current_stream_ptr(dev)), "dissc_yaapt_final_track")
+        return f0
+
+    def _track_workspace(self, B, F):
+        need = lib.dissc_yaapt_track_workspace_bytes(B, F)
+        if self._tws is None or self._tws.numel() < need:
+            self._tws = None
+            self._tws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._tws, need
+
     # -- the tracker -------------------------------------------------------------------------------------
-    def __call__(self, waveforms):
+    def __call__(self, waveforms, host_dp=False):
         """list of 1-D float waveforms @fs -> list of float32 F0 tracks (one value per frame_space, 0 = unvoiced),
-        each of len(arange(frame/2, n + frame - frame/2, hop)) values like pYAAPT's samp_values on the padded signal."""
-        p = self.p
+        each of len(arange(frame/2, n + frame - frame/2, hop)) values like pYAAPT's samp_values on the padded signal.
+        Everything runs on the device (one D2H copy of the tracks at the end); host_dp=True runs the sequential
+        stages with the numpy functions above instead (kept as the readable form and for the tests)."""
         pad = self.flen // 2  # reference sr/dataset.py:29,33: 10 ms of zeros at both ends
         B = len(waveforms)
         if B == 0:
@@ -283,12 +345,22 @@ class YaaptTracker:
         for i, w in enumerate(waveforms):
             wav[i, pad:pad + len(w)] = torch.as_tensor(np.asarray(w, dtype=np.float32))
         s = self.spectral(wav, torch.tensor(lens, dtype=torch.int32))
+        nfr = [lib.dissc_yaapt_frames(self._h, n) for n in lens]
+        ntd = [min(lib.dissc_yaapt_tda_frames(self._h, n), f) for n, f in zip(lens, nfr)]
+        if host_dp:
+            return self._host_stages(s, nfr, ntd)
+        st = self.spec_track(s, nfr, ntd)
+        c1 = self.nccf(s["filt"], s["n_samples"], st["lag_min"], st["lag_max"])
+        c2 = self.nccf(s["nlfilt"], s["n_samples"], st["lag_min"], st["lag_max"])
+        f0 = self.final_track_device(st, c1, c2).cpu().numpy()
+        return [f0[b, :nfr[b]].copy() for b in range(B)]
+
+    def _host_stages(self, s, nfr, ntd):
+        p = self.p
+        B, F = len(nfr), s["F"]
         energy = s["energy"].cpu().numpy().astype(np.float64)
         cp = s["cand_pitch"].cpu().numpy()
         cm = s["cand_merit"].cpu().numpy()
-        F = s["F"]
-        nfr = [lib.dissc_yaapt_frames(self._h, n) for n in lens]
-        ntd = [min(lib.dissc_yaapt_tda_frames(self._h, n), f) for n, f in zip(lens, nfr)]
         specs, stds, ens, vuvs = [], [], [], []
         lmin = np.ones((B, F), dtype=np.int32)
         lmax = np.full((B, F), 2, dtype=np.int32)

@@ -308,6 +308,36 @@ int dissc_yaapt_nccf(dissc_yaapt_t y, const float* sig, const int32_t* n_samples
                      const int32_t* lag_max, int B, int Nmax, int F, float* pitch, float* merit, float* phi_out,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* The sequential stages of the tracker, one workgroup per utterance, fp64 (pYAAPT's spec_track, refine and both
+ * dynamic-programming passes as restated in oracle/yaapt_ref.py [3P-unverified]).  All pointers are device pointers.
+ *   dissc_yaapt_spec_track: energy f32 [B,F], cand_pitch / cand_merit f32 [B,F,4] (dissc_yaapt_spectral's outputs),
+ *     n_frames / n_tda i32 [B] (dissc_yaapt_frames / _tda_frames of each utterance) ->
+ *     en_norm f64 [B,F] (NLFER / its mean), vuv u8 [B,F], spec f64 [B,F] (smoothed spectral F0 track),
+ *     spec_std f64 [B], lag_min / lag_max i32 [B,F] (the NCCF search range of every time-domain frame)
+ *   dissc_yaapt_final_track: the NCCF candidates of the band-passed signal (tp1, tm1) and of its square (tp2, tm2),
+ *     f32 [B,F,3] each, plus the outputs above -> f0 f32 [B,F] (0 = unvoiced, 0 beyond n_tda[b]) */
+typedef struct {
+  double nlfer_thresh1, nlfer_thresh2; /* 0.75, 0.1 */
+  double dp5_k1;                       /* 11 */
+  double merit_boost, merit_pivot, merit_extra; /* 0.20, 0.99, 0.4 */
+  double dp_w1, dp_w2, dp_w3, dp_w4;   /* 0.15, 0.5, 0.1, 0.9 */
+  double spec_pitch_min_std;           /* 0.05 */
+  double f0_min, f0_max;               /* 60, 400 */
+  int32_t median_value;                /* 7 (odd, 3..9) */
+  int32_t nccf_pwidth;                 /* 5 */
+  int32_t fs;                          /* 16000 */
+  int32_t reserved;
+} DisscYaaptTrackConfig;
+size_t dissc_yaapt_track_workspace_bytes(int B, int F);
+int dissc_yaapt_spec_track(const DisscYaaptTrackConfig* cfg, const float* energy, const float* cand_pitch,
+                           const float* cand_merit, const int32_t* n_frames, const int32_t* n_tda, int B, int F,
+                           double* en_norm, uint8_t* vuv, double* spec, double* spec_std, int32_t* lag_min,
+                           int32_t* lag_max, void* workspace, size_t workspace_bytes, void* stream);
+int dissc_yaapt_final_track(const DisscYaaptTrackConfig* cfg, const float* tp1, const float* tm1, const float* tp2,
+                            const float* tm2, const double* en_norm, const uint8_t* vuv, const double* spec,
+                            const double* spec_std, const int32_t* n_tda, int B, int F, float* f0, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Band-limited sinc resampling.
  * Replaces: resampy.resample(data, sr, 16000) at reference data/preprocess.py:22 (and sr/dataset.py:226) --
