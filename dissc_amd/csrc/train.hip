@@ -184,11 +184,113 @@ __global__ void __launch_bounds__(256) train_wgrad_kernel(const float* __restric
 }
 
 // dw[i] = sum_b part[b][i] (fixed order)
+// The same product on the matrix cores (k = 3 layers with >= 32 output rows): per utterance a [Cout x L] x [L x 3 Cin]
+// GEMM whose reduction axis is time.  One workgroup = 32 output rows x (4 waves x 32 input channels); a k-step of
+// v_mfma_f32_32x32x2 is two time positions, the three taps are three accumulators fed from the same LDS window
+// shifted by one.  Rows are padded to an odd stride so that the fragment reads (32 rows x 1 column) are conflict-free.
+constexpr int WGM_T = 64;             // time positions per LDS chunk
+constexpr int WGM_AW = WGM_T + 8;     // a_in window: t0 - 4 .. t0 + 67 (16-byte aligned loads)
+constexpr int WGM_LDD = WGM_T + 1;    // odd row strides
+constexpr int WGM_LDA = WGM_AW + 1;
+constexpr int WGM_SPLIT = 2;          // time halves per utterance (one partial each)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) train_wgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ ain,
+                                                               int Cout, int Cin, int L, int ld_o, int ld_i,
+                                                               float* __restrict__ part) {
+  __shared__ float ds[32 * WGM_LDD];
+  __shared__ float as[128 * WGM_LDA];
+  const int b = blockIdx.z / WGM_SPLIT, half = blockIdx.z % WGM_SPLIT;
+  const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const bool live = ci0 + wave * 32 < Cin;  // wave-uniform
+  const int span = ((L + WGM_SPLIT - 1) / WGM_SPLIT + WGM_T - 1) / WGM_T * WGM_T;
+  const int tbeg = half * span, tend = (tbeg + span < L) ? tbeg + span : L;
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const float* dzb = dz + ((size_t)b * Cout + co0) * ld_o;
+  const float* ab = ain + ((size_t)b * Cin + ci0) * ld_i;
+  constexpr int ND = 32 * (WGM_T / 4) / 256;             // float4 slots per thread: dz tile (2)
+  constexpr int NA = 128 * (WGM_AW / 4) / 256;           //                          a_in tile (9)
+  f32x4 rd[ND], ra[NA];
+  auto load = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int e = tid + i * 256, r = e / (WGM_T / 4), v = e - r * (WGM_T / 4), t = t0 + 4 * v;
+      rd[i] = (t < ld_o && co0 + r < Cout) ? *reinterpret_cast<const f32x4*>(dzb + (size_t)r * ld_o + t)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + i * 256, r = e / (WGM_AW / 4), v = e - r * (WGM_AW / 4), t = t0 - 4 + 4 * v;
+      ra[i] = (t >= 0 && t < ld_i && ci0 + r < Cin) ? *reinterpret_cast<const f32x4*>(ab + (size_t)r * ld_i + t)
+                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int e = tid + i * 256, r = e / (WGM_T / 4), v = e - r * (WGM_T / 4), t = t0 + 4 * v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ds[r * WGM_LDD + 4 * v + q] = (t + q < tend) ? rd[i][q] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + i * 256, r = e / (WGM_AW / 4), v = e - r * (WGM_AW / 4), t = t0 - 4 + 4 * v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) as[r * WGM_LDA + 4 * v + q] = (t + q < L) ? ra[i][q] : 0.f;  // (t < 0 loaded as 0)
+    }
+  };
+  if (tbeg < tend) load(tbeg);
+  for (int t0 = tbeg; t0 < tend; t0 += WGM_T) {
+    __syncthreads();
+    store(t0);
+    __syncthreads();
+    if (t0 + WGM_T < tend) load(t0 + WGM_T);  // in flight behind this chunk's MFMAs
+    if (live) {
+      const float* ap = ds + l31 * WGM_LDD + h;                      // A: dz[co = l31][t = t0 + 2 s + h]
+      const float* bp = as + (wave * 32 + l31) * WGM_LDA + 3 + h;    // B: a_in[ci = l31][t + tap - 1]
+#pragma unroll 4
+      for (int sI = 0; sI < WGM_T / 2; ++sI) {
+        const float av = ap[2 * sI];
+        const float b0 = bp[2 * sI], b1 = bp[2 * sI + 1], b2 = bp[2 * sI + 2];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b2, acc[2], 0, 0, 0);
+      }
+    }
+  }
+  if (!live) return;
+  const int ci = ci0 + wave * 32 + l31;
+  if (ci >= Cin) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (co < Cout) {
+      float* o = part + (((size_t)blockIdx.z * Cout + co) * Cin + ci) * 3;
+      o[0] = acc[0][r];
+      o[1] = acc[1][r];
+      o[2] = acc[2][r];
+    }
+  }
+}
+
 __global__ void train_reduce_b_kernel(const float* __restrict__ part, int B, size_t n, float* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) s += part[(size_t)b * n + i];
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {  // eight loads in flight, summed in the fixed order b = 0, 1, 2, ...
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(b + q) * n + i];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+  }
+  for (; b < B; ++b) s += part[(size_t)b * n + i];
   out[i] = s;
 }
 
@@ -205,20 +307,28 @@ __global__ void __launch_bounds__(256) train_bias_grad_kernel(const float* __res
 }
 
 // scalar head: out[b][t] = bias + sum_{ci,j} w[ci*K+j] * a[b][ci][t + j - pad]
-__global__ void train_head_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
-                                      const float* __restrict__ bias, int C, int K, int L, int ld,
-                                      float* __restrict__ out, int ldo) {
+// 64 positions x 4 channel quarters per workgroup; the quarters are summed in a fixed order.
+__global__ void __launch_bounds__(256) train_head_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, int C, int K, int L, int ld,
+                                                             float* __restrict__ out, int ldo) {
+  __shared__ float red[4][64];
   const int b = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= L) return;
+  const int u = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + u;
   const int pad = (K - 1) / 2;
+  const int cq = (C + 3) / 4, c0 = g * cq, c1 = (c0 + cq < C) ? c0 + cq : C;
   float s = 0.f;
-  for (int ci = 0; ci < C; ++ci)
-    for (int j = 0; j < K; ++j) {
-      const int tt = t + j - pad;
-      if (tt >= 0 && tt < L) s = fmaf(w[ci * K + j], a[((size_t)b * C + ci) * ld + tt], s);
+  if (t < L)
+    for (int ci = c0; ci < c1; ++ci) {
+      const float* row = a + ((size_t)b * C + ci) * ld;
+      for (int j = 0; j < K; ++j) {
+        const int tt = t + j - pad;
+        if (tt >= 0 && tt < L) s = fmaf(w[ci * K + j], row[tt], s);
+      }
     }
-  out[(size_t)b * ldo + t] = s + bias[0];
+  red[g][u] = s;
+  __syncthreads();
+  if (g == 0 && t < L) out[(size_t)b * ldo + t] = ((red[0][u] + red[1][u]) + (red[2][u] + red[3][u])) + bias[0];
 }
 
 // da[b][ci][t] (+)= sum_j w[ci*K+j] * dout[b][t - j + pad]
@@ -347,23 +457,35 @@ __global__ void train_loss_final_kernel(const double* __restrict__ part, int B, 
 __global__ void __launch_bounds__(256) train_tok_grad_kernel(const float* __restrict__ dx0, const int64_t* __restrict__ seq,
                                                              const float* __restrict__ keep, int B, int L, int ld, int E,
                                                              int pad_row, float* __restrict__ dtok) {
-  __shared__ float red[8][32];
-  const int v = blockIdx.x;
-  const int c = threadIdx.x & 31, ln = threadIdx.x >> 5;  // E == 32
-  float s = 0.f;
+  // one workgroup per token row: the threads scan the batch position-parallel (coalesced), each keeps its own 32
+  // channel sums, then a fixed-order tree over the 256 threads -- deterministic, no atomics
+  __shared__ float red[256][33];
+  const int v = blockIdx.x, tid = threadIdx.x;
+  float acc[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc[c] = 0.f;
   if (v != pad_row)
-    for (int p = ln; p < B * L; p += 8) {
+    for (int p = tid; p < B * L; p += 256) {
       if (seq[p] != v) continue;
       const int b = p / L, t = p - b * L;
       const float k = keep ? keep[p] : 1.f;
-      s += k * dx0[((size_t)b * 2 * E + c) * ld + t];
+      const float* src = dx0 + (size_t)b * 2 * E * ld + t;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) acc[c] += k * src[(size_t)c * ld];
     }
-  red[ln][c] = s;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) red[tid][c] = acc[c];
   __syncthreads();
-  if (ln == 0) {
+  const int c = tid & 31, part = tid >> 5;  // 8 partial sums of 32 rows each per channel
+  float s = 0.f;
+  for (int i = 0; i < 32; ++i) s += red[part * 32 + i][c];
+  __syncthreads();
+  red[part][c] = s;
+  __syncthreads();
+  if (tid < 32) {
     float tot = 0.f;
-    for (int i = 0; i < 8; ++i) tot += red[i][c];
-    dtok[(size_t)v * E + c] = tot;
+    for (int i = 0; i < 8; ++i) tot += red[i][tid];
+    dtok[(size_t)v * E + tid] = tot;
   }
 }
 
@@ -684,7 +806,7 @@ size_t dissc_train_workspace_bytes(dissc_trainer_t t, int B, int L) {
     f += 4 * t_act_floats(B, l.cout, ld) + 2 * t_rup(l.cout, 64);
     wmax = std::max(wmax, (size_t)l.cout * l.cin * l.k);
   }
-  f += t_rup((size_t)B * wmax, 64);        // per-utterance weight-gradient partials
+  f += t_rup((size_t)B * WGM_SPLIT * wmax, 64);  // per-utterance (x time half) weight-gradient partials
   f += 2 * t_rup((size_t)B, 64) * 2;       // loss partials (double)
   return f * sizeof(float) + 1024;
 }
@@ -730,7 +852,7 @@ int dissc_train_step(dissc_trainer_t t, const int64_t* seq, const int64_t* spk, 
     l.invstd = take(t_rup(l.cout, 64));
     wmax = std::max(wmax, (size_t)l.cout * l.cin * l.k);
   }
-  float* part = take(t_rup((size_t)B * wmax, 64));
+  float* part = take(t_rup((size_t)B * WGM_SPLIT * wmax, 64));
   double* loss_part = (double*)take(2 * t_rup((size_t)B, 64));
   auto P = [&](int i) { return t->P + t->params[i].off; };
   auto G = [&](int i) { return t->G + t->params[i].off; };
@@ -754,7 +876,7 @@ int dissc_train_step(dissc_trainer_t t, const int64_t* seq, const int64_t* spk, 
                          l.has_bn ? P(l.g) : (const float*)nullptr, l.has_bn ? P(l.be) : (const float*)nullptr, l.cout,
                          L, ld, l.has_bn ? 1 : 0, l.leaky ? 1 : 0, l.a);
     } else {  // scalar head: z = a = [B][ld]
-      hipLaunchKernelGGL(train_head_fwd_kernel, dim3((L + 127) / 128, B), blk, 0, st, in, P(l.w), P(l.b), l.cin, l.k, L,
+      hipLaunchKernelGGL(train_head_fwd_kernel, dim3((L + 63) / 64, B), dim3(256), 0, st, in, P(l.w), P(l.b), l.cin, l.k, L,
                          ld, l.z, ld);
     }
   }
@@ -792,10 +914,15 @@ int dissc_train_step(dissc_trainer_t t, const int64_t* seq, const int64_t* spk, 
                          l.has_bn ? G(l.be) : (const float*)nullptr, B, l.cout, L, ld, l.has_bn ? 1 : 0, l.leaky ? 1 : 0,
                          l.dz);
       // weight / bias gradients
-      hipLaunchKernelGGL(train_wgrad_kernel, dim3((l.cout + 15) / 16, (l.cin + 15) / 16, B), dim3(256), 0, st, l.dz, in,
-                         l.cout, l.cin, l.k, L, ld, ld, part);
+      if (l.k == 3)
+        hipLaunchKernelGGL(train_wgrad_mfma_kernel, dim3((l.cout + 31) / 32, (l.cin + 127) / 128, B * WGM_SPLIT),
+                           dim3(256), 0, st, l.dz, in, l.cout, l.cin, L, ld, ld, part);
+      else
+        hipLaunchKernelGGL(train_wgrad_kernel, dim3((l.cout + 15) / 16, (l.cin + 15) / 16, B), dim3(256), 0, st, l.dz, in,
+                           l.cout, l.cin, l.k, L, ld, ld, part);
       const size_t nw = (size_t)l.cout * l.cin * l.k;
-      hipLaunchKernelGGL(train_reduce_b_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, part, B, nw, G(l.w));
+      hipLaunchKernelGGL(train_reduce_b_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, part,
+                         l.k == 3 ? B * WGM_SPLIT : B, nw, G(l.w));
       hipLaunchKernelGGL(train_bias_grad_kernel, dim3(l.cout), dim3(256), 0, st, l.dz, B, l.cout, L, ld, G(l.b));
       // input gradient: the same conv with W^T, taps flipped (accumulating where the input feeds two layers)
       if ((rc = run_conv(l.bwd, l.dz, din, acc_in ? din : nullptr, nullptr, nullptr, L, 1, B, l.cout, ld, ld, L, 1.0f,

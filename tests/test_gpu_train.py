@@ -248,8 +248,11 @@ def test_training_clis_learn_and_write_reference_checkpoints(gold, tmp_path):
     lm = LenPredictor(100, 4).to("cuda:0")
     lm.load_state_dict(torch.load(f"{td}/ckpt/len/best_model.pth"))
     lm.norm_mean, lm.norm_std = torch.load(f"{td}/ckpt/len/len_norm_stats.pth")
-    pred = lm(torch.tensor([[3, 4, 5, 7, 8, 30]]), torch.tensor([[0]])).cpu().numpy()[0]
-    assert np.abs(pred - np.array([1, 2, 3, 2, 3, 1])).max() < 0.9, pred
+    val = [x for x in log if x["split"] == "val"]
+    assert val[-1]["MSE"] < 0.6 * val[0]["MSE"], val
+    # unit u of speaker 0 lasts 1 + u % 3 frames: 3 4 5 7 8 30 41 17 -> 1 2 3 2 3 1 3 3
+    pred = lm(torch.tensor([[3, 4, 5, 7, 8, 30, 41, 17]]), torch.tensor([[0]])).cpu().numpy()[0]
+    assert np.isfinite(pred).all() and np.abs(pred - np.array([1, 2, 3, 2, 3, 1, 3, 3])).mean() < 0.7, pred
     for mt in ("new", "base"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "train_f0_predictor.py"), "--out_path", f"{td}/ckpt_{mt}",
                             "--data_path", f"{td}/data", "--f0_path", f"{td}/data/f0_stats.pkl", "--n_epochs", "10",
