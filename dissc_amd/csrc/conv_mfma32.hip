@@ -16,7 +16,10 @@ namespace dissc {
 // STRIDE: input step per output position (1; 2 for HuBERT's strided feature convs).
 // SPAN: largest (KS-1)*dil the staging registers are sized for.
 // CPB: 16-channel chunks staged per barrier (4 for 1x1 convs, whose chunk is a single tap).
-template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1>
+// DMA (1x1 convs whose input needs no activation): the window goes global -> LDS directly (global_load_lds_dwordx4,
+// one wave instruction = 1 KB = four 64-column rows), no staging registers, no VALU.  Nothing is masked: a 1x1 conv's
+// output column depends on its own input column only, and columns >= olen are never stored.
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1, bool DMA = false>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const ConvArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BN = 32 * NI * WN;
@@ -57,8 +60,23 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
   // Staging: every slot issues an unconditional, in-bounds 16-byte load (addresses are
   // clamped, never predicated, so nothing waits at the load site); zero padding, the
   // ragged tail and leaky-ReLU are applied when the registers are written to LDS.
-  f32x4 sv[SV];
+  f32x4 sv[DMA ? 1 : SV];
+  static_assert(!DMA || (SPAN == 0 && STRIDE == 1 && BN == 64 && (KCB * 16) % NT == 0), "DMA staging: 1x1, 64 columns");
+  auto stage_dma = [&](float* buf, int c) {
+    // slot e = tid + i*NT -> row e / 16, float4 e % 16; a wave's 64 slots are contiguous in LDS (row stride 64)
+#pragma unroll
+    for (int i = 0; i < (KCB * 16) / NT; ++i) {
+      const int e = tid + i * NT;
+      const int ci = c * KCB + (e >> 4);
+      int t = t0 + 4 * (e & 15);
+      t = t > a.ldx - 4 ? a.ldx - 4 : t;
+      __builtin_amdgcn_global_load_lds(
+          (const void __attribute__((address_space(1)))*)(xb + (size_t)ci * a.ldx + t),
+          (void __attribute__((address_space(3)))*)(buf + (i * NT + (tid & ~63)) * 4), 16, 0, 0);
+    }
+  };
   auto stage_load = [&](int c) {
+    if constexpr (DMA) return;
     int r = r0, v = v0;
 #pragma unroll
     for (int i = 0; i < SV; ++i) {
@@ -73,6 +91,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
     }
   };
   auto stage_store = [&](float* buf, int c) {
+    if constexpr (DMA) return;
     int r = r0, v = v0;
 #pragma unroll
     for (int i = 0; i < SV; ++i) {
@@ -120,8 +139,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
     av[mi][1] = wp[mi][64];
   }
 
-  stage_load(0);
-  stage_store(xs, 0);
+  if constexpr (DMA) {
+    stage_dma(xs, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  } else {
+    stage_load(0);
+    stage_store(xs, 0);
+  }
   __syncthreads();
 
 #define DISSC_MFMA_STEP(KS_, BV)                                                             \
@@ -155,7 +179,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
             avn[mi][0] = wp[mi][(size_t)qn * 128];
             avn[mi][1] = wp[mi][(size_t)qn * 128 + 64];
           }
-          if (j == 0 && sc == 0 && more) stage_load(cb + 1);  // in flight behind this block's MFMAs
+          if (j == 0 && sc == 0 && more) {  // in flight behind this block's MFMAs
+            if constexpr (DMA) stage_dma(xs + ((cb + 1) & 1) * (KCB * XW), cb + 1);
+            else stage_load(cb + 1);
+          }
           __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of the MFMAs
 #pragma unroll
           for (int s = 0; s < 7; ++s)
@@ -188,7 +215,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma32_kernel(const Conv
         }
     }
       }
-    if (more) stage_store(xs + ((cb + 1) & 1) * (KCB * XW), cb + 1);
+    if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next block's window has landed
+    else if (more) stage_store(xs + ((cb + 1) & 1) * (KCB * XW), cb + 1);
     __syncthreads();
   }
 #undef DISSC_MFMA_STEP
@@ -217,6 +245,7 @@ static const TileCfg32 kCfgs32[] = {
 };
 int g_lin_tile = 2;  // "lin_tile" option: channels per barrier / 16 of the 1x1 (linear) convs (2 or 4)
 int g_cpb2 = 0;  // "cpb2" option: kernels with KS <= this stage 32 channels per barrier
+int g_lin_dma = 1;  // "lin_dma" option: 1x1 convs stage their window with global_load_lds (1: 64, 2: 32 channels per barrier)
 int g_mfast = 0;  // measured neutral on HuBERT linears (weights are L2/MALL resident either way)
 static int g_cfg32_for_bm[4] = {3, 2, 1, 0};  // BM class 32, 64, 128, 256 -> cfg id
 
@@ -293,9 +322,10 @@ void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<
               }
 }
 
-template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1>
+template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1, bool DMA = false>
 static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN, NW = WM * WN;
+  if (DMA) a.XW = BN;  // unpadded rows: a wave's 1 KB lands as four whole rows
   constexpr int CW = 32 * NI + 4;
   a.mt_per_group = (a.M + BM - 1) / BM;
   dim3 grid((Lmax_out + BN - 1) / BN, a.mt_per_group * a.groups, B);
@@ -309,11 +339,11 @@ static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>),
+        reinterpret_cast<const void*>(&conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB, DMA>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>), grid, dim3(64 * WM * WN), lds,
+  hipLaunchKernelGGL((conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB, DMA>), grid, dim3(64 * WM * WN), lds,
                      stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
@@ -338,6 +368,11 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
   }
   if (span == 0 && bm32_of(a.M) == 256 && a.nchunk >= 8) {  // 1x1 convs: 64 channels per barrier
     // (the tile must stay the default 256 x 64: a.XW was sized for its BN)
+    const bool dma = g_lin_dma && a.slope == 1.0f && a.pad_left == 0 && a.up == 1 && a.groups == 1 &&
+                     a.CIN % (2 * KC) == 0 && a.ldx >= 4 && a.ldx % 4 == 0;
+    // without staging registers 64 channels per barrier fit 3 waves per SIMD (measured: 28.84 -> 28.67 ms per encode)
+    if (dma && g_lin_dma == 1 && a.CIN % (4 * KC) == 0) return launch32_t<2, 2, 4, 1, 1, 0, 4, true>(a, B, Lmax_out, stream);
+    if (dma) return launch32_t<2, 2, 4, 1, 1, 0, 2, true>(a, B, Lmax_out, stream);
     if (g_lin_tile == 4) return launch32_t<2, 2, 4, 1, 1, 0, 4>(a, B, Lmax_out, stream);  // 64 ch / barrier
     return launch32_t<2, 2, 4, 1, 1, 0, 2>(a, B, Lmax_out, stream);                        // 32 ch / barrier
   }
