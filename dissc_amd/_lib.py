@@ -56,6 +56,8 @@ def _load():
     L.dissc_device_name.argtypes = [i32, ctypes.c_char_p, ctypes.c_size_t]
     L.dissc_gen_create.argtypes = [ctypes.POINTER(DisscGenConfig), ctypes.POINTER(DisscTensor),
                                    ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.dissc_gen_create_ex.argtypes = [ctypes.POINTER(DisscGenConfig), ctypes.POINTER(DisscTensor),
+                                      ctypes.c_size_t, i32, ctypes.POINTER(vp)]
     L.dissc_gen_destroy.argtypes = [vp]
     L.dissc_gen_destroy.restype = None
     L.dissc_gen_hop.argtypes = [vp]

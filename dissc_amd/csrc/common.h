@@ -106,7 +106,7 @@ void pack_conv_weights_bf3(const float* w, int Cout, int Cin, int KS, std::vecto
 int launch_conv_bf3(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream);
 int conv_bf3_tile_bn(int M);
 extern int g_precision;   // "precision" option: 0 = fp32 (default); 1 = split-bf16 generator (read at create)
-extern int g_conv_prec;   // precision make_conv packs for: g_precision inside dissc_gen_create, else 0
+extern thread_local int g_conv_prec;   // precision make_conv packs for: g_precision inside dissc_gen_create, else 0
                           // (predictors and HuBERT feed integer decisions and always stay fp32)
 extern int g_use_mfma32;  // tuning: 0 forces the 16x16x4 kernel everywhere
 

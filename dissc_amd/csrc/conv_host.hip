@@ -8,7 +8,7 @@ namespace dissc {
 
 int g_use_mfma32 = 1;
 int g_precision = 0;
-int g_conv_prec = 0;  // what make_conv packs for; dissc_gen_create raises it to g_precision for its own layers
+thread_local int g_conv_prec = 0;  // (per thread: handles may be built concurrently) what make_conv packs for; dissc_gen_create raises it to g_precision for its own layers
 
 int upload(const std::vector<float>& h, float** d) {
   DISSC_HIP_CHECK(hipMalloc((void**)d, h.size() * sizeof(float)));

@@ -116,6 +116,16 @@ int dissc_device_name(int dev, char* buf, size_t buflen) {
 
 int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size_t n_weights,
                      dissc_gen_t* out) {
+  return dissc_gen_create_ex(cfg, weights, n_weights, -1, out);
+}
+
+int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, size_t n_weights, int precision,
+                        dissc_gen_t* out) {
+  if (precision < -1 || precision > 1) {
+    set_error("dissc_gen_create_ex: precision %d (use -1 = process option, 0 = fp32, 1 = split-bf16)", precision);
+    return DISSC_EINVAL;
+  }
+  const int prec = precision < 0 ? g_precision : precision;  // this handle's arithmetic, fixed from here on
   if (!cfg || !weights || !out) {
     set_error("dissc_gen_create: null argument");
     return DISSC_EINVAL;
@@ -153,9 +163,9 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
   dissc_gen* g = new dissc_gen();
   g->cfg = *cfg;
   struct PrecScope {  // only the generator's layers may be packed for split-bf16
-    PrecScope() { g_conv_prec = g_precision; }
+    explicit PrecScope(int p) { g_conv_prec = p; }
     ~PrecScope() { g_conv_prec = 0; }
-  } prec_scope;
+  } prec_scope(prec);
   int rc = DISSC_OK;
   const float *w = nullptr, *b = nullptr;
   const int c0 = cfg->upsample_initial_channel;
@@ -204,7 +214,7 @@ int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size
         set_error("dissc_gen_create: even resblock kernel size %d unsupported", rk);
         return fail(DISSC_EINVAL);
       }
-      const bool bf3 = g_precision == 1 && resblock_bf3_supported(ch, rk, cfg->resblock_dilations[j]);
+      const bool bf3 = prec == 1 && resblock_bf3_supported(ch, rk, cfg->resblock_dilations[j]);
       const bool fuse = !bf3 && resblock_fused_supported(ch, rk, cfg->resblock_dilations[j]);
       std::vector<float> fw, fb;
       const float* w6[6];

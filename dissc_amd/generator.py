@@ -161,16 +161,10 @@ class CodeGenerator:
             cfg = self._config()
             table, keep = _lib.make_tensor_table(self._folded)
             hnd = ctypes.c_void_p()
-            saved = ctypes.c_int(0)
-            if self.precision is not None:  # the library reads the option when the handle is built
-                check(lib.dissc_get_option(b"precision", ctypes.byref(saved)), "dissc_get_option")
-                check(lib.dissc_set_option(b"precision", self._PRECISIONS[self.precision]), "dissc_set_option")
-            try:
-                check(lib.dissc_gen_create(ctypes.byref(cfg), table, len(keep), ctypes.byref(hnd)),
-                      "dissc_gen_create")
-            finally:
-                if self.precision is not None:
-                    lib.dissc_set_option(b"precision", saved.value)
+            # the handle's arithmetic is an argument of its constructor: no process-wide state is touched
+            prec = -1 if self.precision is None else self._PRECISIONS[self.precision]
+            check(lib.dissc_gen_create_ex(ctypes.byref(cfg), table, len(keep), prec, ctypes.byref(hnd)),
+                  "dissc_gen_create_ex")
             self._handle = hnd
             self.hop = lib.dissc_gen_hop(hnd)
 

@@ -84,6 +84,10 @@ typedef struct dissc_gen* dissc_gen_t;
  * "conv_post.weight/.bias", "dict.weight", "spkr.weight". */
 int dissc_gen_create(const DisscGenConfig* cfg, const DisscTensor* weights, size_t n_weights,
                      dissc_gen_t* out);
+/* the same with the handle's arithmetic given explicitly instead of read from the process-wide "precision" option:
+ * -1 = that option, 0 = exact fp32, 1 = split-bf16 (opt-in, see dissc_set_option) */
+int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, size_t n_weights, int precision,
+                        dissc_gen_t* out);
 void dissc_gen_destroy(dissc_gen_t g);
 /* samples produced per input frame (= prod(upsample_rates) = 320) */
 int dissc_gen_hop(dissc_gen_t g);
