@@ -113,6 +113,42 @@ class _FakeEvent:
         return (other.t - self.t) * 1e3
 
 
+def pipeline_leg(synth, dev, g, utts=32, seconds=10.0, iters=5):
+    """"also report the full pipeline separately" -- encode -> len / pitch prediction -> resynthesis of
+    `utts` x `seconds` s of synthetic audio through the device-resident Converter (dissc_amd/pipeline.py), wall time of
+    the whole call with the input audio already in HBM (like `value`), one converted utterance per input."""
+    import time
+
+    import numpy as np
+    import torch
+    from dissc_amd import predictors as P
+    from dissc_amd.hubert import HubertEncoder
+    from dissc_amd.pipeline import Converter
+    n = int(seconds * 16000)
+    enc = HubertEncoder(synth.synth_hubert_state_dict(6), synth.synth_kmeans_centers(), 6).to(dev)
+    lm = P.LenPredictor(100, 108).to(dev)
+    lm.load_state_dict(synth.synth_len_state_dict(100, 108))
+    lm.norm_mean, lm.norm_std = synth.synth_len_norm_stats()
+    pm = P.PitchPredictor(100, 108).to(dev)
+    pm.load_state_dict(synth.synth_pitch_state_dict("new", 100, 108))
+    conv = Converter(enc, lm, pm, g)
+    waves = [torch.from_numpy(synth.synth_waveform(n, seed=i)).to(dev) for i in range(utts)]
+    out = conv(waves, [6])
+    out_sec = sum(len(w) for w in out.values()) / 16000.0 if isinstance(out, dict) else None
+    ts = []
+    for _ in range(iters):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = conv(waves, [6])
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    wall = float(np.median(ts))
+    return {"workload": f"encode (HuBERT-6L + k-means) -> length / pitch predictors -> HiFi-GAN, {utts} x {seconds:g} s in, "
+                        "1 target speaker, in memory (dissc_amd.pipeline.Converter), input audio resident in HBM",
+            "ms_per_batch": round(wall * 1e3, 2), "value": round(utts * seconds / wall, 1),
+            "unit": "input audio-sec/sec", "output_audio_sec": out_sec, "iters": iters}
+
+
 def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_sec_per_step, flops_step):
     """The opt-in split-bf16 ("bf16x3") arithmetic mode of the same generator, timed on the same
     batch right after the fp32 run and checked against the fp32 waveform (north_star bar: 1e-4 RMS).
@@ -168,6 +204,7 @@ def main():
     ap.add_argument("--frames", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-bf16", action="store_true", help="skip the extra split-bf16 leg (N=1 only)")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the full-pipeline leg (N=1 only)")
     a = ap.parse_args()
 
     # DISSC_BENCH_FAKE=1: CPU/gloo dry run of the distributed bookkeeping only (tests/test_bench_dist.py);
@@ -306,6 +343,8 @@ def main():
         if not a.no_split_bf16 and n_gpus == 1 and not fake:
             out["split_bf16"] = split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y, a.steps,
                                                audio_sec_per_step, flops_step)
+        if not a.no_pipeline and n_gpus == 1 and not fake:
+            out["pipeline"] = pipeline_leg(synth, dev, g)
         if not a.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(synth, sd, torch.from_numpy(code), torch.from_numpy(f0),
                                                torch.from_numpy(spkr))
