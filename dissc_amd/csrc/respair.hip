@@ -235,7 +235,10 @@ __global__ void __launch_bounds__(256) respair16_kernel(const PairArgs a) {
 // next step's fragments are fetched while the current 8*NI MFMAs run (sched_barrier pins the prefetch).
 typedef float f32x16p __attribute__((ext_vector_type(16)));
 
-template <int KS, int DIL, int NI>
+// LM (LDS mode): 0 = separate windows for lrelu(x) and T (70-78 KB: two workgroups per CU); 1 (default) = T overwrites
+// the x window after one more barrier, wave-private epilogue patches in their own 8.7 KB (44-52 KB: three per CU,
+// -0.43 ms per forward).  Letting the patches overwrite the window too (35-43 KB, four per CU) measured the same.
+template <int KS, int DIL, int NI, int LM>
 __global__ void __launch_bounds__(256) respair32_kernel(const PairArgs a) {
   constexpr int C = 32, NW = 4, NT = 64 * NW;
   constexpr int SLOTS = 32 * NI * NW;
@@ -248,8 +251,11 @@ __global__ void __launch_bounds__(256) respair32_kernel(const PairArgs a) {
   constexpr int CW = 32 * NI + 4;
   constexpr int LPR = 8 * NI, RPP = 64 / LPR, NPASS = 8 / RPP;
   static_assert(NW * 8 * CW <= C * XW1, "epilogue patches alias the input window");
+  static_assert(XW2 <= XW1, "T fits the x window");
   __shared__ __attribute__((aligned(16))) float Xs[C * XW1];
-  __shared__ __attribute__((aligned(16))) float Ts[C * XW2];
+  __shared__ __attribute__((aligned(16))) float Tsep[LM == 0 ? C * XW2 : 4];
+  __shared__ __attribute__((aligned(16))) float Psep[LM == 1 ? NW * 8 * CW : 4];
+  float* const Ts = LM == 0 ? Tsep : Xs;
 
   const int b = blockIdx.y;
   const int len = a.lengths ? a.lengths[b] * a.len_mul : a.len_default;
@@ -335,6 +341,7 @@ __global__ void __launch_bounds__(256) respair32_kernel(const PairArgs a) {
   }
   // epilogue 1: T = lrelu(conv_d + b1), 0 outside the utterance.  D layout: col = lane & 31,
   // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+  if constexpr (LM != 0) __syncthreads();  // every wave is done reading the x window T is about to overwrite
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int u = wave * (32 * NI) + ni * 32 + l31;
@@ -357,8 +364,8 @@ __global__ void __launch_bounds__(256) respair32_kernel(const PairArgs a) {
     DISSC_PAIR32_TAPS(w2p, bt, XW2, 1, w2p)  // (the last prefetch re-reads tap 0: harmless)
   }
 #undef DISSC_PAIR32_TAPS
-  // epilogue 2: 8 rows at a time through a wave-private patch [8][CW] (aliases Xs) -> 16 B per lane
-  float* ep = Xs + wave * (8 * CW);
+  // epilogue 2: 8 rows at a time through a wave-private patch [8][CW] -> 16 B per lane
+  float* ep = (LM == 1 ? Psep : Xs) + wave * (8 * CW);
   const int prow = lane / LPR, pc4 = lane % LPR;
   const int ncol = wave * (32 * NI) + 4 * pc4;
   const int tcol = o0 + ncol;
@@ -397,7 +404,10 @@ template <int KS, int DIL>
 static int launch_pair32(const PairArgs& a, int B, int Lmax, hipStream_t stream) {
   constexpr int NI = 2, SLOTS = 32 * NI * 4, WOUT = (SLOTS - (KS - 1)) & ~3;
   dim3 grid((Lmax + WOUT - 1) / WOUT, B);
-  hipLaunchKernelGGL((respair32_kernel<KS, DIL, NI>), grid, dim3(256), 0, stream, a);
+  if (g_pair_lds_mode == 0)
+    hipLaunchKernelGGL((respair32_kernel<KS, DIL, NI, 0>), grid, dim3(256), (size_t)g_pair_pad_lds, stream, a);
+  else
+    hipLaunchKernelGGL((respair32_kernel<KS, DIL, NI, 1>), grid, dim3(256), (size_t)g_pair_pad_lds, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
@@ -406,11 +416,13 @@ template <int KS, int DIL>
 static int launch_pair16(const PairArgs& a, int B, int Lmax, hipStream_t stream) {
   constexpr int NI = 4, SLOTS = 16 * NI * 4, WOUT = (SLOTS - (KS - 1)) & ~3;
   dim3 grid((Lmax + WOUT - 1) / WOUT, B);
-  hipLaunchKernelGGL((respair16_kernel<KS, DIL, NI>), grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((respair16_kernel<KS, DIL, NI>), grid, dim3(256), (size_t)g_pair_pad_lds, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
 
+int g_pair_lds_mode = 1;  // "pair_lds" option: LDS layout of respair32 (see LM)
+int g_pair_pad_lds = 0;  // diagnostics: extra dynamic LDS bytes per workgroup (lowers occupancy)
 int g_pair_max_c = 32;  // "pair_max_c" option: widest stage run as fused residual pairs (0 = off)
 
 bool respair_supported(int C, int KS, int dil) {
