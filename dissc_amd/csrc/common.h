@@ -169,6 +169,7 @@ int launch_resblock_fused(int C, const float* x, float* acc, const float* wpack,
 
 // one residual pair y = x + conv_1(lrelu(conv_d(lrelu(x)))) per launch, exact fp32 (respair.hip)
 extern int g_pair_pad_lds;
+extern int g_conv_pad_lds;
 extern int g_pair_lds_mode;
 extern int g_pair_max_c;  // "pair_max_c" option: widest stage run this way (0 = off)
 bool respair_supported(int C, int KS, int dil);

@@ -250,6 +250,7 @@ static const TileCfg32 kCfgs32[] = {
 int g_lin_tile = 2;  // "lin_tile" option: channels per barrier / 16 of the 1x1 (linear) convs (2 or 4)
 int g_cpb2 = 0;  // "cpb2" option: kernels with KS <= this stage 32 channels per barrier
 int g_lin_dma = 1;  // "lin_dma" option: 1x1 convs stage their window with global_load_lds (1: 64, 2: 32 channels per barrier)
+int g_conv_pad_lds = 0;  // "conv_pad_lds" option (diagnostics): extra LDS bytes per workgroup
 int g_mfast = 0;  // measured neutral on HuBERT linears (weights are L2/MALL resident either way)
 static int g_cfg32_for_bm[4] = {3, 2, 1, 0};  // BM class 32, 64, 128, 256 -> cfg id
 
@@ -339,7 +340,7 @@ static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   if (a.mfast) grid = dim3(grid.y, grid.x, grid.z);
   size_t lds_f = (size_t)2 * KC * CPB * a.XW;
   if (lds_f < (size_t)NW * 8 * CW) lds_f = (size_t)NW * 8 * CW;
-  const size_t lds = lds_f * sizeof(float);
+  const size_t lds = lds_f * sizeof(float) + (size_t)g_conv_pad_lds;  // (+ diagnostics: occupancy experiments)
   static bool attr_done = false;
   if (!attr_done) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(

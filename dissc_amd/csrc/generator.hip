@@ -581,6 +581,7 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "fused_max_c") == 0) { fused_set_option(2, value); return DISSC_OK; }
   if (strcmp(key, "pair_max_c") == 0) { g_pair_max_c = value; return DISSC_OK; }
   if (strcmp(key, "pair_pad_lds") == 0) { g_pair_pad_lds = value; return DISSC_OK; }
+  if (strcmp(key, "conv_pad_lds") == 0) { g_conv_pad_lds = value; return DISSC_OK; }
   if (strcmp(key, "pair_lds") == 0) { g_pair_lds_mode = value; return DISSC_OK; }
   if (strcmp(key, "fused_variant") == 0) {
     fused_set_option(3, value);
