@@ -11,6 +11,9 @@
 #ifndef DISSC_LB32
 #define DISSC_LB32 2
 #endif
+#ifndef DISSC_LB32_DMA
+#define DISSC_LB32_DMA 4  // the LDS-DMA instances have no staging registers: 4 waves per SIMD
+#endif
 
 namespace dissc {
 
@@ -24,7 +27,7 @@ namespace dissc {
 // one wave instruction = 1 KB = four 64-column rows), no staging registers, no VALU.  Nothing is masked: a 1x1 conv's
 // output column depends on its own input column only, and columns >= olen are never stored.
 template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1, bool DMA = false>
-__global__ void __launch_bounds__(64 * WM * WN, DISSC_LB32) conv_mfma32_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN, DMA ? DISSC_LB32_DMA : DISSC_LB32) conv_mfma32_kernel(const ConvArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BN = 32 * NI * WN;
   constexpr int KCB = KC * CPB;  // channels staged per barrier
