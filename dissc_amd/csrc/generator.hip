@@ -34,6 +34,12 @@ void set_error(const char* fmt, ...) {
 using namespace dissc;
 
 static int g_stream_prio = 1;  // "stream_prio" option: prioritise the longer ResBlock chains
+static int g_graphs = 0;          // "graphs" option: replay small forwards from a captured hipGraph.  OFF by default:
+                                  // measured on ROCm 7.2 / MI355X, hipGraphLaunch of the ~85-node three-branch graph costs
+                                  // 1.3-1.8 ms MORE per forward than the plain three-stream launches (tools/graph_ab.py)
+static int g_graph_frames = 2048;  // "graph_frames" option: largest B * Tmax that is graphed
+static int g_graph_hits = 0, g_graph_captures = 0;  // diagnostics (dissc_get_option)
+static unsigned g_opt_epoch = 0;   // bumped by every dissc_set_option: captured graphs of older epochs are dropped
 static int g_multistream = 1;  // "multistream" option: concurrent ResBlock chains (read at create)
 static int g_par_ups = 1;      // "par_ups" option: ConvTranspose phase groups on concurrent streams
 
@@ -77,7 +83,22 @@ struct dissc_gen {
   // small-kernel layers overlap with matrix-bound large-kernel ones.
   hipStream_t aux[DISSC_MAX_RK] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_x = nullptr, ev_fin[DISSC_MAX_RK] = {nullptr, nullptr, nullptr, nullptr};
+  // Opt-in (option "graphs"): small forwards (the reference's one-utterance-at-a-time mode: ~85 launches of a few us each
+  // over three streams, 11 % of the period idle) captured once per (shapes, buffers) into a hipGraph and replayed.
+  struct GraphEntry {
+    const void *code, *f0, *spkr, *lengths, *out, *ws;
+    int B, T;
+    unsigned epoch;
+    hipGraphExec_t exec;
+    unsigned long long stamp;
+  };
+  std::vector<GraphEntry> graphs;
+  hipStream_t cap_stream = nullptr;
+  unsigned long long graph_clock = 0;
+  int graph_failures = 0;  // captures that did not produce a graph: after two, this handle stops trying
   ~dissc_gen() {
+    for (auto& e : graphs) (void)hipGraphExecDestroy(e.exec);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
     free_conv(conv_pre);
     for (auto& v : ups) for (auto& c : v) free_conv(c);
     for (auto& c : rb1) free_conv(c);
@@ -328,6 +349,10 @@ double dissc_gen_flops(dissc_gen_t g, int64_t frames) {
   return 2.0 * macs * (double)frames;
 }
 
+static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0, const int64_t* spkr,
+                            const int32_t* lengths, int B, int Tmax, float* wav_out, void* workspace,
+                            hipStream_t stream);
+
 int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const int64_t* spkr,
                       const int32_t* lengths, int B, int Tmax, float* wav_out, void* workspace,
                       size_t workspace_bytes, void* stream_) {
@@ -350,6 +375,62 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
     return DISSC_ENOMEM;
   }
   hipStream_t stream = (hipStream_t)stream_;
+  if (!g_graphs || g->graph_failures >= 2 || (long long)B * Tmax > g_graph_frames)
+    return gen_forward_body(g, code, f0, spkr, lengths, B, Tmax, wav_out, workspace, stream);
+  // ---- small forward: replay (or first capture) its hipGraph ----
+  for (auto& e : g->graphs)
+    if (e.code == code && e.f0 == f0 && e.spkr == spkr && e.lengths == lengths && e.out == wav_out && e.ws == workspace &&
+        e.B == B && e.T == Tmax && e.epoch == g_opt_epoch) {
+      e.stamp = ++g->graph_clock;
+      ++g_graph_hits;
+      DISSC_HIP_CHECK(hipGraphLaunch(e.exec, stream));
+      return DISSC_OK;
+    }
+  if (!g->cap_stream && hipStreamCreateWithFlags(&g->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    return gen_forward_body(g, code, f0, spkr, lengths, B, Tmax, wav_out, workspace, stream);
+  }
+  // capture on the handle's own stream (the caller's may be the legacy default stream, which cannot capture); the side
+  // streams join the capture through the events the body records and waits on, and all rejoin before it ends
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int rc = DISSC_EHIP;
+  if (hipStreamBeginCapture(g->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+    rc = gen_forward_body(g, code, f0, spkr, lengths, B, Tmax, wav_out, workspace, g->cap_stream);
+    const hipError_t e = hipStreamEndCapture(g->cap_stream, &graph);
+    if (rc == DISSC_OK && (e != hipSuccess || !graph)) rc = DISSC_EHIP;
+    if (rc == DISSC_OK && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = DISSC_EHIP;
+    if (graph) (void)hipGraphDestroy(graph);
+  }
+  if (rc != DISSC_OK) {  // anything the capture cannot express: run it the plain way
+    (void)hipGetLastError();
+    ++g->graph_failures;
+    return gen_forward_body(g, code, f0, spkr, lengths, B, Tmax, wav_out, workspace, stream);
+  }
+  // keep the eight most recently used graphs (and none of an older option epoch)
+  for (size_t i = 0; i < g->graphs.size();)
+    if (g->graphs[i].epoch != g_opt_epoch) {
+      (void)hipGraphExecDestroy(g->graphs[i].exec);
+      g->graphs.erase(g->graphs.begin() + i);
+    } else {
+      ++i;
+    }
+  if (g->graphs.size() >= 8) {
+    size_t old = 0;
+    for (size_t i = 1; i < g->graphs.size(); ++i)
+      if (g->graphs[i].stamp < g->graphs[old].stamp) old = i;
+    (void)hipGraphExecDestroy(g->graphs[old].exec);
+    g->graphs.erase(g->graphs.begin() + old);
+  }
+  ++g_graph_captures;
+  g->graphs.push_back({code, f0, spkr, lengths, wav_out, workspace, B, Tmax, g_opt_epoch, exec, ++g->graph_clock});
+  DISSC_HIP_CHECK(hipGraphLaunch(exec, stream));
+  return DISSC_OK;
+}
+
+static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0, const int64_t* spkr,
+                            const int32_t* lengths, int B, int Tmax, float* wav_out, void* workspace,
+                            hipStream_t stream) {
   const size_t nbuf = gen_buf_floats(g, B, Tmax);
   float* base = (float*)round_up((size_t)workspace, 256);
   float* X = base;
@@ -540,6 +621,9 @@ int dissc_get_option(const char* key, int* value) {
   if (!key || !value) return DISSC_EINVAL;
   if (strcmp(key, "precision") == 0) { *value = g_precision; return DISSC_OK; }
   if (strcmp(key, "multistream") == 0) { *value = g_multistream; return DISSC_OK; }
+  if (strcmp(key, "graphs") == 0) { *value = g_graphs; return DISSC_OK; }
+  if (strcmp(key, "graph_hits") == 0) { *value = g_graph_hits; return DISSC_OK; }
+  if (strcmp(key, "graph_captures") == 0) { *value = g_graph_captures; return DISSC_OK; }
   if (strcmp(key, "stream_prio") == 0) { *value = g_stream_prio; return DISSC_OK; }
   if (strcmp(key, "par_ups") == 0) { *value = g_par_ups; return DISSC_OK; }
   if (strcmp(key, "pair_max_c") == 0) { *value = g_pair_max_c; return DISSC_OK; }
@@ -549,6 +633,9 @@ int dissc_get_option(const char* key, int* value) {
 
 int dissc_set_option(const char* key, int value) {
   if (!key) return DISSC_EINVAL;
+  ++g_opt_epoch;
+  if (strcmp(key, "graphs") == 0) { g_graphs = value; return DISSC_OK; }
+  if (strcmp(key, "graph_frames") == 0) { g_graph_frames = value; return DISSC_OK; }
   if (strncmp(key, "conv_cfg_bm", 11) == 0) {  // "conv_cfg_bm16|32|64|128|256" -> tile config id
     const int bm = atoi(key + 11);
     int cls = 0;

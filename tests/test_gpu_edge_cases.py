@@ -36,6 +36,35 @@ def test_batch_with_empty_and_single_frame_utterances(env):
     assert not y[1].any()
 
 
+def test_hipgraph_replay_is_bit_identical(env):
+    """option "graphs" (off by default: measured slower on ROCm 7.2): a small forward captured into a hipGraph --
+    the three ResBlock streams join the capture through their events -- and replayed gives the same bits, also when
+    the ragged lengths behind the same pointer change between replays"""
+    g, synth, lib = env["g"], env["synth"], env["lib"]
+    code, f0, spkr, _ = synth.synth_generator_inputs(3, 60, seed=7)
+    kw = dict(code=torch.from_numpy(code).cuda(), f0=torch.from_numpy(f0).cuda(), spkr=torch.from_numpy(spkr).cuda())
+    lens = torch.tensor([60, 41, 13], dtype=torch.int32).cuda()
+    plain = [g(**kw, lengths=lens).clone()]
+    lens.copy_(torch.tensor([22, 60, 5], dtype=torch.int32))
+    plain.append(g(**kw, lengths=lens).clone())
+    hits0, cap0 = ctypes.c_int(), ctypes.c_int()
+    lib.dissc_get_option(b"graph_hits", ctypes.byref(hits0))
+    assert lib.dissc_set_option(b"graphs", 1) == 0
+    try:
+        lens.copy_(torch.tensor([60, 41, 13], dtype=torch.int32))
+        for rep in range(4):
+            y = g(**kw, lengths=lens)
+            assert torch.equal(y, plain[0]), rep
+            del y
+        lens.copy_(torch.tensor([22, 60, 5], dtype=torch.int32))
+        assert torch.equal(g(**kw, lengths=lens), plain[1])
+        hits = ctypes.c_int()
+        lib.dissc_get_option(b"graph_hits", ctypes.byref(hits))
+        assert hits.value > hits0.value  # replays happened (the caching allocator hands the same buffers back)
+    finally:
+        assert lib.dissc_set_option(b"graphs", 0) == 0
+
+
 def test_long_utterance_30s(env):
     """1500 frames (30 s): beyond the bench shape; finite, bounded, and batch independent."""
     g, synth = env["g"], env["synth"]
