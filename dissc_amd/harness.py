@@ -128,11 +128,11 @@ def pack_waves(waves, job_ids, n_max, l_max, device):
 
 
 _PIN = {"buf": None}
-_PIN_MAX_BYTES = 256 << 20
+_PIN_MAX_BYTES = 64 << 20  # page-locking costs ~0.2 ms per MB once; larger buffers go through in chunks
 
 
 def _pinned_rows(n_floats_per_row, rows):
-    """page-locked staging rows (cached: page-locking costs more than the copy itself), at most 256 MB"""
+    """page-locked staging rows (cached: page-locking costs more than the copy itself), at most 64 MB"""
     cap = max(1, min(rows, _PIN_MAX_BYTES // (4 * n_floats_per_row)))
     need = cap * n_floats_per_row
     if _PIN["buf"] is None or _PIN["buf"].numel() < need:
@@ -143,7 +143,7 @@ def _pinned_rows(n_floats_per_row, rows):
 
 def unpack_waves(gathered, copy=False):
     """packed f32 [rows, 4+l_max] (any device) -> {job_id: 1-D float32 numpy array}.  A device buffer comes over in
-    ONE device-to-host copy into a cached page-locked staging buffer (chunks of <= 256 MB for very large sweeps; a
+    ONE device-to-host copy into a cached page-locked staging buffer (chunks of <= 64 MB for large sweeps; a
     pageable ``.cpu()`` of the 20 MB of a 32-utterance batch takes 1.7 ms, this 0.7 ms), and every job's valid
     samples are copied out of it into an array of their own.  A host buffer is viewed in place unless ``copy``."""
     out = {}
