@@ -279,6 +279,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
 // host side
 // ---------------------------------------------------------------------------------
 static int pick_bm(int M) {
+  if (M == 48) return 48;  // HuBERT's positional conv: 48 rows per group = three 16-row tiles, nothing padded
   if (M >= 256) return 256;
   if (M >= 128) return 128;
   if (M >= 64) return 64;
@@ -299,6 +300,7 @@ static const TileCfg kCfgs[] = {
     {2, 4, 2, 2},  // 7:  64 x 128
     {2, 4, 4, 1},  // 8: 128 x 64
     {4, 2, 4, 2},  // 9: 256 x 64, 8 waves
+    {3, 4, 1, 4},  // 10: 48 x 256 (pick_bm(48) only)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static int g_cfg_for_bm[5] = {6, 5, 7, 1, 0};  // index log2(BM/16) -> cfg id (tunable)
@@ -309,6 +311,7 @@ void conv_set_cfg(int bm_class, int cfg) {
 
 int conv_cfg(int M) {
   const int bm = pick_bm(M);
+  if (bm == 48) return 10;
   int cls = 0;
   while ((16 << cls) < bm) ++cls;
   int cfg = g_cfg_for_bm[cls];
@@ -421,6 +424,7 @@ int launch_conv(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t 
   if (span > MAX_TAP_SPAN) {
     // wide taps (HuBERT positional conv k=128, 48 rows per group): 32x256 tile only
     if (span <= WIDE_TAP_SPAN && cfg == 5) return launch_t<2, 4, 1, 4, 1, WIDE_TAP_SPAN>(a, B, Lmax_out, stream);
+    if (span <= WIDE_TAP_SPAN && cfg == 10) return launch_t<3, 4, 1, 4, 1, WIDE_TAP_SPAN>(a, B, Lmax_out, stream);
     set_error("launch_conv: kernel %d x dilation %d unsupported for %d rows", a.KS, a.dil, a.M);
     return DISSC_EINVAL;
   }
@@ -436,6 +440,7 @@ int launch_conv(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t 
     case 6: return launch_t<1, 4, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     case 7: return launch_t<2, 4, 2, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     case 8: return launch_t<2, 4, 4, 1, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
+    case 10: return launch_t<3, 4, 1, 4, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     default: return launch_t<4, 2, 4, 2, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
   }
 }
