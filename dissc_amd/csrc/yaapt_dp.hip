@@ -69,6 +69,14 @@ __device__ inline double median_at(const double* a, int n, int c, int ks) {
   return w[h];
 }
 
+// a lane's double as a wave-uniform value (two v_readlane_b32; `lane` is a compile-time constant at every call site --
+// a ds_bpermute shuffle here put ~100 cycles of LDS latency, sixteen times, on every step of the serial chain)
+__device__ inline double readlane_d(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // One wave: min-plus recursion over n frames with the K candidates on the lanes (lane % K = candidate).
 //   val(i, k): the candidate's pitch, local(i, k): its own cost, scal(i): a per-step scalar of the step i-1 -> i,
 //   cost(cur, prv, s): transition cost.  The per-frame operands are fetched one frame ahead, so that only shuffles
@@ -89,7 +97,7 @@ __device__ inline void viterbi_wave(int n, Val val, Local local, Scal scal, Cost
     int arg = 0;
 #pragma unroll
     for (int fr = 0; fr < K; ++fr) {
-      const double c = cost(v_cur, __shfl(v_prev, fr, 64), s_cur) + __shfl(cum, fr, 64);
+      const double c = cost(v_cur, readlane_d(v_prev, fr), s_cur) + readlane_d(cum, fr);
       if (fr == 0 || c < best) { best = c; arg = fr; }  // first minimum on ties (np.argmin)
     }
     cum = best + l_cur;
@@ -98,8 +106,9 @@ __device__ inline void viterbi_wave(int n, Val val, Local local, Scal scal, Cost
   }
   double bestc = 0.0;
   int last = 0;
+#pragma unroll
   for (int k = 0; k < K; ++k) {
-    const double c = __shfl(cum, k, 64);
+    const double c = readlane_d(cum, k);
     if (k == 0 || c < bestc) { bestc = c; last = k; }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -455,11 +464,12 @@ __global__ void __launch_bounds__(DP_NT) yaapt_final_track_kernel(const FinalArg
   const double mean_pitch = n > 0.0 ? s / n : 150.0;
   if (tid < 64) {
     const double w1 = c.dp_w1, w2 = c.dp_w2, w3 = c.dp_w3, w4 = c.dp_w4;
+    const double inv_mean = 1.0 / mean_pitch;  // eight fp64 divisions per frame on the serial chain otherwise
     viterbi_wave<8>(
         t, [&](int i, int k) { return P(k)[i]; }, [&](int i, int k) { return w4 * (1.0 - M(k)[i]); },
         [&](int i) { return w2 * (1.0 - fmin(1.0, fabs(en[i - 1] - en[i]))); },
         [&](double cur, double prv, double mixed) {
-          if (cur > 0.0 && prv > 0.0) return w1 * fabs(cur - prv) / mean_pitch;
+          if (cur > 0.0 && prv > 0.0) return w1 * fabs(cur - prv) * inv_mean;  // (numpy divides: <= 1 ulp apart)
           if (cur == 0.0 && prv == 0.0) return w3;
           return mixed;
         },
