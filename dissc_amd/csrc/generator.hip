@@ -719,10 +719,10 @@ int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int e
   const int saved_cls = (flags >> 16) & 0xf;
   if (flags & 0x8000) conv_set_cfg(saved_cls, (flags >> 8) & 0x3f);
   for (int it = 0; it < 2 && !rc; ++it)
-    rc = run_conv(dc, x, y, r, a, nullptr, L, 1, B, Cin, ld, ld, L, 0.1f, epi, 3.f, nullptr);
+    rc = run_conv(dc, x, y, r, a, nullptr, L, 1, B, Cin, ld, ld, L, (flags & 1) ? 1.0f : 0.1f, epi, 3.f, nullptr);
   DISSC_HIP_CHECK(hipEventRecord(e0, nullptr));
   for (int it = 0; it < iters && !rc; ++it)
-    rc = run_conv(dc, x, y, r, a, nullptr, L, 1, B, Cin, ld, ld, L, 0.1f, epi, 3.f, nullptr);
+    rc = run_conv(dc, x, y, r, a, nullptr, L, 1, B, Cin, ld, ld, L, (flags & 1) ? 1.0f : 0.1f, epi, 3.f, nullptr);
   DISSC_HIP_CHECK(hipEventRecord(e1, nullptr));
   hipError_t e = hipEventSynchronize(e1);
   float ms = 0.f;
