@@ -353,8 +353,11 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["pipeline"] = {"error": f"{type(e).__name__}: {e}"}
         if not a.no_cpu_baseline and n_gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(synth, sd, torch.from_numpy(code), torch.from_numpy(f0),
-                                               torch.from_numpy(spkr))
+            try:
+                out["cpu_baseline"] = cpu_baseline(synth, sd, torch.from_numpy(code), torch.from_numpy(f0),
+                                                   torch.from_numpy(spkr))
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
