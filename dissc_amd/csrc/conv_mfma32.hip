@@ -68,14 +68,20 @@ __global__ void __launch_bounds__(64 * WM * WN, DMA ? DISSC_LB32_DMA : DISSC_LB3
   // clamped, never predicated, so nothing waits at the load site); zero padding, the
   // ragged tail and leaky-ReLU are applied when the registers are written to LDS.
   f32x4 sv[DMA ? 1 : SV];
-  static_assert(!DMA || (SPAN == 0 && STRIDE == 1 && BN == 64 && (KCB * 16) % NT == 0), "DMA staging: 1x1, 64 columns");
+  static_assert(!DMA || (BN == 64 && CPB * 16 * 64 % NT == 0 && ((SPAN == 0 && STRIDE == 1) || (STRIDE == 2 && CPB == 1))),
+                "DMA staging: 1x1 convs, or the stride-2 valid convs of HuBERT's feature extractor");
+  // stride-2 DMA: rows are the raw window [2 t0, 2 t0 + 136) (k <= 9), packed back to back (row stride 136 floats), and
+  // the fragment reads step two floats per lane (a 2-way bank conflict on 2 reads per 4 MFMAs: irrelevant)
+  constexpr int DW4 = (STRIDE == 2) ? 34 : 16;  // float4 per staged row
   auto stage_dma = [&](float* buf, int c) {
-    // slot e = tid + i*NT -> row e / 16, float4 e % 16; a wave's 64 slots are contiguous in LDS (row stride 64)
+    // slot e = tid + i*NT -> row e / DW4, float4 e % DW4; a wave's 64 slots are contiguous in LDS
+    constexpr int NSLOT = KCB * DW4;
 #pragma unroll
-    for (int i = 0; i < (KCB * 16) / NT; ++i) {
+    for (int i = 0; i < (NSLOT + NT - 1) / NT; ++i) {
       const int e = tid + i * NT;
-      const int ci = c * KCB + (e >> 4);
-      int t = t0 + 4 * (e & 15);
+      if (NSLOT % NT != 0 && e >= NSLOT) continue;
+      const int ci = c * KCB + e / DW4;
+      int t = tin0 + 4 * (e % DW4);
       t = t > a.ldx - 4 ? a.ldx - 4 : t;
       __builtin_amdgcn_global_load_lds(
           (const void __attribute__((address_space(1)))*)(xb + (size_t)ci * a.ldx + t),
@@ -160,8 +166,9 @@ __global__ void __launch_bounds__(64 * WM * WN, DMA ? DISSC_LB32_DMA : DISSC_LB3
   _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                          \
       acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][(KS_) >> 2][(KS_) & 3], BV[ni], acc[mi][ni], 0, 0, 0);
 
-  const int boff = (STRIDE == 2) ? h * XW + wn * (32 * NI) + l31 : h * XW + sh + (wn * (32 * NI) + l31);
-  constexpr int CS = (STRIDE == 2) ? 1 : STRIDE;  // column step of the fragment reads
+  constexpr bool PLANES = (STRIDE == 2) && !DMA;  // even / odd sample planes (register staging only)
+  const int boff = PLANES ? h * XW + wn * (32 * NI) + l31 : h * XW + sh + (wn * (32 * NI) + l31) * STRIDE;
+  constexpr int CS = PLANES ? 1 : STRIDE;  // column step of the fragment reads
   const int XH = XW >> 1;
   const int XW2 = 2 * XW;
   int q = 0;
@@ -175,7 +182,7 @@ __global__ void __launch_bounds__(64 * WM * WN, DMA ? DISSC_LB32_DMA : DISSC_LB3
       {
       const float* bch = blk + sc * (KC * XW);
         // tap j of a stride-2 conv reads plane (sh+j)&1 at column offset (sh+j)>>1
-        const float* bj = (STRIDE == 2) ? bch + (sh & 1) * XH + (sh >> 1) : bch;
+        const float* bj = PLANES ? bch + (sh & 1) * XH + (sh >> 1) : bch;
         float b0[NI], bk[7][NI], b0n[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) b0[ni] = bj[ni * 32 * CS];
@@ -196,7 +203,7 @@ __global__ void __launch_bounds__(64 * WM * WN, DMA ? DISSC_LB32_DMA : DISSC_LB3
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) bk[s][ni] = bj[(s + 1) * XW2 + ni * 32 * CS];
           DISSC_MFMA_STEP(0, b0)
-          if constexpr (STRIDE == 2) {
+          if constexpr (PLANES) {
             const int tj = sh + j + 1;
             bj = bch + (tj & 1) * XH + (tj >> 1);
           } else {
@@ -254,6 +261,7 @@ int g_lin_tile = 2;  // "lin_tile" option: channels per barrier / 16 of the 1x1 
 int g_cpb2 = 0;  // "cpb2" option: kernels with KS <= this stage 32 channels per barrier
 int g_lin_dma = 1;  // "lin_dma" option: 1x1 convs stage their window with global_load_lds (1: 64, 2: 32 channels per barrier)
 int g_conv_pad_lds = 0;  // "conv_pad_lds" option (diagnostics): extra LDS bytes per workgroup
+int g_conv2_dma = 1;  // "conv2_dma" option: stride-2 valid convs stage their window with global_load_lds
 int g_mfast = 0;  // measured neutral on HuBERT linears (weights are L2/MALL resident either way)
 static int g_cfg32_for_bm[4] = {3, 2, 1, 0};  // BM class 32, 64, 128, 256 -> cfg id
 
@@ -333,7 +341,7 @@ void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<
 template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1, bool DMA = false>
 static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN, NW = WM * WN;
-  if (DMA) a.XW = BN;  // unpadded rows: a wave's 1 KB lands as four whole rows
+  if (DMA) a.XW = (STRIDE == 2) ? 136 : BN;  // unpadded rows: a wave's 1 KB of the DMA lands as whole rows, back to back
   constexpr int CW = 32 * NI + 4;
   a.mt_per_group = (a.M + BM - 1) / BM;
   dim3 grid((Lmax_out + BN - 1) / BN, a.mt_per_group * a.groups, B);
@@ -361,6 +369,11 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
   const int span = (a.KS - 1) * a.dil;
   const int cfg = a.cfg32 >= 0 ? a.cfg32 : conv32_cfg(a.M);
   if (stride == 2 && span <= MAX_TAP_SPAN && a.up == 1) {
+    // valid (unpadded) convs on an already-activated input: raw LDS-DMA window, nothing to mask -- every output column
+    // below the utterance's output length reads inputs below its input length
+    if (cfg == 0 && g_conv2_dma && a.slope == 1.0f && a.pad_left == 0 && a.groups == 1 && a.KS <= 9 && a.dil == 1 &&
+        a.CIN % KC == 0 && a.ldx >= 4 && a.ldx % 4 == 0)
+      return launch32_t<2, 2, 4, 1, 2, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);
     if (cfg == 0) return launch32_t<2, 2, 4, 1, 2, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
     set_error("launch_conv32: stride 2 needs >= 256 output rows (got %d)", a.M);
     return DISSC_EINVAL;
