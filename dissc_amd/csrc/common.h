@@ -35,7 +35,11 @@ enum Epi : int {
   EPI_MRF_SET = 2,  // acc = conv + res                         (xs = resblock_0(x))
   EPI_MRF_ADD = 3,  // acc = acc + (conv + res)                 (xs += resblock_j(x))
   EPI_MRF_DIV = 4,  // acc = (acc + (conv + res)) / mrf_div     (x = xs / num_kernels)
+  // out = lrelu(conv, out_slope), and zeros in [olen, olen + 8) and [ldo - 8, ldo) of every row: the layout a consumer
+  // that stages its window by LDS-DMA needs (no activation, no masks: a row's zero tail is the next row's left halo)
+  EPI_STORE_ACT = 5,
 };
+constexpr int ZERO_TAIL = 8;  // >= the largest padding of a consumer ((11 - 1) / 2 = 5), multiple of 4
 
 // One dilated "same" Conv1d (or a phase-decomposed ConvTranspose1d when up > 1)
 // as an implicit GEMM on v_mfma_f32_16x16x4_f32:  D[M, time] += Wpack[M, K] * Xwin[K, time].
@@ -68,6 +72,8 @@ struct ConvArgs {
   long long x_bstride, o_bstride;
   float slope;          // leaky-ReLU slope applied to x on load (1 = identity)
   float mrf_div;
+  float out_slope;      // EPI_STORE_ACT: leaky-ReLU slope applied to the stored value
+  int dma_in;           // 1: x has the EPI_STORE_ACT layout (activated, zero tails) -> LDS-DMA staging, slope must be 1
   int epi;
   int up;               // 1 = conv; s = ConvTranspose stride
   int up_np, up_p0;     // ConvTranspose phase group: row = co*up_np + pi, phase = up_p0 + pi
@@ -152,14 +158,14 @@ int set_affine(DevConv& dc, const float* scale, const float* shift, int n);  // 
 void free_conv(DevConv& dc);
 int run_conv(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
              const int32_t* lengths, int len_default, int len_mul, int B, int C_x, int ldx, int ldo,
-             int Lmax, float slope, int epi, float mrf_div, hipStream_t stream);
+             int Lmax, float slope, int epi, float mrf_div, hipStream_t stream, float out_slope = 0.f, int dma_in = 0);
 
 int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res, const ConvIO& io,
                 int B, int C_x_total, int ldx, int ldo, int Lmax_out, float slope, int epi,
                 hipStream_t stream);
 int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
                 const ConvIO& io, int B, int C_x_total, int ldx, int ldo, int Lmax_out, float slope,
-                int epi, float mrf_div, hipStream_t stream);
+                int epi, float mrf_div, hipStream_t stream, float out_slope = 0.f, int dma_in = 0);
 
 // fused ResBlock1 for narrow stages (resblock_fused.hip)
 bool resblock_fused_supported(int C, int KS, const int* dil);

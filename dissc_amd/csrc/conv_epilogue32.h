@@ -10,6 +10,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
+// EPI_STORE_ACT: zeros for the columns tcol .. tcol+3 of one row that lie in [olen, olen + ZERO_TAIL) or [ldo - ZERO_TAIL, ldo)
+__device__ __forceinline__ void zero_tail4(const ConvArgs& a, size_t rowoff, int tcol, int olen) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int t = tcol + e;
+    if (t >= olen && t < a.ldo && (t < olen + ZERO_TAIL || t >= a.ldo - ZERO_TAIL)) a.out[rowoff + t] = 0.f;
+  }
+}
+
+// a whole tile beyond the utterance (t0 >= olen): only its part of the zero tails is written
+template <int NT, int BN>
+__device__ __forceinline__ void zero_tail_tile(const ConvArgs& a, int b, int t0, int olen) {
+  if (!(t0 < olen + ZERO_TAIL || t0 + BN > a.ldo - ZERO_TAIL) || t0 >= a.ldo) return;
+  const size_t ob = (size_t)b * a.o_bstride;
+  for (int row = threadIdx.x; row < a.M * a.groups; row += NT)
+    for (int t = t0; t < t0 + BN && t < a.ldo; ++t)
+      if (t < olen + ZERO_TAIL || t >= a.ldo - ZERO_TAIL) a.out[ob + (size_t)row * a.ldo + t] = 0.f;
+}
+
 // acc[mi][ni]: rows (ms0 + mi) * 32 .. +31 of group grp, columns t0 + wn * 32 * NI + ni * 32 .. +31.
 // xs: the workgroup's LDS (free at this point): one [8][32 * NI + 4] patch per wave.  All lanes of
 // the calling wave must take part; waves are told apart by threadIdx.x >> 6.
@@ -91,7 +110,11 @@ __device__ __forceinline__ void conv_epilogue32(const ConvArgs& a, f32x16 (&acc)
         const int rl = p * RPP + prow;
         const int row = (ms0 + mi) * 32 + qd * 8 + rl;  // within the group
         f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * CW + 4 * pc4);
-        if (row >= a.M || tcol >= olen) continue;
+        if (row >= a.M) continue;
+        if (tcol >= olen) {
+          if (epi == EPI_STORE_ACT) zero_tail4(a, ob + (size_t)(grp * a.M + row) * a.ldo, tcol, olen);
+          continue;
+        }
         const int prow_idx = grp * a.nsub_group * 32 + row;  // bias/scale/shift are [groups][Mpad]
         const float bz = a.bias[prow_idx];
         v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
@@ -104,6 +127,17 @@ __device__ __forceinline__ void conv_epilogue32(const ConvArgs& a, f32x16 (&acc)
         }
         const size_t idx = ob + (size_t)(grp * a.M + row) * a.ldo + tcol;
         const int nv = olen - tcol;  // >= 1
+        if (epi == EPI_STORE_ACT) {
+          const float sl = a.out_slope;
+          v[0] = lrelu(v[0], sl); v[1] = lrelu(v[1], sl); v[2] = lrelu(v[2], sl); v[3] = lrelu(v[3], sl);
+          if (nv >= 4) {
+            *reinterpret_cast<f32x4*>(a.out + idx) = v;
+          } else {
+            for (int e = 0; e < nv; ++e) a.out[idx + e] = v[e];
+            zero_tail4(a, idx - tcol, tcol, olen);  // the rest of this float4 lies in the zero tail
+          }
+          continue;
+        }
         if (nv >= 4) {
           if (epi == EPI_STORE) {
             *reinterpret_cast<f32x4*>(a.out + idx) = v;

@@ -120,8 +120,9 @@ void free_conv(DevConv& dc) {
 
 int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
                 const ConvIO& io, int B, int C_x_total, int ldx, int ldo, int Lmax_out, float slope,
-                int epi, float mrf_div, hipStream_t stream) {
+                int epi, float mrf_div, hipStream_t stream, float out_slope, int dma_in) {
   ConvArgs a;
+  a.out_slope = out_slope; a.dma_in = dma_in;
   a.x = x; a.wpack = dc.wpack; a.bias = dc.bias; a.scale = dc.scale; a.shift = dc.shift; a.res = res;
   a.out = out; a.acc = acc;
   a.lengths = io.lengths_in; a.len_default = io.len_default; a.len_mul = io.len_mul;
@@ -152,10 +153,10 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
 
 int run_conv(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
              const int32_t* lengths, int len_default, int len_mul, int B, int C_x, int ldx, int ldo,
-             int Lmax, float slope, int epi, float mrf_div, hipStream_t stream) {
+             int Lmax, float slope, int epi, float mrf_div, hipStream_t stream, float out_slope, int dma_in) {
   ConvIO io;
   io.lengths_in = lengths; io.len_default = len_default; io.len_mul = len_mul;
-  return run_conv_ex(dc, x, out, res, acc, io, B, C_x, ldx, ldo, Lmax, slope, epi, mrf_div, stream);
+  return run_conv_ex(dc, x, out, res, acc, io, B, C_x, ldx, ldo, Lmax, slope, epi, mrf_div, stream, out_slope, dma_in);
 }
 
 }  // namespace dissc

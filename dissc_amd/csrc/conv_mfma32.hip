@@ -41,7 +41,10 @@ __global__ void __launch_bounds__(64 * WM * WN, DMA ? DISSC_LB32_DMA : DISSC_LB3
   const int bx = a.mfast ? blockIdx.y : blockIdx.x;  // time tile
   const int by = a.mfast ? blockIdx.x : blockIdx.y;  // (group, M tile)
   const int t0 = bx * BN;
-  if (t0 >= olen) return;
+  if (t0 >= olen) {
+    if (a.epi == EPI_STORE_ACT && by == 0) zero_tail_tile<NT, BN>(a, b, t0, olen);
+    return;
+  }
   const int grp = by / a.mt_per_group;
   const int mt = by - grp * a.mt_per_group;
 
@@ -68,23 +71,28 @@ __global__ void __launch_bounds__(64 * WM * WN, DMA ? DISSC_LB32_DMA : DISSC_LB3
   // clamped, never predicated, so nothing waits at the load site); zero padding, the
   // ragged tail and leaky-ReLU are applied when the registers are written to LDS.
   f32x4 sv[DMA ? 1 : SV];
-  static_assert(!DMA || (BN == 64 && CPB * 16 * 64 % NT == 0 && ((SPAN == 0 && STRIDE == 1) || (STRIDE == 2 && CPB == 1))),
-                "DMA staging: 1x1 convs, or the stride-2 valid convs of HuBERT's feature extractor");
-  // stride-2 DMA: rows are the raw window [2 t0, 2 t0 + 136) (k <= 9), packed back to back (row stride 136 floats), and
-  // the fragment reads step two floats per lane (a 2-way bank conflict on 2 reads per 4 MFMAs: irrelevant)
-  constexpr int DW4 = (STRIDE == 2) ? 34 : 16;  // float4 per staged row
+  static_assert(!DMA || (CPB * 16 * 64 % NT == 0 && ((SPAN == 0 && STRIDE == 1 && BN == 64) || CPB == 1)),
+                "DMA staging: 1x1 convs (64 columns), the stride-2 valid convs of HuBERT, stride-1 convs on an EPI_STORE_ACT input");
+  // DMA windows: row r of a chunk is the raw window [tb, tb + 4 * DW4) of channel r, rows packed back to back (row stride
+  // XW = 4 * DW4 floats).  Nothing is clamped or masked:
+  //   1x1:       64 columns from t0 (clamped to the row: the only variant that may touch the end of the allocation);
+  //   stride 2:  valid convs, [2 t0, 2 t0 + 136) (k <= 9); fragment reads step two floats per lane;
+  //   stride 1:  the input has the EPI_STORE_ACT layout -- activated values, zeros in [len, len + 8) and in the last 8
+  //              columns of every row, so a row's tail is the left halo of the next row (and 8 zeroed floats precede
+  //              the first row): the window may start before the row and run past its end.
+  constexpr bool DMA1 = DMA && STRIDE == 1 && SPAN > 0;
+  const int DW4 = DMA1 ? (XW >> 2) : ((STRIDE == 2) ? 34 : 16);  // float4 per staged row
   auto stage_dma = [&](float* buf, int c) {
     // slot e = tid + i*NT -> row e / DW4, float4 e % DW4; a wave's 64 slots are contiguous in LDS
-    constexpr int NSLOT = KCB * DW4;
-#pragma unroll
-    for (int i = 0; i < (NSLOT + NT - 1) / NT; ++i) {
+    const int nslot = KCB * DW4;
+    for (int i = 0; i * NT < nslot; ++i) {
       const int e = tid + i * NT;
-      if (NSLOT % NT != 0 && e >= NSLOT) continue;
+      if (e >= nslot) continue;
       const int ci = c * KCB + e / DW4;
-      int t = tin0 + 4 * (e % DW4);
-      t = t > a.ldx - 4 ? a.ldx - 4 : t;
+      int t = (DMA1 ? tb : tin0) + 4 * (e % DW4);
+      if constexpr (!DMA1) t = t > a.ldx - 4 ? a.ldx - 4 : t;
       __builtin_amdgcn_global_load_lds(
-          (const void __attribute__((address_space(1)))*)(xb + (size_t)ci * a.ldx + t),
+          (const void __attribute__((address_space(1)))*)(xb + (ptrdiff_t)ci * a.ldx + t),
           (void __attribute__((address_space(3)))*)(buf + (i * NT + (tid & ~63)) * 4), 16, 0, 0);
     }
   };
@@ -341,10 +349,11 @@ void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<
 template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1, bool DMA = false>
 static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN, NW = WM * WN;
-  if (DMA) a.XW = (STRIDE == 2) ? 136 : BN;  // unpadded rows: a wave's 1 KB of the DMA lands as whole rows, back to back
+  if (DMA && !(STRIDE == 1 && SPAN > 0)) a.XW = (STRIDE == 2) ? 136 : BN;  // rows packed back to back (stride-1 taps keep conv_xw's XW)
   constexpr int CW = 32 * NI + 4;
   a.mt_per_group = (a.M + BM - 1) / BM;
-  dim3 grid((Lmax_out + BN - 1) / BN, a.mt_per_group * a.groups, B);
+  // EPI_STORE_ACT writes zero tails up to the end of the output rows: the grid covers ldo, not just the longest utterance
+  dim3 grid(((a.epi == EPI_STORE_ACT ? a.ldo : Lmax_out) + BN - 1) / BN, a.mt_per_group * a.groups, B);
   // Many M tiles (HuBERT's 768..3072-row linears): let blockIdx.x walk them, so that the blocks an
   // XCD receives (id % 8) share a few M tiles and their weight slices stay L2-resident.
   a.mfast = (a.mt_per_group * a.groups >= 3 && g_mfast) ? 1 : 0;
@@ -402,6 +411,12 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
     if (cfg == 0) return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
     if (cfg == 1) return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
     if (cfg == 2) return launch32_t<1, 2, 2, 2, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
+  }
+  if (a.dma_in && a.slope == 1.0f && a.up == 1 && a.groups == 1 && a.CIN % KC == 0 && a.KS > 1) {
+    // input in the EPI_STORE_ACT layout (generator: the second conv of a residual pair): raw LDS-DMA windows
+    if (cfg == 0) return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);
+    if (cfg == 1) return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);
+    if (cfg == 2) return launch32_t<1, 2, 2, 2, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);
   }
   switch (cfg) {
     case 0: return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN>(a, B, Lmax_out, stream);

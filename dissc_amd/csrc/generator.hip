@@ -40,6 +40,7 @@ static int g_graphs = 0;          // "graphs" option: replay small forwards from
 static int g_graph_frames = 2048;  // "graph_frames" option: largest B * Tmax that is graphed
 static int g_graph_hits = 0, g_graph_captures = 0;  // diagnostics (dissc_get_option)
 static unsigned g_opt_epoch = 0;   // bumped by every dissc_set_option: captured graphs of older epochs are dropped
+static int g_pair_dma = 1;  // "pair_dma" option: wide residual pairs hand their intermediate over in the EPI_STORE_ACT layout
 static int g_multistream = 1;  // "multistream" option: concurrent ResBlock chains (read at create)
 static int g_par_ups = 1;      // "par_ups" option: ConvTranspose phase groups on concurrent streams
 
@@ -321,12 +322,14 @@ void dissc_gen_destroy(dissc_gen_t g) { delete g; }
 
 int dissc_gen_hop(dissc_gen_t g) { return g ? g->hop : 0; }
 
+constexpr size_t BUF_GUARD = 64;  // floats in front of the chains' scratch buffers (their last ZERO_TAIL are kept zero)
 static size_t gen_buf_floats(const dissc_gen* g, int B, int Tmax) {
-  size_t per = (size_t)g->cfg.upsample_initial_channel * round_up(Tmax, 4);
-  per = std::max(per, (size_t)g->cfg.model_in_dim * round_up(Tmax, 4));
+  // rows may carry a zero tail (EPI_STORE_ACT layout): ZERO_TAIL extra columns
+  size_t per = (size_t)g->cfg.upsample_initial_channel * round_up(Tmax + ZERO_TAIL, 4);
+  per = std::max(per, (size_t)g->cfg.model_in_dim * round_up(Tmax + ZERO_TAIL, 4));
   for (size_t i = 0; i < g->stage_C.size(); ++i)
-    per = std::max(per, (size_t)g->stage_C[i] * round_up((size_t)Tmax * g->stage_mul[i], 4));
-  return round_up(per * B, 64);
+    per = std::max(per, (size_t)g->stage_C[i] * round_up((size_t)Tmax * g->stage_mul[i] + ZERO_TAIL, 4));
+  return round_up(per * B + BUF_GUARD + 512, 64);  // + slack: LDS-DMA windows run up to ~130 floats past a row
 }
 
 size_t dissc_gen_workspace_bytes(dissc_gen_t g, int B, int Tmax) {
@@ -438,8 +441,10 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
   float* TMPj[DISSC_MAX_RK];
   float* XKj[DISSC_MAX_RK];
   for (int j = 0; j < g->cfg.num_kernels; ++j) {
-    TMPj[j] = base + (size_t)(2 + 2 * j) * nbuf;
+    TMPj[j] = base + (size_t)(2 + 2 * j) * nbuf + BUF_GUARD;
     XKj[j] = base + (size_t)(3 + 2 * j) * nbuf;
+    // the floats right in front of a scratch buffer are the left halo of its first row when a conv stages it by LDS-DMA
+    DISSC_HIP_CHECK(hipMemsetAsync(TMPj[j] - ZERO_TAIL, 0, ZERO_TAIL * sizeof(float), stream));
   }
   float* TMP = TMPj[0];
   const bool multi = g->ev_x != nullptr;
@@ -540,8 +545,13 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
       for (int m = 0; m < 3; ++m) {
         const size_t idx = ((size_t)i * nk + j) * 3 + m;
         const float* xin = (m == 0) ? X : XKc;
-        if ((rc = run_conv(g->rb1[idx], xin, TMPc, nullptr, nullptr, lengths, L, mul, B, ch, ld, ld,
-                           L, 0.1f, EPI_STORE, 1.f, sj)))
+        // wide stages: the first conv stores lrelu(t) with zero tails (EPI_STORE_ACT) so that the second one -- the only
+        // reader of t -- stages its windows by LDS-DMA: no staging registers, no masks, one more wave per SIMD
+        const bool dma2 = g_pair_dma && g->rb1[idx].m32 && g->rb2[idx].m32 && !g->rb1[idx].prec && !g->rb2[idx].prec &&
+                          ch % KC == 0;
+        const int ldt = dma2 ? (int)round_up((size_t)L + ZERO_TAIL, 4) : ld;
+        if ((rc = run_conv(g->rb1[idx], xin, TMPc, nullptr, nullptr, lengths, L, mul, B, ch, ld, ldt,
+                           L, 0.1f, dma2 ? EPI_STORE_ACT : EPI_STORE, 1.f, sj, 0.1f, 0)))
           return rc;
         int epi = EPI_RES;
         if (m == 2) {
@@ -550,8 +560,8 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
           // xs = r0; xs += r1; x = (xs + r2)/3: only the chains' LAST convs are ordered
           if (multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));
         }
-        if ((rc = run_conv(g->rb2[idx], TMPc, XKc, xin, ACC, lengths, L, mul, B, ch, ld, ld, L, 0.1f,
-                           epi, (float)nk, sj)))
+        if ((rc = run_conv(g->rb2[idx], TMPc, XKc, xin, ACC, lengths, L, mul, B, ch, ldt, ld, L, dma2 ? 1.0f : 0.1f,
+                           epi, (float)nk, sj, 0.f, dma2 ? 1 : 0)))
           return rc;
       }
       if (multi) DISSC_HIP_CHECK(hipEventRecord(g->ev_fin[j], sj));
@@ -658,6 +668,7 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "mfast") == 0) { g_mfast = value; return DISSC_OK; }
   if (strcmp(key, "lin_dma") == 0) { g_lin_dma = value; return DISSC_OK; }
   if (strcmp(key, "pos48") == 0) { g_pos48 = value; return DISSC_OK; }
+  if (strcmp(key, "pair_dma") == 0) { g_pair_dma = value; return DISSC_OK; }
   if (strcmp(key, "conv2_dma") == 0) { g_conv2_dma = value; return DISSC_OK; }
   if (strcmp(key, "mfma32") == 0) { g_use_mfma32 = value; return DISSC_OK; }
   if (strncmp(key, "conv32_cfg_bm", 13) == 0) {

@@ -36,6 +36,29 @@ def test_batch_with_empty_and_single_frame_utterances(env):
     assert not y[1].any()
 
 
+def test_dma_handover_of_wide_residual_pairs_on_a_poisoned_workspace(env):
+    """option "pair_dma" (default on): the first conv of a wide residual pair stores lrelu(t) with zero tails and the second
+    stages its windows by LDS-DMA without masks, relying on those zeros (a row's tail is the next row's left halo).  With
+    the scratch memory filled with NaN beforehand, a ragged batch must still give the bits of the masked path."""
+    g, synth, lib = env["g"], env["synth"], env["lib"]
+    B, T = 5, 70
+    code, f0, spkr, _ = synth.synth_generator_inputs(B, T, seed=11)
+    kw = dict(code=torch.from_numpy(code).cuda(), f0=torch.from_numpy(f0).cuda(), spkr=torch.from_numpy(spkr).cuda())
+    lens = torch.tensor([70, 64, 33, 1, 17], dtype=torch.int32).cuda()
+    outs = {}
+    for v in (0, 1):
+        assert lib.dissc_set_option(b"pair_dma", v) == 0
+        g(**kw, lengths=lens)  # sizes the workspace
+        g._ws.view(torch.float32)[: g._ws.numel() // 4].fill_(float("nan"))
+        outs[v] = g(**kw, lengths=lens).clone()
+        assert torch.isfinite(outs[v]).all(), v
+    assert lib.dissc_set_option(b"pair_dma", 1) == 0
+    assert torch.equal(outs[0], outs[1])
+    hop = outs[0].shape[-1] // T
+    for b, n in enumerate([70, 64, 33, 1, 17]):
+        assert not outs[1][b, 0, n * hop:].any()
+
+
 def test_hipgraph_replay_is_bit_identical(env):
     """option "graphs" (off by default: measured slower on ROCm 7.2): a small forward captured into a hipGraph --
     the three ResBlock streams join the capture through their events -- and replayed gives the same bits, also when
