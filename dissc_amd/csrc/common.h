@@ -105,6 +105,7 @@ extern int g_attn_fused;
 extern int g_lin_tile;
 extern int g_cpb2;
 extern int g_conv2_dma;
+extern int g_c64_wide;
 extern int g_pos48;       // tuning: 48-row groups on the 16x16x4 kernel
 extern int g_lin_dma;     // tuning: LDS-DMA staging of the 1x1 convs
 extern int g_mfast;       // tuning: 0 disables the M-fastest block order

@@ -269,6 +269,7 @@ int g_lin_tile = 2;  // "lin_tile" option: channels per barrier / 16 of the 1x1 
 int g_cpb2 = 0;  // "cpb2" option: kernels with KS <= this stage 32 channels per barrier
 int g_lin_dma = 1;  // "lin_dma" option: 1x1 convs stage their window with global_load_lds (1: 64, 2: 32 channels per barrier)
 int g_conv_pad_lds = 0;  // "conv_pad_lds" option (diagnostics): extra LDS bytes per workgroup
+int g_c64_wide = 1;  // "c64_wide" option: 64 x 256 tile (64 x 64 wave tiles) for the DMA-staged second convs of the C = 64 stage
 int g_conv2_dma = 1;  // "conv2_dma" option: stride-2 valid convs stage their window with global_load_lds
 int g_mfast = 0;  // measured neutral on HuBERT linears (weights are L2/MALL resident either way)
 static int g_cfg32_for_bm[4] = {3, 2, 1, 0};  // BM class 32, 64, 128, 256 -> cfg id
@@ -349,6 +350,7 @@ void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<
 template <int MI, int NI, int WM, int WN, int STRIDE, int SPAN, int CPB = 1, bool DMA = false>
 static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN, NW = WM * WN;
+  if (DMA && STRIDE == 1 && SPAN > 0) a.XW = (BN + (a.KS - 1) * a.dil + 3 + 3) & ~3;  // this tile's own window
   if (DMA && !(STRIDE == 1 && SPAN > 0)) a.XW = (STRIDE == 2) ? 136 : BN;  // rows packed back to back (stride-1 taps keep conv_xw's XW)
   constexpr int CW = 32 * NI + 4;
   a.mt_per_group = (a.M + BM - 1) / BM;
@@ -416,6 +418,7 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
     // input in the EPI_STORE_ACT layout (generator: the second conv of a residual pair): raw LDS-DMA windows
     if (cfg == 0) return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);
     if (cfg == 1) return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);
+    if (cfg == 2 && g_c64_wide) return launch32_t<2, 2, 1, 4, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);  // 64 x 256
     if (cfg == 2) return launch32_t<1, 2, 2, 2, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);
   }
   switch (cfg) {

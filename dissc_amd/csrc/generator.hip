@@ -669,6 +669,7 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "lin_dma") == 0) { g_lin_dma = value; return DISSC_OK; }
   if (strcmp(key, "pos48") == 0) { g_pos48 = value; return DISSC_OK; }
   if (strcmp(key, "pair_dma") == 0) { g_pair_dma = value; return DISSC_OK; }
+  if (strcmp(key, "c64_wide") == 0) { g_c64_wide = value; return DISSC_OK; }
   if (strcmp(key, "conv2_dma") == 0) { g_conv2_dma = value; return DISSC_OK; }
   if (strcmp(key, "mfma32") == 0) { g_use_mfma32 = value; return DISSC_OK; }
   if (strncmp(key, "conv32_cfg_bm", 13) == 0) {
