@@ -92,7 +92,9 @@ def cpu_baseline(synth, sd, code, f0, spkr, budget_s=14.0, max_utts=400):
 class _FakeGenerator:
     """CPU stand-in used only by the DISSC_BENCH_FAKE dry run."""
 
-    def __call__(self, code, f0, spkr):
+    h = {"upsample_rates": [5, 4, 4, 2, 2]}
+
+    def __call__(self, code, f0, spkr, lengths=None):
         return (code.float().mean(1, keepdim=True) + spkr.float()).unsqueeze(2).expand(-1, 1, 320 * code.shape[1]).contiguous()
 
     def flops(self, frames):
@@ -113,10 +115,37 @@ class _FakeEvent:
         return (other.t - self.t) * 1e3
 
 
+def calibrate_len_model(lm, units, frames, spk, iters=4):
+    """Give the SYNTHETIC length predictor (random weights) statistics under which a conversion roughly preserves the
+    duration: sum of predicted frames ~= source frames, as a trained rhythm model does on average (reference
+    infer.py:24-45 keeps the utterance's units and re-times them).  Without this the synthetic checkpoint turns 320 s of
+    input into ~72 s of output and the generator stage does a quarter of a real conversion's work.  Untimed set-up:
+    the raw (de-normalised with mean 0 / std 1) outputs fix the spread, a few fixed-point steps fix the mean against
+    the clamp-at-one-frame rule of the rounding stage."""
+    from dissc_amd import predictors as P
+    vals, _, n = P.dedup(units, frames)
+    lm.norm_mean, lm.norm_std = torch.tensor(0.0), torch.tensor(1.0)
+    raw = lm(vals, spk, lengths=n)
+    valid = torch.arange(raw.shape[1], device=raw.device)[None, :] < n[:, None]
+    r = raw[valid].double()
+    mu, sd = float(r.mean()), float(r.std())
+    want = float(frames.sum()) / float(n.sum())      # mean frames per dedup'd unit of the source
+    target = want
+    for _ in range(iters):
+        std = 0.35 * want / max(sd, 1e-6)
+        lm.norm_mean, lm.norm_std = torch.tensor(target - std * mu, dtype=torch.float32), torch.tensor(std, dtype=torch.float32)
+        tot = P.infer_batch(units, frames, spk, lm, None)["totals"]
+        ratio = float(tot.sum()) / float(frames.sum())
+        target += want * (1.0 - ratio)
+    return ratio
+
+
 def pipeline_leg(synth, dev, g, utts=32, seconds=10.0, iters=5):
     """"also report the full pipeline separately" -- encode -> len / pitch prediction -> resynthesis of
     `utts` x `seconds` s of synthetic audio through the device-resident Converter (dissc_amd/pipeline.py), wall time of
-    the whole call with the input audio already in HBM (like `value`), one converted utterance per input."""
+    the whole call with the input audio already in HBM (like `value`), one converted utterance per input.  The
+    synthetic rhythm model is calibrated to preserve the duration (output_audio_sec ~= input), and a separate profiled
+    pass splits the batch time into stages with HIP events."""
     import time
 
     import numpy as np
@@ -125,16 +154,31 @@ def pipeline_leg(synth, dev, g, utts=32, seconds=10.0, iters=5):
     from dissc_amd.hubert import HubertEncoder
     from dissc_amd.pipeline import Converter
     n = int(seconds * 16000)
-    enc = HubertEncoder(synth.synth_hubert_state_dict(6), synth.synth_kmeans_centers(), 6).to(dev)
+    hsd = synth.synth_hubert_state_dict(6)
+    enc = HubertEncoder(hsd, synth.synth_kmeans_centers(), 6).to(dev)
     lm = P.LenPredictor(100, 108).to(dev)
     lm.load_state_dict(synth.synth_len_state_dict(100, 108))
-    lm.norm_mean, lm.norm_std = synth.synth_len_norm_stats()
-    pm = P.PitchPredictor(100, 108).to(dev)
-    pm.load_state_dict(synth.synth_pitch_state_dict("new", 100, 108))
-    conv = Converter(enc, lm, pm, g)
+    # the pitch model type the reference's conversion scripts use for the VCTK / ESD checkpoints
+    # (scripts/convert_eval.py:82-85); it has no 850-frame positional-encoding limit
+    pm = P.PitchPredictorBase(100, 108).to(dev)
+    pm.load_state_dict(synth.synth_pitch_state_dict("base", 100, 108))
     waves = [torch.from_numpy(synth.synth_waveform(n, seed=i)).to(dev) for i in range(utts)]
+    ns = torch.full((utts,), n, dtype=torch.int32)
+    # Untimed set-up of a REPRESENTATIVE synthetic unit stream: random centroids against a random-weight HuBERT give
+    # degenerate units (whole utterances of one unit), so the codebook is re-drawn from the encoder's own features
+    # (100 seeded frames of these utterances): units then change every few frames like k-means units of speech do.
+    e = enc(torch.stack(waves), n_samples=ns, want_dense=True)
+    dense = e["dense"].reshape(-1, e["dense"].shape[-1])
+    pick = torch.from_numpy(np.random.RandomState(17).choice(dense.shape[0], 100, replace=False)).to(dev)
+    enc = HubertEncoder(hsd, dense.index_select(0, pick).float().cpu(), 6).to(dev)
+    e = enc(torch.stack(waves), n_samples=ns, want_dense=False)
+    spk = torch.full((utts, 1), 6, dtype=torch.int64)
+    ratio = calibrate_len_model(lm, e["units"], e["frames"].to(dev), spk)
+    _, _, n_units = P.dedup(e["units"], e["frames"].to(dev))
+    mean_run = float(e["frames"].sum()) / max(float(n_units.sum()), 1.0)
+    conv = Converter(enc, lm, pm, g)
     out = conv(waves, [6])
-    out_sec = sum(len(w) for w in out.values()) / 16000.0 if isinstance(out, dict) else None
+    out_sec = sum(len(w) for w in out.values()) / 16000.0
     ts = []
     for _ in range(iters):
         torch.cuda.synchronize()
@@ -143,10 +187,117 @@ def pipeline_leg(synth, dev, g, utts=32, seconds=10.0, iters=5):
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     wall = float(np.median(ts))
+    # stage split: HIP events between the stages of separate, profiled calls (median per stage)
+    profs = []
+    for _ in range(iters):
+        conv.profile = {}
+        conv(waves, [6])
+        profs.append(conv.profile)
+    conv.profile = None
+    st = {k: float(np.median([p.get(k, 0.0) for p in profs])) for k in profs[0]}
+    stages = {"encode_ms": round(st.get("encode_ms", 0.0), 2), "predict_ms": round(st.get("predict_ms", 0.0), 2),
+              "generator_ms": round(st.get("generator_ms", 0.0), 2),
+              "host_ms": round(st.get("stage_ms", 0.0) + st.get("pack_d2h_ms", 0.0), 2)}
     return {"workload": f"encode (HuBERT-6L + k-means) -> length / pitch predictors -> HiFi-GAN, {utts} x {seconds:g} s in, "
-                        "1 target speaker, in memory (dissc_amd.pipeline.Converter), input audio resident in HBM",
+                        "1 target speaker, base pitch model, in memory (dissc_amd.pipeline.Converter), input audio resident in "
+                        "HBM; synthetic codebook drawn from the encoder's own features and synthetic rhythm model calibrated "
+                        "to preserve the duration (untimed set-up)",
             "ms_per_batch": round(wall * 1e3, 2), "value": round(utts * seconds / wall, 1),
-            "unit": "input audio-sec/sec", "output_audio_sec": out_sec, "iters": iters}
+            "unit": "input audio-sec/sec", "input_audio_sec": utts * seconds, "output_audio_sec": round(out_sec, 1),
+            "duration_ratio": round(ratio, 3), "mean_frames_per_unit": round(mean_run, 2), "iters": iters,
+            "stages": dict(stages, sum_ms=round(sum(stages.values()), 2),
+                           note="HIP-event spans of a profiled pass; host_ms = padding of the batch on the device + "
+                                "ragged pack + D2H of the waveforms + unpack")}
+
+
+def d2h_leg(g, d_code, d_f0, d_spkr, steps, audio_sec_per_step):
+    """the same step INCLUDING the GPU post-processing and the device-to-host copy of the decoded
+    waveforms (page-locked destination); a second figure, never `value`."""
+    from dissc_amd.generator import wav_postprocess_
+    B, L = d_code.shape[0], d_code.shape[1] * 320
+    n = torch.full((B,), L, dtype=torch.int32, device=d_code.device)
+    host = torch.empty(B, 1, L, dtype=torch.float32, pin_memory=True)
+    for _ in range(2):
+        y = g(code=d_code, f0=d_f0, spkr=d_spkr)
+        wav_postprocess_(y, n)
+        host.copy_(y, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        y = g(code=d_code, f0=d_f0, spkr=d_spkr)
+        wav_postprocess_(y, n)
+        host.copy_(y, non_blocking=True)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"what": "generator + int16-truncate / peak-normalise on the GPU + D2H of the waveforms into page-locked memory, "
+                    "host-synchronised every step", "ms_per_step": round(dt * 1e3, 3),
+            "value": round(audio_sec_per_step / dt, 1), "unit": "audio-sec/sec"}
+
+
+def strong_jobs(synth, n_utts=256, targets=(6, 57, 3, 101), seed=77):
+    """The fixed job list of the strong-scaling figure: 256 ragged utterances of 2-5 s (100-250
+    frames, BASELINE configs[3]/[4] shaped) x 4 target speakers = 1 024 generator jobs, the same list at every N."""
+    rs = np.random.RandomState(seed)
+    jobs = []
+    for u in range(n_utts):
+        T = int(rs.randint(100, 251))
+        code, f0, _, _ = synth.synth_generator_inputs(1, T, seed=7000 + u)
+        for t in targets:
+            jobs.append(dict(code=code[0], f0=f0[0, 0], spkr=int(t)))
+    return jobs
+
+
+def strong_leg(synth, g, dev, rank, world, dist, fake=False, reps=3):
+    """Strong scaling: the fixed 1 024-job list LPT-sharded over the ranks by length, each rank batching its share
+    through the generator + GPU post-processing, ONE all-gather of the ragged exchange buffer, rank 0 unpacking every
+    waveform to the host.  Wall = barrier -> slowest rank done (rank 0's unpack included); per-rank compute times and
+    the load imbalance of the partition are reported next to it."""
+    from dissc_amd import harness
+    post = None
+    if not fake:
+        from dissc_amd.generator import wav_postprocess_ as post
+    jobs = strong_jobs(synth) if not fake else strong_jobs(synth, 16, (6, 57))
+    lengths = [len(j["code"]) for j in jobs]
+    audio_sec = sum(lengths) * 320 / 16000.0
+    best = None
+    for rep in range(reps + 1):  # first pass = warm-up (workspace, staging buffers)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        stats = {}
+        t0 = time.perf_counter()
+        waves = harness.run_resynthesis(g, jobs, rank, world, dev, dist, postprocess=post, stats=stats)
+        torch.cuda.synchronize()
+        t_rank = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        if rank == 0:
+            assert len(waves) == len(jobs) and all(len(waves[j]) == 320 * lengths[j] for j in (0, len(jobs) - 1))
+        rec = torch.tensor([wall, stats["compute_s"], t_rank], dtype=torch.float64, device=dev)
+        if dist is not None:
+            allr = torch.empty(world, 3, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(allr, rec[None])
+        else:
+            allr = rec[None]
+        allr = allr.cpu().numpy()
+        cur = (float(allr[:, 0].max()), allr, stats)
+        if rep > 0 and (best is None or cur[0] < best[0]):
+            best = cur
+    wall, allr, stats = best
+    comp = allr[:, 1]
+    return {"workload": f"{len(jobs)} generator jobs ({len(jobs) // 4 if not fake else len(jobs) // 2} ragged utterances of 2-5 s x "
+                        f"{4 if not fake else 2} targets), the same list at every N, LPT-sharded by length; host batching + H2D + "
+                        "generator + GPU post-processing + ragged pack + all-gather + rank-0 D2H unpack all inside the wall",
+            "scaling": "strong", "jobs": len(jobs), "audio_sec": round(audio_sec, 1),
+            "wall_ms": round(wall * 1e3, 2), "value": round(audio_sec / wall, 1), "unit": "audio-sec/sec",
+            "per_rank_compute_ms": [round(float(c) * 1e3, 2) for c in comp],
+            "compute_imbalance": round(float(comp.max() / comp.mean()), 4),
+            "load_imbalance": round(float(stats["imbalance"]), 4),
+            "exchange": {"collectives": int(stats.get("collectives", 0)), "rounds": int(stats["rounds"]),
+                         "sent_bytes_per_rank": 4 * int(stats["sent_floats"]),
+                         "payload_bytes_this_rank": 4 * int(stats["payload_floats"])},
+            "best_of": reps}
 
 
 def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_sec_per_step, flops_step):
@@ -178,20 +329,40 @@ def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_se
             "max_abs_vs_fp32": float(err.abs().max()), "tolerance_rms": 1e-4}
 
 
+GEN_KERNEL_SOURCES = ("common.h", "conv_epilogue32.h", "conv_host.hip", "conv_mfma.hip", "conv_mfma32.hip",
+                      "gen_misc.hip", "generator.hip", "respair.hip")
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the generator's default-path kernels: what a PMC capture is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in GEN_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "dissc_amd", "csrc", fn), "rb") as f:
+            h.update(fn.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def hbm_traffic(B, T):
     """HBM bytes per step from the latest committed PMC capture of these kernels (profiles/rNN/hbm_traffic.json:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 correction applied,
-    tools/capture_profiles.sh + tools/prof_tables.py); only valid for the shape it was captured on.
-    PMC counters cannot be read from inside the timed run, so this is a committed measurement, named in
-    the output (`traffic_source`)."""
+    tools/capture_profiles.sh + tools/prof_tables.py); only valid for the shape it was captured on AND for the
+    kernel sources it was captured from: the capture stores `kernel_source_hash`, and a capture of other sources
+    is refused (traffic null, the reason in `traffic_source`).  PMC counters cannot be read from inside the
+    timed run, so this is a committed measurement, named in the output."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")), reverse=True):
         try:
             j = json.load(open(path))
-            if (B, T) == (32, 500):
-                return j["bytes_per_step_B32_T500"], os.path.relpath(path, ROOT) + ": " + j.get("kernel_version", "")
         except Exception:
             continue
+        rel = os.path.relpath(path, ROOT)
+        if (B, T) != (32, 500):
+            return None, f"{rel}: captured at B=32 x T=500 only"
+        if j.get("kernel_source_hash") != kernel_source_hash():
+            return None, (f"{rel}: STALE -- captured from kernel sources {j.get('kernel_source_hash')}, "
+                          f"this build is {kernel_source_hash()} (re-run tools/capture_profiles.sh)")
+        return j["bytes_per_step_B32_T500"], rel + ": " + j.get("kernel_version", "")
     return None, None
 
 
@@ -205,6 +376,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-bf16", action="store_true", help="skip the extra split-bf16 leg (N=1 only)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the full-pipeline leg (N=1 only)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (fixed 1 024-job list)")
+    ap.add_argument("--no-d2h", action="store_true", help="skip the D2H-inclusive figure (N=1 only)")
     a = ap.parse_args()
 
     # DISSC_BENCH_FAKE=1: CPU/gloo dry run of the distributed bookkeeping only (tests/test_bench_dist.py);
@@ -226,7 +399,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     dist = None
-    if world > 1:
+    backend = "gloo" if fake else os.environ.get("DISSC_BENCH_BACKEND", "nccl")
+    # DISSC_FORCE_DIST=1: initialise the process group with ONE rank too, so that the collectives of the path run
+    # on RCCL on a one-GPU box (the default N=1 line has no collective and no process group)
+    if world > 1 or os.environ.get("DISSC_FORCE_DIST", "0") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -236,7 +412,6 @@ def main():
             # DISSC_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks
             # (ranks share devices round-robin, gloo stages the device tensors through the host);
             # the driver's runs use the default, RCCL with one GPU per rank.
-            backend = os.environ.get("DISSC_BENCH_BACKEND", "nccl")
             if backend != "nccl":
                 local_rank = local_rank % torch.cuda.device_count()
             torch.cuda.set_device(local_rank)
@@ -246,8 +421,7 @@ def main():
     if n_gpus != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python bench.py --gpus N spawns them itself)")
-    if not fake and world > 1 and os.environ.get("DISSC_BENCH_BACKEND", "nccl") == "nccl" \
-            and torch.cuda.device_count() < world:
+    if not fake and world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
         raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, {torch.cuda.device_count()} visible")
     import synthdata as synth  # deterministic synthetic checkpoints / inputs
     sd = synth.synth_generator_state_dict(seed=0)
@@ -271,17 +445,17 @@ def main():
     d_f0 = torch.from_numpy(f0).to(dev)
     d_spkr = torch.from_numpy(spkr).to(dev)
     hop = 320
-    gathered = torch.empty(world * B, 1, hop * T, device=dev) if world > 1 else None
+    gathered = torch.empty(world * B, 1, hop * T, device=dev) if dist is not None else None
 
     def step():
         y = g(code=d_code, f0=d_f0, spkr=d_spkr)
-        if world > 1:
+        if dist is not None:
             dist.all_gather_into_tensor(gathered, y)  # the path's single RCCL collective
         return y
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -292,7 +466,7 @@ def main():
         ev0.record()
         y = g(code=d_code, f0=d_f0, spkr=d_spkr)
         ev1.record()
-        if world > 1:
+        if dist is not None:
             # The gather of step k runs on RCCL's stream while step k+1's generator kernels run
             # on the compute stream; it is only waited for right before the next gather reuses
             # `gathered` (and after the loop), so all K gathers are inside the timed region.
@@ -303,17 +477,27 @@ def main():
         gen_ms += ev0.elapsed_time(ev1)
     if pending is not None:
         pending[0].wait()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     audio_sec_per_step = world * B * T * hop / 16000.0
     value = audio_sec_per_step * a.steps / dt
+
+    # strong-scaling figure (every rank takes part; rank 0 reports): a fixed ragged job list at every N
+    strong = None
+    if not a.no_strong:
+        try:
+            strong = strong_leg(synth, g, dev, rank, world, dist, fake)
+        except Exception as e:  # noqa: BLE001
+            if dist is not None:
+                raise  # a rank that drops out of a collective must not leave the others waiting
+            strong = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         flops_step = g.flops(B * T)          # algorithmic 2*MAC per rank per step
@@ -328,7 +512,11 @@ def main():
             "config": {"workload": "HiFi-GAN generator only (sr/inference.py generate()), "
                                    f"B={B} x T={T} frames (10 s @16 kHz) per GPU, VCTK hubert100_lut config",
                        "batch_per_gpu": B, "frames": T, "parallelism": f"dp{n_gpus}",
-                       "collective": "1 all_gather of waveforms per step" if world > 1 else "none"},
+                       "collective": (f"1 all_gather_into_tensor ({backend}) of the step's waveforms [B,1,L] per rank and step, "
+                                      "asynchronous, overlapping the next step's kernels; `strong` leg: 1 all_gather_into_tensor of "
+                                      "the ragged exchange buffer per run; bookkeeping outside the timed regions: barrier, "
+                                      "all_reduce(MAX) of the wall time, all_gather of 3 timing doubles")
+                       if dist is not None else "none (no process group at N=1)"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": hbm_traffic(B, T)[0], "traffic_source": hbm_traffic(B, T)[1],
@@ -340,7 +528,14 @@ def main():
             gbps = traffic / kern_s / 1e9
             out["roofline"]["hbm"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                       "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+        if strong is not None:
+            out["strong"] = strong
         # the extra legs never decide whether the headline line gets printed
+        if n_gpus == 1 and not fake and not a.no_d2h:
+            try:
+                out["d2h_inclusive"] = d2h_leg(g, d_code, d_f0, d_spkr, a.steps, audio_sec_per_step)
+            except Exception as e:  # noqa: BLE001
+                out["d2h_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
         if not a.no_split_bf16 and n_gpus == 1 and not fake:
             try:
                 out["split_bf16"] = split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y, a.steps,
@@ -359,7 +554,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

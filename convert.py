@@ -17,7 +17,9 @@ sample for sample (tests/test_gpu_pipeline.py).  The file-based scripts remain f
 Multi-GPU (BASELINE.json configs[3], [4]): launch with ``python -m torch.distributed.run
 --nproc-per-node N convert.py ...``; utterances are LPT-sharded over the ranks by length, every
 rank runs encode -> predict -> resynthesise for its share, and rank 0 receives every waveform
-through ONE all-gather (dissc_amd/pipeline.py, dissc_amd/harness.py) and writes the files.
+through ONE all-gather per round (dissc_amd/pipeline.py, dissc_amd/harness.py) and writes the files; a run is a
+single round unless a rank's share exceeds --round_seconds.  ``DISSC_FORCE_DIST=1`` runs the collectives on RCCL
+with a single rank too.
 """
 import argparse
 import json
@@ -61,27 +63,16 @@ def build_parser():
     ap.add_argument("--id_to_spkr", required=True, help="pickled speaker list (index = id)")
     ap.add_argument("--target_speakers", nargs="+", required=True)
     ap.add_argument("--no_pred_len", action="store_true", help="keep the source rhythm (infer.py without --pred_len)")
+    ap.add_argument("--round_seconds", default=16384.0, type=float,
+                    help="input audio x targets per rank and round: each round is gathered, written and freed "
+                         "(one round = one all-gather; the default holds 1 GiB of waveforms per rank)")
     return ap
 
 
 def main(argv=None):
     a = build_parser().parse_args(argv)
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29513")
-        # DISSC_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks share devices
-        # round-robin, tensors staged through the host); the default is RCCL with one GPU per rank
-        backend = os.environ.get("DISSC_DIST_BACKEND", "nccl")
-        if backend != "nccl":
-            local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
-        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    from dissc_amd import harness
+    rank, local_rank, world, dist = harness.init_distributed(29513)
     device = torch.device("cuda", local_rank)
 
     from encode import load_wav
@@ -132,15 +123,35 @@ def main(argv=None):
             raise ValueError(f"{files[i]}: sample rate {sr}, expected 16000 (run data/preprocess.py first)")
         return x
 
-    conv = Converter(enc.model, len_model, pitch_model, generator, norm_pitch=True, n_tokens=a.n_tokens)
-    out = conv.run_sharded(n_samples, load, targets, rank, world, dist)
+    # the vocoder data set's F0 normalisation by the SOURCE speaker's statistics (reference sr/dataset.py:255-267,
+    # sr/inference.py build_jobs here): the shipped configs set f0_normalize with f0_stats, and the chain applies it
+    # to whatever F0 the manifest holds -- so does this entry
+    f0_stats = None
+    if h.get("f0_normalize", False) and h.get("f0_stats", None):
+        import pickle
+        with open(h["f0_stats"], "rb") as f:
+            st = pickle.load(f)
+        pairs = []
+        for fn in files:
+            e = st.get(formats.speaker_of(fn), None)
+            pairs.append((e["mean"], e["std"]) if e is not None else (st["f0_mean"], st["f0_std"]))
+        f0_stats = (np.array([p[0] for p in pairs], np.float64), np.array([p[1] for p in pairs], np.float64))
+
+    conv = Converter(enc.model, len_model, pitch_model, generator, norm_pitch=True, n_tokens=a.n_tokens,
+                     f0_median=bool(h.get("f0_median", False)))
     if rank == 0:
         os.makedirs(a.output_dir, exist_ok=True)
-        for (i, t), w in sorted(out.items()):
+
+    def write(waves):  # rank 0, once per round: files are on disk before the next round starts
+        for (i, t), w in sorted(waves.items()):
             wavfile.write(os.path.join(a.output_dir, f"{os.path.splitext(files[i])[0]}_{t}_gen.wav"),
                           h.sampling_rate, w)
-        print(f"{len(out)} waveforms written to {a.output_dir}")
-    if world > 1:
+
+    n = conv.run_sharded(n_samples, load, targets, rank, world, dist, f0_stats=f0_stats, sink=write,
+                         round_floats=int(a.round_seconds * 16000))
+    if rank == 0:
+        print(f"{n} waveforms written to {a.output_dir}")
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

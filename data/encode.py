@@ -102,30 +102,41 @@ def main(argv=None):
             continue
         lengths[f] = n
     order = sorted(lengths, key=lambda f: (-lengths[f], f))
-    # Lines are appended per batch (a failure keeps what was already encoded, like the reference's
-    # per-file append), i.e. in length-sorted order rather than listdir order -- the file is a set of
-    # independent lines keyed by 'audio' for every consumer.
+    # Batches run longest first, but the manifest keeps the reference's line order (os.listdir order, one line per
+    # file: data/encode.py:24-41 there) -- positional consumers (`infer.py -n N`, data_split) must see the same
+    # subset.  Finished batches are appended to `<out_file>.partial` as they complete (a failure keeps what was
+    # already encoded, like the reference's per-file append); the ordered lines are appended to out_file at the end.
+    partial = str(args.out_file) + '.partial'
+    lines = {}
     i = 0
     while i < len(order):
         n0 = lengths[order[i]]
         bsz = max(1, int(args.batch_seconds * 16000 // n0))
         batch = order[i:i + bsz]
         i += len(batch)
-        wav = np.zeros((len(batch), n0), dtype=np.float32)
-        ns = np.zeros(len(batch), dtype=np.int32)
-        for k, f in enumerate(batch):
-            x, sr = load_wav(os.path.join(args.base_dir, f))
+        xs = [load_wav(os.path.join(args.base_dir, f))[0] for f in batch]
+        ns = np.array([len(x) for x in xs], dtype=np.int32)
+        # rows are sized from the DECODED lengths: a header that disagrees with its data must not break the batch
+        wav = np.zeros((len(batch), int(ns.max())), dtype=np.float32)
+        for k, x in enumerate(xs):
             wav[k, :len(x)] = x
-            ns[k] = len(x)
+        del xs
         out = encoder.model(torch.from_numpy(wav), n_samples=torch.from_numpy(ns), want_dense=False)
         units = out["units"].cpu()
         f0s = track_f0(wav, ns, [int(t) for t in out["frames"]], args) if args.f0 == 'yaapt' else None
-        with open(args.out_file, 'a+') as fo:
+        with open(partial, 'a+') as fo:
             for k, f in enumerate(batch):
                 T = int(out["frames"][k])
                 u = units[k, :T].tolist()
                 f0 = f0s[k] if f0s is not None else [0.0] * T
-                fo.write(json.dumps({"units": u, "f0": f0, "durations": [1] * T, "audio": f}) + "\n")
+                lines[f] = json.dumps({"units": u, "f0": f0, "durations": [1] * T, "audio": f}) + "\n"
+                fo.write(lines[f])
+    with open(args.out_file, 'a+') as fo:
+        for f in files:
+            if f in lines:
+                fo.write(lines[f])
+    if os.path.exists(partial):
+        os.remove(partial)
 
 
 if __name__ == '__main__':

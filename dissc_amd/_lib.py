@@ -97,8 +97,7 @@ def _load():
     L.dissc_wav_postprocess.argtypes = [vp, vp, i32, i32, vp]
     L.dissc_pitch_stats.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     i64 = ctypes.c_longlong
-    L.dissc_pack_waves.argtypes = [vp, i64, vp, vp, i32, vp, i64, i32, vp]
-    L.dissc_pack_empty_rows.argtypes = [vp, i64, i32, i32, vp]
+    L.dissc_pack_rows.argtypes = [vp, i64, vp, vp, i32, i32, vp, vp]
     L.dissc_resample.argtypes = [vp, i32, vp, i32, ctypes.c_double, vp, vp, i32, i32, vp]
     return L
 

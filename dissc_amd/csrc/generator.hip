@@ -121,7 +121,7 @@ static inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; 
 extern "C" {
 
 const char* dissc_last_error(void) { return g_err; }
-int dissc_abi_version(void) { return 2; }
+int dissc_abi_version(void) { return 3; }
 
 int dissc_device_count(void) {
   int n = 0;

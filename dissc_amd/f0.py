@@ -187,11 +187,14 @@ def final_track(pitch, merit, energy, p):
 
 
 def f0_per_unit(f0_frames, n_units, ratio=4):
-    """textless' alignment of the 5 ms track to 20 ms units [3P-unverified]: unit i = frames [4i, 4i+4), mean of
-    the voiced values, 0.0 when there is none"""
+    """textless' alignment of the 5 ms track to 20 ms units (align_f0_to_durations [3P-unverified]): the track is cut
+    to ratio * n_units frames or, when shorter, extended with its LAST value (not with zeros: the last unit keeps
+    the voicing of the track's end); unit i = frames [4i, 4i+4), mean of the voiced values, 0.0 when there is none"""
     f = np.zeros(n_units * ratio, dtype=np.float64)
     m = min(len(f0_frames), len(f))
     f[:m] = np.asarray(f0_frames[:m], dtype=np.float64)
+    if 0 < m < len(f):
+        f[m:] = f[m - 1]
     f = f.reshape(n_units, ratio)
     cnt = (f != 0).sum(1)
     return np.where(cnt > 0, f.sum(1) / np.maximum(cnt, 1), 0.0)

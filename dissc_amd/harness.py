@@ -1,22 +1,31 @@
 """Data-parallel harness: shard jobs over ranks, batch them, and return every waveform to rank 0
-with ONE all-gather.
+with ONE all-gather per round.
 
 Replaces the reference's ``multiprocessing.Pool(8)`` of B=1 workers writing their own files
 (reference sr/inference.py:288-292,351-354): one process per GPU (torchrun env), each rank
 batches its share through ``dissc_amd.CodeGenerator`` and the decoded waveforms of all ranks are
-exchanged with a single ``all_gather_into_tensor`` of a packed ``[n_max, 4 + L_max]`` fp32 buffer
-(row = [job id | sample count | 0 | 0] as int32 bit patterns, then the samples; layout and the
-pack kernel: include/dissc_hip.h ``dissc_pack_waves``).  Utterances are independent, so there is
-no other collective on the data path.  The buffer is packed on the device by one kernel launch per
-generator batch; only the ranks that consume the result (rank 0 by default) copy it to the host.
+exchanged with a single ``all_gather_into_tensor`` of a packed RAGGED fp32 buffer (header + row table
++ rows back to back, each padded to 16 bytes only; layout and the pack kernel: include/dissc_hip.h
+``dissc_pack_rows``).  Utterances are independent, so there is no other collective on the data path.
+
+A run is ONE round -- one all-gather -- unless a rank's share exceeds ``round_floats`` (default 2^28
+floats = 1 GiB = 4.6 hours of 16 kHz audio per rank): then every rank cuts its share into the same number
+of rounds, and each round is packed, gathered, handed to ``sink`` (rank 0 writes the files) and FREED before
+the next one starts, so the resident footprint is bounded by the round and a failure loses one round at most.
 
 Everything here is host logic; it runs on CPU tensors with the gloo backend in the tests (there the
-rows are packed with torch copies) and on CUDA tensors over RCCL/xGMI in production.
+rows are packed with torch copies) and on CUDA tensors over RCCL/xGMI in production.  A non-None ``dist``
+means "a process group exists": the collective then runs at ANY world size (world_size 1 included --
+``DISSC_FORCE_DIST=1`` in the CLIs -- which is how RCCL is exercised on a one-GPU box).
 """
+import os
+
 import numpy as np
 import torch
 
-HDR = 4  # header floats per packed row (16 B: keeps the samples 16-byte aligned)
+HDR = 4               # header floats (16 B)
+ENT = 4               # table floats per row (16 B): job id, sample count, offset lo, offset hi
+ROUND_FLOATS = 1 << 28
 
 
 def lpt_shard(lengths, world_size):
@@ -31,6 +40,13 @@ def lpt_shard(lengths, world_size):
         parts[r].append(i)
         load[r] += int(lengths[i])
     return parts
+
+
+def imbalance(lengths, parts):
+    """max / mean of the per-rank loads of a partition (1.0 = perfectly even)."""
+    loads = [sum(int(lengths[i]) for i in p) for p in parts]
+    mean = sum(loads) / max(len(loads), 1)
+    return max(loads) / mean if mean > 0 else 1.0
 
 
 def make_batches(job_ids, lengths, max_batch=32, max_frames=32 * 500):
@@ -49,73 +65,126 @@ def make_batches(job_ids, lengths, max_batch=32, max_frames=32 * 500):
     return batches
 
 
+def plan_rounds(lengths, parts, budget=None):
+    """Cut every rank's share (longest first) into rounds of at most ``budget`` length units (a round
+    always takes at least one job).  Every rank derives the same plan; the number of rounds is the
+    maximum over ranks (a rank that runs out contributes empty rounds, it still joins the collectives).
+    Returns list[round] of list[world_size] of job-index lists.  ``budget`` None = one round."""
+    per_rank = []
+    for p in parts:
+        ids = sorted(p, key=lambda i: (-int(lengths[i]), i))
+        if budget is None:
+            per_rank.append([ids])
+            continue
+        rounds, cur, tot = [], [], 0
+        for i in ids:
+            n = int(lengths[i])
+            if cur and tot + n > budget:
+                rounds.append(cur)
+                cur, tot = [], 0
+            cur.append(i)
+            tot += n
+        rounds.append(cur)
+        per_rank.append(rounds)
+    n_rounds = max((len(r) for r in per_rank), default=1)
+    return [[r[k] if k < len(r) else [] for r in per_rank] for k in range(n_rounds)]
+
+
+def _r4(n):
+    return (int(n) + 3) // 4 * 4
+
+
 def pack_geometry(lengths, parts, hop):
-    """(n_max, L_max) of the packed exchange buffer -- derived from the global job list, so
-    all ranks agree without a collective."""
-    n_max = max((len(p) for p in parts), default=0)
-    l_max = max((int(x) for x in lengths), default=0) * hop
-    return n_max, l_max
+    """(n_cap, data_cap) of the exchange buffer -- the most rows and the most (16-byte padded) data floats
+    any rank packs; derived from the global job list, so all ranks agree without a collective."""
+    n_cap = max((len(p) for p in parts), default=0)
+    data_cap = max((sum(_r4(int(lengths[i]) * hop) for i in p) for p in parts), default=0)
+    return n_cap, data_cap
 
 
-def row_floats(l_max):
-    return HDR + (int(l_max) + 3) // 4 * 4
+def buffer_floats(n_cap, data_cap):
+    return HDR + ENT * int(n_cap) + int(data_cap)
 
 
 class WaveStore:
     """The decoded waveforms of one rank, kept on the device as the generator produced them:
-    a list of batches (wav [B, ld], n_samples i32 [B], job ids i32 [B])."""
+    a list of batches (wav [B, ld], sample counts, job ids).  Sample counts live on the HOST (both
+    callers know them without a sync): the row offsets of the ragged pack are their prefix sum."""
 
     def __init__(self, device):
         self.device = torch.device(device)
         self.batches = []
         self.n = 0
+        self.data_floats = 0  # sum of the 16-byte padded sample counts
 
     def add(self, wav, n_samples, job_ids):
-        """wav f32 [B,1,L] or [B,L]; n_samples int [B] (host or device); job_ids: ints [B]"""
+        """wav f32 [B,1,L] or [B,L]; n_samples int [B] (host preferred; a device tensor costs a sync);
+        job_ids: ints [B]"""
         w2 = wav.view(wav.shape[0], -1)
-        ns = torch.as_tensor(n_samples).to(self.device, torch.int32).contiguous()
-        ids = torch.as_tensor(np.asarray(job_ids, dtype=np.int32)).to(self.device)
-        assert ns.numel() == w2.shape[0] == ids.numel()
+        if torch.is_tensor(n_samples):
+            n_samples = n_samples.cpu().numpy()
+        ns = np.minimum(np.asarray(n_samples, dtype=np.int64).reshape(-1), w2.shape[1]).astype(np.int32)
+        ids = np.asarray(job_ids, dtype=np.int32).reshape(-1)
+        assert ns.size == w2.shape[0] == ids.size
         self.batches.append((w2, ns, ids))
         self.n += w2.shape[0]
+        self.data_floats += int(((ns.astype(np.int64) + 3) // 4 * 4).sum())
 
     def add_empty(self, job_ids):
         k = len(job_ids)
         if k:
             self.add(torch.zeros(k, 4, dtype=torch.float32, device=self.device), np.zeros(k, np.int32), job_ids)
 
-    def pack(self, n_max, l_max):
-        """-> f32 [n_max, 4 + l_max (rounded up to 4)] on the device."""
-        if self.n > n_max:
-            raise ValueError(f"{self.n} waveforms do not fit {n_max} rows")
-        ld = row_floats(l_max)
-        buf = torch.empty(max(n_max, 1), ld, dtype=torch.float32, device=self.device)[:n_max]
-        row = 0
+    def clear(self):
+        self.batches, self.n, self.data_floats = [], 0, 0
+
+    def pack(self, n_cap, data_cap):
+        """-> f32 [4 + 4*n_cap + data_cap] on the device (layout: include/dissc_hip.h)."""
+        if self.n > n_cap or self.data_floats > data_cap:
+            raise ValueError(f"{self.n} waveforms / {self.data_floats} floats do not fit "
+                             f"{n_cap} rows / {data_cap} floats")
+        ns = np.concatenate([b[1] for b in self.batches]) if self.batches else np.zeros(0, np.int32)
+        ids = np.concatenate([b[2] for b in self.batches]) if self.batches else np.zeros(0, np.int32)
+        slots = (ns.astype(np.int64) + 3) // 4 * 4
+        offs = np.cumsum(slots) - slots
+        head = np.zeros((1 + n_cap, 4), dtype=np.int32)
+        head[0, 0] = self.n
+        head[0, 2:4] = np.array([self.data_floats], dtype=np.int64).view(np.int32)
+        head[1:, 0] = -1
+        head[1:1 + self.n, 0] = ids
+        head[1:1 + self.n, 1] = ns
+        head[1:1 + self.n, 2:4] = offs.astype(np.int64).view(np.int32).reshape(-1, 2)
+        tbl = HDR + ENT * n_cap
+        buf = torch.empty(buffer_floats(n_cap, data_cap), dtype=torch.float32, device=self.device)
+        buf[:tbl].copy_(torch.from_numpy(head.reshape(-1)).view(torch.float32))
         if self.device.type == "cuda":
             from ._lib import check, current_stream_ptr, lib
+            d_ns = torch.from_numpy(ns).to(self.device)
+            d_off = torch.from_numpy(offs.astype(np.int64)).to(self.device)
+            data = buf[tbl:]
+            assert data.data_ptr() % 16 == 0
             with torch.cuda.device(self.device):
                 st = current_stream_ptr(self.device)
-                for w2, ns, ids in self.batches:
-                    check(lib.dissc_pack_waves(w2.data_ptr(), w2.stride(0), ns.data_ptr(), ids.data_ptr(),
-                                               w2.shape[0], buf.data_ptr(), ld, row, st), "dissc_pack_waves")
-                    row += w2.shape[0]
-                check(lib.dissc_pack_empty_rows(buf.data_ptr(), ld, row, n_max - row, st), "dissc_pack_empty_rows")
+                row = 0
+                for w2, bns, _ in self.batches:
+                    B = w2.shape[0]
+                    check(lib.dissc_pack_rows(w2.data_ptr(), w2.stride(0), d_ns[row:].data_ptr(),
+                                              d_off[row:].data_ptr(), B, int(bns.max()) if B else 0,
+                                              data.data_ptr(), st), "dissc_pack_rows")
+                    row += B
         else:  # gloo/CPU rehearsal of the same layout (tests)
-            buf.zero_()
-            hdr = buf.view(torch.int32)
-            hdr[:, 0] = -1
-            for w2, ns, ids in self.batches:
+            buf[tbl:].zero_()
+            row = 0
+            for w2, bns, _ in self.batches:
                 for k in range(w2.shape[0]):
-                    n = min(int(ns[k]), ld - HDR)
-                    hdr[row, 0] = int(ids[k])
-                    hdr[row, 1] = n
-                    buf[row, HDR:HDR + n] = w2[k, :n]
+                    o, n = tbl + int(offs[row]), int(bns[k])
+                    buf[o:o + n] = w2[k, :n]
                     row += 1
         return buf
 
 
-def pack_waves(waves, job_ids, n_max, l_max, device):
-    """waves: list of 1-D float tensors; -> packed f32 [n_max, 4 + l_max] (one row per waveform)."""
+def pack_waves(waves, job_ids, n_cap, data_cap, device):
+    """waves: list of 1-D float tensors; -> packed exchange buffer of one rank."""
     st = WaveStore(device)
     for w, j in zip(waves, job_ids):
         w = w.reshape(1, -1).to(st.device, torch.float32)
@@ -124,124 +193,215 @@ def pack_waves(waves, job_ids, n_max, l_max, device):
             st.add_empty([j])
         else:
             st.add(w.contiguous(), [n], [j])
-    return st.pack(n_max, l_max)
+    return st.pack(n_cap, data_cap)
 
 
 _PIN = {"buf": None}
-_PIN_MAX_BYTES = 64 << 20  # page-locking costs ~0.2 ms per MB once; larger buffers go through in chunks
+_PIN_MAX_FLOATS = (64 << 20) // 4  # page-locking costs ~0.2 ms per MB once; larger buffers go through in chunks
 
 
-def _pinned_rows(n_floats_per_row, rows):
-    """page-locked staging rows (cached: page-locking costs more than the copy itself), at most 64 MB"""
-    cap = max(1, min(rows, _PIN_MAX_BYTES // (4 * n_floats_per_row)))
-    need = cap * n_floats_per_row
+def _pinned(n_floats):
+    """page-locked staging (cached: page-locking costs more than the copy itself), at most 64 MB"""
+    need = max(1, min(int(n_floats), _PIN_MAX_FLOATS))
     if _PIN["buf"] is None or _PIN["buf"].numel() < need:
         _PIN["buf"] = None
         _PIN["buf"] = torch.empty(need, dtype=torch.float32, pin_memory=True)
-    return _PIN["buf"][:need].view(cap, n_floats_per_row), cap
+    return _PIN["buf"][:need]
 
 
-def unpack_waves(gathered, copy=False):
-    """packed f32 [rows, 4+l_max] (any device) -> {job_id: 1-D float32 numpy array}.  A device buffer comes over in
-    ONE device-to-host copy into a cached page-locked staging buffer (chunks of <= 64 MB for large sweeps; a
-    pageable ``.cpu()`` of the 20 MB of a 32-utterance batch takes 1.7 ms, this 0.7 ms), and every job's valid
-    samples are copied out of it into an array of their own.  A host buffer is viewed in place unless ``copy``."""
-    out = {}
-    if gathered.is_cuda:
-        rows, width = gathered.shape
-        stage, cap = _pinned_rows(width, rows)
-        for r0 in range(0, rows, cap):
-            n = min(cap, rows - r0)
-            stage[:n].copy_(gathered[r0:r0 + n], non_blocking=True)
-            torch.cuda.current_stream(gathered.device).synchronize()
-            g = stage[:n].numpy()
-            hdr = g.view(np.int32)[:, :2]
-            for r in np.flatnonzero(hdr[:, 0] >= 0):
-                out[int(hdr[r, 0])] = g[r, HDR:HDR + hdr[r, 1]].copy()
-        return out
-    g = gathered.numpy()
-    hdr = g.view(np.int32)[:, :2]
-    for r in np.flatnonzero(hdr[:, 0] >= 0):
-        w = g[r, HDR:HDR + hdr[r, 1]]
-        out[int(hdr[r, 0])] = w.copy() if copy else w
+def _to_host(t):
+    """1-D device f32 tensor -> numpy copy, through the cached page-locked staging buffer in <= 64 MB chunks
+    (a pageable ``.cpu()`` of the 20 MB of a 32-utterance batch takes 1.7 ms, this 0.7 ms)."""
+    n = t.numel()
+    out = np.empty(n, dtype=np.float32)
+    stage = _pinned(n)
+    cap = stage.numel()
+    for o in range(0, n, cap):
+        k = min(cap, n - o)
+        stage[:k].copy_(t[o:o + k], non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        out[o:o + k] = stage[:k].numpy()
     return out
 
 
-def gather_store(store, n_max, l_max, rank, world_size, dist=None, unpack_ranks=(0,)):
-    """The single collective of the path.  Returns {job_id: samples} on the ranks in ``unpack_ranks``
-    (None = every rank), {} elsewhere -- only the consumers pay the device-to-host copy."""
-    buf = store.pack(n_max, l_max)
-    if world_size > 1:
-        out = torch.empty(world_size * n_max, buf.shape[1], dtype=torch.float32, device=buf.device)
+def unpack_waves(gathered, n_cap, copy=False, stats=None):
+    """gathered: f32 [world * (4 + 4*n_cap + data_cap)] or [world, ...] (any device) -> {job_id: 1-D float32
+    numpy array}.  From a device buffer only what the tables say is in use comes over: the world headers +
+    tables first (a few KB), then each rank's used data region through the page-locked staging buffer.
+    A host buffer is viewed in place unless ``copy``."""
+    tbl = HDR + ENT * n_cap
+    g = gathered.reshape(-1)
+    per = None
+    out = {}
+    # the buffer length per rank is not stored: recover it from the caller's shape when 2-D, else it is one rank
+    if gathered.dim() == 2:
+        world, per = gathered.shape
+    else:
+        world, per = 1, g.numel()
+    if per < tbl:
+        raise ValueError("exchange buffer shorter than its table")
+    g2 = g.view(world, per)
+    heads = g2[:, :tbl]
+    heads = (heads.cpu() if heads.is_cuda else heads).contiguous().numpy().view(np.int32).reshape(world, 1 + n_cap, 4)
+    moved = 0
+    for r in range(world):
+        n_rows = int(heads[r, 0, 0])
+        used = int(heads[r, 0, 2:4].copy().view(np.int64)[0])
+        if n_rows < 0 or n_rows > n_cap or used < 0 or used > per - tbl:
+            raise ValueError(f"rank {r}: corrupt exchange header (rows {n_rows}, data floats {used})")
+        if n_rows == 0:
+            continue
+        if g2.is_cuda:
+            data = _to_host(g2[r, tbl:tbl + used])
+            moved += used
+            own = True
+        else:
+            data = g2[r, tbl:tbl + used].numpy()
+            own = False
+        ent = heads[r, 1:1 + n_rows]
+        offs = ent[:, 2:4].copy().view(np.int64).reshape(-1)
+        for k in range(n_rows):
+            w = data[int(offs[k]):int(offs[k]) + int(ent[k, 1])]
+            out[int(ent[k, 0])] = w.copy() if (copy and not own) else w
+    if stats is not None:
+        stats["d2h_floats"] = stats.get("d2h_floats", 0) + moved + (world * tbl if g2.is_cuda else 0)
+    return out
+
+
+def gather_store(store, n_cap, data_cap, rank, world_size, dist=None, unpack_ranks=(0,), stats=None):
+    """The single collective of a round.  Returns {job_id: samples} on the ranks in ``unpack_ranks``
+    (None = every rank), {} elsewhere -- only the consumers pay the device-to-host copy.  The collective
+    runs whenever a process group is given (``dist`` not None), also at world_size 1."""
+    buf = store.pack(n_cap, data_cap)
+    if stats is not None:
+        stats["payload_floats"] = stats.get("payload_floats", 0) + sum(int(b[1].sum()) for b in store.batches)
+        stats["sent_floats"] = stats.get("sent_floats", 0) + buf.numel()
+        stats["collectives"] = stats.get("collectives", 0) + (1 if dist is not None else 0)
+    if dist is not None:
+        out = torch.empty(world_size * buf.numel(), dtype=torch.float32, device=buf.device)
         dist.all_gather_into_tensor(out, buf)
-        buf = out
+        buf = out.view(world_size, -1)
+    else:
+        buf = buf.view(1, -1)
     if unpack_ranks is not None and rank not in unpack_ranks:
         return {}
-    return unpack_waves(buf)
+    return unpack_waves(buf, n_cap, stats=stats)
 
 
 def gather_waves(local_waves, local_ids, lengths, parts, hop, rank, world_size, device, dist=None,
                  unpack_ranks=None):
     """List-of-tensors front end of gather_store (geometry from the global job list)."""
-    n_max, l_max = pack_geometry(lengths, parts, hop)
+    n_cap, data_cap = pack_geometry(lengths, parts, hop)
     st = WaveStore(device)
     for w, j in zip(local_waves, local_ids):
         if w.numel() == 0:
             st.add_empty([j])
         else:
             st.add(w.reshape(1, -1).contiguous(), [w.numel()], [j])
-    return gather_store(st, n_max, l_max, rank, world_size, dist, unpack_ranks)
+    return gather_store(st, n_cap, data_cap, rank, world_size, dist, unpack_ranks)
 
 
-def agree_geometry(n_local, l_local, world_size, device, dist=None):
-    """(n_max, l_max) over ranks when they cannot be derived from the job list (predicted durations
+def agree_geometry(n_local, data_local, world_size, device, dist=None):
+    """(n_cap, data_cap) over ranks when they cannot be derived from the job list (predicted durations
     decide the output lengths): one 16-byte MAX all-reduce ahead of the waveform all-gather."""
-    if world_size == 1:
-        return int(n_local), int(l_local)
-    t = torch.tensor([int(n_local), int(l_local)], dtype=torch.int64, device=device)
+    if dist is None:
+        return int(n_local), int(data_local)
+    t = torch.tensor([int(n_local), int(data_local)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t = t.cpu()
     return int(t[0]), int(t[1])
 
 
+def init_distributed(default_port, backend_env="DISSC_DIST_BACKEND"):
+    """Process-group set-up shared by the CLIs (sr/inference.py, convert.py): one process per GPU from the
+    torchrun environment.  Returns (rank, local_rank, world_size, dist-or-None).
+
+    * WORLD_SIZE > 1: RCCL (backend "nccl") with one GPU per rank; ``DISSC_DIST_BACKEND=gloo`` is the rehearsal
+      mode for a box with fewer GPUs than ranks (ranks share devices round-robin, tensors staged through the host).
+    * WORLD_SIZE == 1: no process group -- unless ``DISSC_FORCE_DIST=1``, which initialises the same backend with
+      one rank so that the collectives of the path run on the one GPU that is there."""
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world == 1 and os.environ.get("DISSC_FORCE_DIST", "0") != "1":
+        return rank, local_rank, world, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(default_port))
+    backend = os.environ.get(backend_env, "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
+    elif torch.cuda.device_count() <= local_rank:
+        raise RuntimeError(f"rank {rank}: local rank {local_rank} but {torch.cuda.device_count()} GPUs visible "
+                           f"(one GPU per rank; {backend_env}=gloo shares devices for rehearsals)")
+    torch.cuda.set_device(local_rank)
+    kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world, dist
+
+
 def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist=None, max_batch=32,
-                    max_frames=32 * 500, postprocess=None, unpack_ranks=(0,)):
+                    max_frames=32 * 500, postprocess=None, unpack_ranks=(0,), sink=None,
+                    round_floats=ROUND_FLOATS, stats=None):
     """jobs: list of dicts {code: int array [T], f0: float array [T], spkr: int}.
-    Every rank runs its LPT share in length-bucketed batches; returns {job_id: float32 samples}
-    after the all-gather (on ``unpack_ranks``; None = all).  ``postprocess(wav[B,1,L], n_samples[B])``
-    runs on the GPU in place."""
+    Every rank runs its LPT share in length-bucketed batches, one all-gather per round (one round unless a
+    rank's share exceeds ``round_floats`` output samples).  Returns {job_id: float32 samples} (on
+    ``unpack_ranks``; None = all) -- or, with ``sink``, calls ``sink({job_id: samples})`` once per round on
+    those ranks and returns the number of waveforms delivered (nothing is retained between rounds).
+    ``postprocess(wav[B,1,L], n_samples[B])`` runs on the GPU in place.  ``stats`` (a dict) is filled with
+    per-rank timing and traffic figures."""
+    import time
     lengths = [len(j["code"]) for j in jobs]
     for j, job in enumerate(jobs):
         if len(job["f0"]) != lengths[j]:
             raise ValueError(f"job {j}: {lengths[j]} units but {len(job['f0'])} f0 values")
     parts = lpt_shard(lengths, world_size)
-    mine = parts[rank]
     hop = int(np.prod(generator.h["upsample_rates"]))  # same on every rank, even one with no jobs
-    store = WaveStore(device)
-    for batch in make_batches(mine, lengths, max_batch, max_frames):
-        B = len(batch)
-        T = max(lengths[i] for i in batch)
-        if T == 0:
-            # empty `units` lines: empty waveforms (the generator rejects T = 0).  Never abort one rank
-            # here -- the others would wait in the all-gather forever.
-            store.add_empty(batch)
-            continue
-        code = np.zeros((B, T), dtype=np.int64)
-        f0 = np.zeros((B, 1, T), dtype=np.float32)
-        spkr = np.zeros((B, 1), dtype=np.int64)
-        lens = np.zeros(B, dtype=np.int32)
-        for k, i in enumerate(batch):
-            n = lengths[i]
-            code[k, :n] = jobs[i]["code"]
-            f0[k, 0, :n] = jobs[i]["f0"]
-            spkr[k, 0] = jobs[i]["spkr"]
-            lens[k] = n
-        y = generator(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
-                      lengths=torch.from_numpy(lens))
-        assert y.shape[-1] == hop * T
-        ns = torch.from_numpy(lens * hop).to(store.device)
-        if postprocess is not None:
-            postprocess(y, ns)
-        store.add(y, ns, batch)
-    n_max, l_max = pack_geometry(lengths, parts, hop)
-    return gather_store(store, n_max, l_max, rank, world_size, dist, unpack_ranks)
+    dev = torch.device(device)
+    result, delivered = {}, 0
+    t_compute = 0.0
+    rounds = plan_rounds(lengths, parts, None if round_floats is None else max(1, round_floats // hop))
+    for shares in rounds:
+        t0 = time.perf_counter()
+        store = WaveStore(dev)
+        for batch in make_batches(shares[rank], lengths, max_batch, max_frames):
+            B = len(batch)
+            T = max(lengths[i] for i in batch)
+            if T == 0:
+                # empty `units` lines: empty waveforms (the generator rejects T = 0).  Never abort one rank
+                # here -- the others would wait in the all-gather forever.
+                store.add_empty(batch)
+                continue
+            code = np.zeros((B, T), dtype=np.int64)
+            f0 = np.zeros((B, 1, T), dtype=np.float32)
+            spkr = np.zeros((B, 1), dtype=np.int64)
+            lens = np.zeros(B, dtype=np.int32)
+            for k, i in enumerate(batch):
+                n = lengths[i]
+                code[k, :n] = jobs[i]["code"]
+                f0[k, 0, :n] = jobs[i]["f0"]
+                spkr[k, 0] = jobs[i]["spkr"]
+                lens[k] = n
+            y = generator(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
+                          lengths=torch.from_numpy(lens))
+            assert y.shape[-1] == hop * T
+            if postprocess is not None:
+                postprocess(y, torch.from_numpy(lens * hop).to(dev))
+            store.add(y, lens * hop, batch)
+        if stats is not None and dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        t_compute += time.perf_counter() - t0
+        n_cap, data_cap = pack_geometry(lengths, shares, hop)
+        got = gather_store(store, n_cap, data_cap, rank, world_size, dist, unpack_ranks, stats)
+        store.clear()
+        if sink is not None:
+            if got:
+                sink(got)
+            delivered += len(got)
+        else:
+            result.update(got)
+    if stats is not None:
+        stats["compute_s"] = t_compute
+        stats["imbalance"] = imbalance(lengths, parts)
+        stats["rounds"] = len(rounds)
+    return delivered if sink is not None else result

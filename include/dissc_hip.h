@@ -253,18 +253,22 @@ int dissc_pipe_overlap(int mfma_iters, int valu_iters, float* ms);
 int dissc_wav_postprocess(float* wav, const int32_t* n_samples, int B, int ld, void* stream);
 
 /* ------------------------------------------------------------------------- *
- * Waveform exchange buffer (the payload of the path's single all-gather).
+ * Waveform exchange buffer (the payload of the path's all-gather).
  * Replaces: the per-worker file writes of the reference's Pool(8) (sr/inference.py:205-207,
- * 249-251,288-292,351-354): every rank packs its decoded waveforms into rows of one
- * f32 [n_rows, ld_buf] buffer, row = [job id (int32 bits) | sample count (int32 bits) | 0 | 0 |
- * samples ... zero fill]; ld_buf = 4 + L_max rounded up to a multiple of 4.
- * dissc_pack_waves copies the B utterances of one generator batch (wav f32 [B, ld_wav],
- * n_samples/job_ids i32 [B], all device) into rows row0 .. row0+B-1; dissc_pack_empty_rows marks
- * rows without a job (id -1).
+ * 249-251,288-292,351-354).  Every rank packs the waveforms it decoded into ONE flat f32 buffer of
+ * the same size on every rank (ragged: rows back to back, nothing padded to the longest waveform):
+ *   floats [0,4)            int32 bits: {rows used, 0, data floats used lo, hi}
+ *   floats [4, 4+4*n_cap)   table, one entry per row: int32 {job id (-1 = unused), sample count,
+ *                           offset lo, offset hi} -- offset in floats from the start of the data region,
+ *                           a multiple of 4 (the exclusive prefix sum of the sample counts rounded up to 4)
+ *   floats [4+4*n_cap, ..)  data region: row r at its offset, zero-filled up to the next multiple of 4
+ * The header and table are written by the host (a few KB, one H2D copy); dissc_pack_rows moves the B
+ * utterances of one generator batch (wav f32 [B, ld_wav], n_samples i32 [B], offsets i64 [B], all device;
+ * n_max = the largest sample count of the batch, sizes the launch) into the data region, 16 B per lane.
+ * data must be 16-byte aligned.
  * ------------------------------------------------------------------------- */
-int dissc_pack_waves(const float* wav, long long ld_wav, const int32_t* n_samples, const int32_t* job_ids,
-                     int B, float* buf, long long ld_buf, int row0, void* stream);
-int dissc_pack_empty_rows(float* buf, long long ld_buf, int row0, int rows, void* stream);
+int dissc_pack_rows(const float* wav, long long ld_wav, const int32_t* n_samples, const long long* offsets,
+                    int B, int n_max, float* data, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * YAAPT F0 tracker, device front end.

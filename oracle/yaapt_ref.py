@@ -392,8 +392,12 @@ def get_yaapt_f0(audio, rate=16000):
 
 
 def f0_per_unit(f0_frames, n_units, ratio=4):
-    """textless align_f0_to_durations for deduplicate=False [3P-unverified]: unit i covers frames
+    """textless align_f0_to_durations for deduplicate=False [3P-unverified]: the track is truncated to
+    ratio * n_units frames or, when shorter, extended with its last value; unit i covers frames
     [ratio*i, ratio*(i+1)); mean of its voiced (non-zero) values, 0.0 if none"""
+    f0_frames = np.asarray(f0_frames, dtype=np.float64)[:ratio * n_units]
+    if 0 < len(f0_frames) < ratio * n_units:
+        f0_frames = np.concatenate([f0_frames, np.full(ratio * n_units - len(f0_frames), f0_frames[-1])])
     out = np.zeros(n_units)
     for i in range(n_units):
         seg = np.asarray(f0_frames[ratio * i:ratio * (i + 1)])

@@ -196,22 +196,8 @@ def main(argv=None):
     np.random.seed(seed)
     torch.manual_seed(seed)
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29512')
-        # DISSC_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks share devices
-        # round-robin); the default is RCCL with one GPU per rank
-        backend = os.environ.get('DISSC_DIST_BACKEND', 'nccl')
-        if backend != 'nccl':
-            local_rank = local_rank % torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
-        kw = {'device_id': torch.device('cuda', local_rank)} if backend == 'nccl' else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    from dissc_amd import harness
+    rank, local_rank, world, dist = harness.init_distributed(29512)
     device = torch.device('cuda', local_rank)
 
     if os.path.isdir(a.checkpoint_file):
@@ -257,11 +243,13 @@ def main(argv=None):
 
     os.makedirs(a.output_dir, exist_ok=True)
     jobs, items = build_jobs(a, h, samples, id_to_spkr, f0_stats_cfg, target_f0_stats)
-    waves = harness.run_resynthesis(generator, jobs, rank, world, device, dist,
-                                    postprocess=wav_postprocess_)
+
+    def write(waves):  # rank 0, once per round (a run is one round unless a rank decodes > 1 GiB of audio)
+        for j, w in sorted(waves.items()):
+            wavfile.write(os.path.join(a.output_dir, jobs[j]['out']), h.sampling_rate, w)
+
+    harness.run_resynthesis(generator, jobs, rank, world, device, dist, postprocess=wav_postprocess_, sink=write)
     if rank == 0:
-        for j, job in enumerate(jobs):
-            wavfile.write(os.path.join(a.output_dir, job['out']), h.sampling_rate, waves[j])
         if a.sample_df is None:
             for stem, audio_path, code_len in items:
                 gt = load_gt(str(audio_path), code_len, a.pad, h.sampling_rate,
@@ -270,7 +258,7 @@ def main(argv=None):
                     wavfile.write(os.path.join(a.output_dir, stem + '_gt.wav'), h.sampling_rate,
                                   peak_normalize(gt))
         print(f'{len(jobs)} waveforms written to {a.output_dir}')
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -29,6 +29,13 @@ def test_bench_two_ranks_gloo_dry_run():
     # whole-job aggregate: 2 ranks x 4 utterances x 20 frames x 20 ms per step
     assert abs(j["value"] * j["ms_per_step"] / 1e3 - 2 * 4 * 20 * 0.02) < 1e-3 * 2 * 4 * 20 * 0.02 + 1e-2
     assert "cpu_baseline" not in j and j["roofline"]["bound"] == "mfma"
+    # the strong-scaling leg: the same fixed job list sharded over both ranks, ONE all-gather, per-rank times
+    st = j["strong"]
+    assert st["scaling"] == "strong" and st["jobs"] == 32 and st["value"] > 0
+    assert len(st["per_rank_compute_ms"]) == 2 and st["compute_imbalance"] >= 1.0 and 1.0 <= st["load_imbalance"] < 1.2
+    assert st["exchange"]["collectives"] == 1 and st["exchange"]["rounds"] == 1
+    assert st["exchange"]["sent_bytes_per_rank"] <= 1.2 * st["exchange"]["payload_bytes_this_rank"] + 1024
+    assert "all_gather_into_tensor" in j["config"]["collective"]
 
 
 def test_bench_gpus_flag_spawns_its_own_ranks():

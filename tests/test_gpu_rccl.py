@@ -1,0 +1,116 @@
+"""RCCL on the one GPU this box has: the collectives of the path (all_gather_into_tensor of the exchange buffer,
+the 16-byte MAX all-reduce of convert.py) executed on the "nccl" backend with world_size 1 (DISSC_FORCE_DIST=1), held
+to the run without a process group byte for byte.  N > 1 over xGMI stays the driver's multi-GPU run; what this
+removes is the "has never executed" risk of the NCCL branch: device_id= initialisation, device-side gather into a
+fresh tensor, the unpack of the gathered 2-D buffer, barrier + destroy."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DISSC_FORCE_DIST",
+                                                            "DISSC_DIST_BACKEND", "DISSC_BENCH_BACKEND")}
+    env.update(kw)
+    return env
+
+
+def test_exchange_buffer_device_pack_equals_host_pack_and_survives_rccl():
+    """dissc_pack_rows (device) writes the same bytes as the host rehearsal of the layout; an all-gather of it on
+    RCCL (one rank) returns it unchanged; unpack gives back every waveform."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.distributed as dist
+    from dissc_amd import harness
+    rs = np.random.RandomState(0)
+    lens = [0, 1, 3, 4, 5, 4095, 4096, 4097, 160000, 9001, 12288]
+    waves = [torch.from_numpy(rs.standard_normal(n).astype(np.float32)) for n in lens]
+    ids = list(range(100, 100 + len(lens)))
+    data_cap = sum((n + 3) // 4 * 4 for n in lens) + 64
+    host = harness.pack_waves(waves, ids, len(lens) + 2, data_cap, "cpu")
+    used = harness.HDR + harness.ENT * (len(lens) + 2) + data_cap - 64
+    # batches of several rows with a padded row stride, like the generator's output
+    st = harness.WaveStore(DEV)
+    order = [[0, 1, 2], [3, 4, 5, 6], [7], [8, 9, 10]]
+    for grp in order:
+        ld = max(lens[k] for k in grp) + 8
+        w = torch.full((len(grp), ld), float("nan"), device=DEV)
+        for r, k in enumerate(grp):
+            w[r, :lens[k]] = waves[k].to(DEV)
+        st.add(w, [lens[k] for k in grp], [ids[k] for k in grp])
+    dev = st.pack(len(lens) + 2, data_cap)
+    assert torch.equal(dev[:used].cpu().view(torch.int32), host[:used].view(torch.int32))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        out = harness.gather_store(st, len(lens) + 2, data_cap, 0, 1, dist)
+        n_cap, d_cap = harness.agree_geometry(7, 12345, 1, DEV, dist)
+    finally:
+        dist.destroy_process_group()
+    assert (n_cap, d_cap) == (7, 12345)
+    assert sorted(out) == ids
+    for k, j in enumerate(ids):
+        np.testing.assert_array_equal(out[j], waves[k].numpy())
+
+
+def test_sr_inference_on_rccl_world_size_one_matches_no_process_group(tmp_path):
+    import synthdata as synth
+    td = str(tmp_path)
+    os.makedirs(f"{td}/ckpt")
+    os.makedirs(f"{td}/meta")
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "vctk_id_to_spkr.pkl"), f"{td}/meta/id_to_spkr.pkl")
+    cfg = dict(synth.VCTK_CONFIG, input_training_file=f"{td}/meta/train.txt", f0_normalize=False, f0_stats=None)
+    json.dump(cfg, open(f"{td}/ckpt/config.json", "w"))
+    torch.save({"generator": synth.synth_generator_state_dict(seed=0)}, f"{td}/ckpt/g_00000001")
+    rs = np.random.RandomState(4)
+    with open(f"{td}/man.txt", "w") as f:
+        for u in range(48):
+            T = int(rs.randint(20, 260)) if u else 0  # one empty `units` line rides along
+            code, f0, _, _ = synth.synth_generator_inputs(1, max(T, 1), seed=900 + u)
+            f.write(json.dumps({"units": code[0, :T].tolist(), "f0": [float(v) for v in f0[0, 0, :T]],
+                                "audio": f"p{225 + u % 7}_{u:03d}.wav"}) + "\n")
+    args = [os.path.join(ROOT, "sr", "inference.py"), "--input_code_file", f"{td}/man.txt", "--data_path", f"{td}/nowav",
+            "--checkpoint_file", f"{td}/ckpt/", "--vc", "--target-speakers", "p231", "p225", "--unseen_speaker",
+            "--id_to_spkr", f"{td}/meta/id_to_spkr.pkl", "-n", "-1"]
+    for name, env in (("plain", _env()), ("rccl", _env(DISSC_FORCE_DIST="1", MASTER_PORT=str(_free_port())))):
+        r = subprocess.run([sys.executable] + args + ["--output_dir", f"{td}/{name}"], env=env, capture_output=True,
+                           text=True, timeout=900, cwd=td)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    files = sorted(os.listdir(f"{td}/plain"))
+    assert len(files) == 96 and sorted(os.listdir(f"{td}/rccl")) == files
+    for fn in files:
+        assert open(f"{td}/plain/{fn}", "rb").read() == open(f"{td}/rccl/{fn}", "rb").read(), fn
+
+
+def test_bench_on_rccl_world_size_one():
+    """bench.py with the process group forced: the weak-scaling step's all-gather and the strong leg's exchange run on
+    RCCL; the line names every collective."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-split-bf16", "--no-pipeline", "--no-d2h"],
+                       env=_env(DISSC_FORCE_DIST="1", MASTER_PORT=str(_free_port())), capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and "nccl" in j["config"]["collective"] and j["value"] > 200
+    st = j["strong"]
+    assert st["jobs"] == 1024 and st["exchange"]["collectives"] == 1 and st["value"] > 200
+    assert st["exchange"]["sent_bytes_per_rank"] <= 1.1 * st["exchange"]["payload_bytes_this_rank"]

@@ -60,11 +60,12 @@ def test_training_step_matches_the_reference(gold, kind):
                 a, b = compact(gv.numpy()).astype(np.float64), np.asarray(want, dtype=np.float64)
                 assert np.linalg.norm(a - b) <= (0.15 if kind == "len" else 0.05) * np.linalg.norm(b) + 1e-6, k
                 continue
-            # LeakyReLU's derivative jumps at 0: an activation within rounding of 0 (one such element exists in the
-            # golden batch, channel 104 of the last trunk layer of the length model) takes the other branch and
-            # moves every gradient below it by ~1.4 % (tools/diag_train2.py locates it; all other channels agree to 1e-7).
+            # LeakyReLU's derivative jumps at 0: an activation within rounding of 0 would take the other branch and
+            # move every gradient below it by O(1 %) (round 2's length batch had one, in channel 104 of the last trunk
+            # layer).  The golden batches are now generated with every pre-activation >= 2e-5 away from 0
+            # (make_golden.py _search_len_batch), so all three models are held to 1e-4 in the l2 sense.
             a, b = compact(gv.numpy()).astype(np.float64), np.asarray(want, dtype=np.float64)
-            lim = 0.03 if kind == "len" else 1e-4  # (the pitch models have no such element: 1e-6 measured)
+            lim = 1e-4
             assert np.linalg.norm(a - b) <= lim * np.linalg.norm(b) + 1e-6, \
                 (f"grad {k} step {step}", np.linalg.norm(a - b) / np.linalg.norm(b))
         sd = tr.state_dict()
@@ -84,6 +85,24 @@ def test_training_step_matches_the_reference(gold, kind):
             _close(v.float().numpy(), g[pre + "after/" + k], 1e-4, 1e-6 + noise, f"after {k} step {step}")
         nbt = [k for k in sd if k.endswith("num_batches_tracked")][0]
         assert int(sd[nbt]) == int(initial_state(kind)[nbt]) + step + 1
+
+
+def test_long_batch_gradients_match_the_reference(gold):
+    """3 x 150 padded units: longer than the 128-column tiles of the conv / weight-gradient kernels and no multiple of
+    64, so the time split of train_wgrad_mfma_kernel has its seam inside every utterance; every gradient of the
+    length model against the reference's at 1e-4 (l2) and elementwise."""
+    from dissc_amd.train import Trainer
+    g = gold
+    tr = Trainer("len", initial_state("len"), 3e-4, norm=(3.3, 2.1)).to("cuda:0")
+    seq, tgt, spk, keep = (torch.from_numpy(g["len_long/" + n]) for n in ("seq", "tgt", "spk", "keep"))
+    loss = float(tr.step(seq, spk, tgt, keep=keep))
+    assert abs(loss - float(g["len_long/loss"])) <= 5e-5 * abs(float(g["len_long/loss"]))
+    for k, gv in tr.grads().items():
+        if k in BN_FED_BIASES["len"]:
+            continue
+        a, b = compact(gv.numpy()).astype(np.float64), np.asarray(g["len_long/grad/" + k], dtype=np.float64)
+        assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b) + 1e-6, (k, np.linalg.norm(a - b) / np.linalg.norm(b))
+        _close(gv.numpy(), g["len_long/grad/" + k], 2e-4, 5e-6, f"grad {k}")
 
 
 def _flip_tolerant(got, want, what, l2=0.03):

@@ -13,7 +13,7 @@ import pytest
 import torch
 from scipy.io import wavfile
 
-from test_yaapt import CASES, FS, check_track, pulse_train, voiced
+from test_yaapt import CASES, FS, _speech, check_track, pulse_train, speech_track_is_plausible, voiced
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -119,6 +119,39 @@ def test_tracker_agrees_with_the_oracle_and_is_batch_independent(trk):
         alone = trk([x])[0]  # an utterance on its own == the same utterance in the batch
         np.testing.assert_array_equal(alone, got[i])
     assert not got[3].any() and (got[4] > 0).mean() <= 0.1
+
+
+def test_tracker_on_the_reference_speech_fixtures(trk, tmp_path):
+    """Real speech (the reference's own fixtures, tests/golden/s1_1.wav / s1_2.wav): the HIP tracker gives a plausible
+    track, agrees with the CPU restatement (voicing on >= 97 % of the frames, F0 within 0.5 % on >= 99 % of the frames
+    both call voiced) and with the committed copy of the restatement's track; the per-unit F0 and the speaker
+    statistics data/prep_dataset.py derives from it are finite.  Parity with amfm_decompy stays UNPINNED."""
+    from oracle import yaapt_ref as yr
+    from dissc_amd import stats as S
+    from dissc_amd.f0 import f0_per_unit
+    names = ["s1_1", "s1_2"]
+    sigs = [_speech(n) for n in names]
+    got = trk(sigs)
+    fixture = np.load(os.path.join(ROOT, "tests", "golden", "yaapt_speech.npz"))
+    per_unit = []
+    for n, x, f0 in zip(names, sigs, got):
+        assert f0.dtype == np.float32 and len(f0) == 400
+        speech_track_is_plausible(f0.astype(np.float64), n)
+        for want, src in ((yr.get_yaapt_f0(x), "oracle"), (fixture[n].astype(np.float64), "fixture")):
+            agree = ((f0 > 0) == (want > 0)).mean()
+            both = (f0 > 0) & (want > 0)
+            rel = np.abs(f0[both] - want[both]) / want[both]
+            print(f"{n} vs {src}: voicing agreement {agree:.4f}, co-voiced frames {int(both.sum())}, "
+                  f"within 0.5 %: {(rel <= 5e-3).mean():.4f}, max rel {rel.max():.2e}")
+            assert agree >= 0.97, (n, src, agree)
+            assert (rel <= 5e-3).mean() >= 0.99, (n, src, (rel <= 5e-3).mean())
+        np.testing.assert_array_equal(trk([x])[0], f0)  # batch independence on speech too
+        u = f0_per_unit(f0, 99)
+        assert np.isfinite(u).all() and (u > 0).mean() >= 0.5
+        per_unit.append(u)
+    # encode -> prep_dataset statistics (mean / std of the voiced per-unit values per speaker), on the device
+    st = S.pitch_stats({"s1": np.concatenate(per_unit)}, device="cuda:0", on_unvoiced="raise")["s1"]
+    assert np.isfinite(st["mean"]) and np.isfinite(st["std"]) and 80 < float(st["mean"]) < 200 and 5 < float(st["std"]) < 60
 
 
 def _long_batch():

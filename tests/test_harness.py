@@ -38,13 +38,55 @@ def test_make_batches_limits():
 
 def test_pack_unpack_roundtrip():
     waves = [torch.arange(5, dtype=torch.float32), torch.zeros(0), torch.full((9,), -2.5)]
-    buf = harness.pack_waves(waves, [7, 3, 100000], n_max=4, l_max=9, device="cpu")
-    assert buf.shape == (4, harness.HDR + 12)  # rows padded to a multiple of 4 floats
-    out = harness.unpack_waves(buf)
+    buf = harness.pack_waves(waves, [7, 3, 100000], n_cap=4, data_cap=24, device="cpu")
+    # ragged layout: 16 B header + 16 B per table entry + rows padded to 16 B only (8 + 0 + 12 floats used)
+    assert buf.shape == (harness.HDR + 4 * harness.ENT + 24,)
+    head = buf[:harness.HDR + 4 * harness.ENT].numpy().view(np.int32).reshape(5, 4)
+    assert head[0, 0] == 3 and head[0, 2] == 20 and head[4, 0] == -1
+    assert head[1:4, :3].tolist() == [[7, 5, 0], [3, 0, 8], [100000, 9, 8]]
+    out = harness.unpack_waves(buf, 4)
     assert sorted(out) == [3, 7, 100000]
     np.testing.assert_array_equal(out[7], np.arange(5, dtype=np.float32))
     assert out[3].shape == (0,)
     np.testing.assert_array_equal(out[100000], np.full(9, -2.5, np.float32))
+    with pytest.raises(ValueError):
+        harness.pack_waves(waves, [7, 3, 100000], n_cap=4, data_cap=16, device="cpu")
+    bad = buf.clone()
+    bad.view(torch.int32)[0] = 9  # more rows than the table holds
+    with pytest.raises(ValueError):
+        harness.unpack_waves(bad, 4)
+
+
+def test_plan_rounds_covers_every_job_once_and_is_bounded():
+    rs = np.random.RandomState(1)
+    lengths = rs.randint(1, 500, size=300).tolist()
+    parts = harness.lpt_shard(lengths, 4)
+    assert harness.plan_rounds(lengths, parts) == [[sorted(p, key=lambda i: (-lengths[i], i)) for p in parts]]
+    rounds = harness.plan_rounds(lengths, parts, budget=3000)
+    assert len(rounds) > 1 and all(len(r) == 4 for r in rounds)
+    for r in range(4):
+        got = [i for rd in rounds for i in rd[r]]
+        assert sorted(got) == sorted(parts[r])
+        for rd in rounds:
+            assert sum(lengths[i] for i in rd[r]) <= 3000
+    one_big = harness.plan_rounds([10, 5000, 7], [[0, 1, 2], []], budget=100)  # a job above the budget rides alone
+    assert [rd[0] for rd in one_big] == [[1], [0, 2]] and all(rd[1] == [] for rd in one_big)
+    assert 1.0 <= harness.imbalance(lengths, parts) < 1.01
+
+
+def test_exchange_moves_little_more_than_the_payload_at_sweep_size():
+    """BASELINE configs[4] geometry (108 speakers x 24 utterances x 4 targets = 10 368 jobs of 2-5 s over 8
+    ranks): the ragged buffer every rank sends is within 1.1x of the samples it holds (the dense
+    [n_max, 4 + L_max] layout of rounds 1-2 sent 1.5x), and nothing is padded to the longest waveform."""
+    rs = np.random.RandomState(5)
+    frames = np.repeat(rs.randint(100, 251, size=108 * 24), 4).tolist()
+    parts = harness.lpt_shard(frames, 8)
+    n_cap, data_cap = harness.pack_geometry(frames, parts, 320)
+    sent = harness.buffer_floats(n_cap, data_cap)
+    payload = [sum(frames[i] * 320 for i in p) for p in parts]
+    assert sent <= 1.1 * min(payload), (sent, min(payload))
+    dense = n_cap * (4 + max(frames) * 320)
+    assert dense > 1.3 * sent
 
 
 class _FakeGenerator:
@@ -84,6 +126,12 @@ def _worker(rank, world, port, q):
     only0 = harness.run_resynthesis(_FakeGenerator(), _jobs(), rank, world, "cpu", dist, max_batch=4,
                                     max_frames=100)  # default: only rank 0 unpacks
     assert (len(only0) == 25) == (rank == 0)
+    # bounded rounds: several all-gathers, each handed to the sink and freed; same waveforms
+    seen, stats = {}, {}
+    n = harness.run_resynthesis(_FakeGenerator(), _jobs(), rank, world, "cpu", dist, max_batch=4, max_frames=100,
+                                unpack_ranks=None, sink=seen.update, round_floats=400, stats=stats)
+    assert n == 25 and stats["rounds"] >= 2 and stats["collectives"] == stats["rounds"]
+    assert sorted(seen) == sorted(out) and all(np.array_equal(seen[k], out[k]) for k in out)
     q.put((rank, {k: v.tolist() for k, v in out.items()}))
     dist.barrier()
     dist.destroy_process_group()
@@ -93,6 +141,10 @@ def test_two_rank_gloo_matches_single_process():
     single = harness.run_resynthesis(_FakeGenerator(), _jobs(), 0, 1, "cpu", None, max_batch=4,
                                      max_frames=100)
     assert sorted(single) == list(range(25)) and single[23].shape == (0,) and single[24].shape == (0,)
+    rounds = {}
+    assert harness.run_resynthesis(_FakeGenerator(), _jobs(), 0, 1, "cpu", None, max_batch=4, max_frames=100,
+                                   sink=rounds.update, round_floats=200) == 25
+    assert all(np.array_equal(rounds[k], single[k]) for k in single)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

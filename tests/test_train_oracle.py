@@ -81,3 +81,19 @@ def test_training_step_oracle_matches_the_reference(kind):
             close(v.numpy(), g[pre + "after/" + k], 2e-5 if step == 0 else 2e-4, 1e-7 + noise, f"after {k} step {step}")
     # padding rows never move: token_emb's pad row has no gradient
     assert torch.equal(sd["token_emb.weight"][100], initial_state(kind)["token_emb.weight"][100])
+
+
+def test_long_batch_step_oracle_matches_the_reference():
+    """the second length-model case of the golden file: 3 x 150 padded units (longer than a 128-column tile, no
+    multiple of 64), every LeakyReLU input >= 2e-5 away from 0 (the generator of the fixture searches the batch seed)"""
+    g = np.load(os.path.join(GOLDEN, "train.npz"))
+    assert float(g["len_long/min_abs_preact"]) >= 2e-5 and float(g["len/s0/min_abs_preact"]) >= 2e-5
+    sd = {k: v.clone() for k, v in initial_state("len").items()}
+    seq, tgt, spk, keep = (torch.from_numpy(g["len_long/" + n]) for n in ("seq", "tgt", "spk", "keep"))
+    assert seq.shape == (3, 150)
+    loss, grads = tr.train_step("len", sd, seq, spk, tgt, keep, 3e-4, {}, norm=(torch.tensor(3.3), torch.tensor(2.1)))
+    assert abs(float(loss) - float(g["len_long/loss"])) <= 2e-5 * abs(float(g["len_long/loss"]))
+    for k in tr.trainable_keys(sd):
+        if k in BN_FED_BIASES["len"]:
+            continue
+        close(grads[k].numpy(), g["len_long/grad/" + k], 2e-4, 5e-6, f"grad {k}")

@@ -2,6 +2,8 @@
 stages of the product (dissc_amd/f0.py: spectral track, candidate merge, final DP -- vectorised numpy) against the
 oracle's own versions of the same stages.  PARITY UNPINNED against amfm_decompy (absent offline): what is pinned
 is ground truth (synthetic speech-like signals with a known F0) and mutual agreement."""
+import os
+
 import numpy as np
 import pytest
 
@@ -71,7 +73,11 @@ def test_f0_per_unit_alignment():
     np.testing.assert_allclose(yr.f0_per_unit(f, 3), [105.0, 0.0, 200.0])
     from dissc_amd.f0 import f0_per_unit
     np.testing.assert_allclose(f0_per_unit(f, 3), [105.0, 0.0, 200.0])
-    np.testing.assert_allclose(f0_per_unit(f, 5), yr.f0_per_unit(f, 5))  # more units than frames: zeros
+    # more units than frames: the track is extended with its last value (textless pads with f0[-1], not zeros)
+    np.testing.assert_allclose(f0_per_unit(f, 5), [105.0, 0.0, 200.0, 50.0, 50.0])
+    np.testing.assert_allclose(f0_per_unit(f, 5), yr.f0_per_unit(f, 5))
+    np.testing.assert_allclose(f0_per_unit(f[:12], 4), [105.0, 0.0, 200.0, 200.0])
+    np.testing.assert_allclose(f0_per_unit(np.zeros(0), 2), [0.0, 0.0])
 
 
 def test_product_host_stages_equal_the_oracle_stages():
@@ -120,3 +126,39 @@ def test_product_host_stages_equal_the_oracle_stages():
     np.testing.assert_allclose(prod.final_track(rp_o, rm_o, energy, prod.DEFAULTS), yr.dynamic(rp_o, rm_o, energy),
                                rtol=1e-12)
     assert prod.DEFAULTS == {k: v for k, v in p.items() if k != "dec_factor"}
+
+
+def _speech(name):
+    from scipy.io import wavfile
+    sr, x = wavfile.read(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".wav"))
+    assert sr == FS
+    return x.astype(np.float32) / 32768.0
+
+
+def speech_track_is_plausible(f0, what):
+    """what any F0 tracker must deliver on a clean, mostly voiced read sentence of one speaker"""
+    v = f0 > 0
+    assert 0.5 <= v.mean() <= 0.95, (what, v.mean())
+    assert f0[v].min() >= 60.0 and f0[v].max() <= 400.0, (what, f0[v].min(), f0[v].max())
+    both = v[1:] & v[:-1]
+    jumps = np.abs(np.diff(f0))[both] / f0[:-1][both]
+    assert np.median(jumps) < 0.10, (what, np.median(jumps))          # the verdict's bar
+    assert np.median(jumps) < 0.03 and (jumps < 0.25).mean() >= 0.9, (what, np.median(jumps))  # what is measured
+    # one speaker: the bulk of the voiced frames lies within an octave around the median
+    med = np.median(f0[v])
+    assert ((f0[v] > med / 1.6) & (f0[v] < med * 1.6)).mean() >= 0.93, what
+
+
+@pytest.mark.parametrize("name", ["s1_1", "s1_2"])
+def test_oracle_on_the_reference_speech_fixtures(name):
+    """the reference's own speech fixtures through the restatement: a plausible track, and the committed copy of it
+    (tests/golden/yaapt_speech.npz, written by make_yaapt_tracks.py from this same oracle) shows drift"""
+    f0 = yr.get_yaapt_f0(_speech(name))
+    assert len(f0) == 400
+    speech_track_is_plausible(f0, name)
+    want = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yaapt_speech.npz"))[name]
+    assert ((f0 > 0) == (want > 0)).mean() >= 0.995
+    both = (f0 > 0) & (want > 0)
+    assert np.abs(f0[both] - want[both]).max() <= 1e-3 * want[both].max()
+    per_unit = yr.f0_per_unit(f0, 99)
+    assert np.isfinite(per_unit).all() and (per_unit > 0).mean() >= 0.5

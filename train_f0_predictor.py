@@ -21,6 +21,8 @@ def train(data_path, f0_path, device='cuda:0', args=None):
     from dissc_amd.predictors import PitchPredictor, PitchPredictorBase
     from dissc_amd.train import Trainer, batches, init_state_dict, load_pitch_dataset, write_log
     pad = -100
+    # --seed -1 = non-deterministic, as documented (reference train_*_predictor.py --seed help): draw one
+    run_seed = args.seed if args.seed >= 0 else torch.seed() % (1 << 31)
     out_path = args.out_path + '/pitch'
     f0_param_dict = formats.load_pickle(f0_path)
     spk_id_dict = formats.spk_id_dict_from_list(formats.load_pickle(f'{args.data_path}/id_to_spkr.pkl'))
@@ -29,8 +31,8 @@ def train(data_path, f0_path, device='cuda:0', args=None):
     va = load_pitch_dataset(f'{data_path}/val.txt', spk_id_dict, f0_param_dict, args.n_tokens, pad)
     kind = 'base' if args.model_type == 'base' else 'new'
     trainer = Trainer(kind, init_state_dict(kind, args.n_tokens, len(spk_id_dict)), args.learning_rate,
-                      stats=(id2mean, id2std), seed=max(args.seed, 0)).to(device)
-    gen = torch.Generator().manual_seed(max(args.seed, 0))
+                      stats=(id2mean, id2std), seed=run_seed).to(device)
+    gen = torch.Generator().manual_seed(run_seed)
     log = out_path + '/log.jsonl'
     if os.path.exists(log):
         os.remove(log)

@@ -36,6 +36,8 @@ def train(data_path, device='cuda:0', args=None):
     from dissc_amd.predictors import LenPredictor
     from dissc_amd.train import Trainer, batches, init_state_dict, load_len_dataset, write_log
     pad = -1
+    # --seed -1 = non-deterministic, as documented (reference train_*_predictor.py --seed help): draw one
+    run_seed = args.seed if args.seed >= 0 else torch.seed() % (1 << 31)
     out_path = args.out_path + '/len'
     spk_id_dict = formats.spk_id_dict_from_list(formats.load_pickle(f'{args.data_path}/id_to_spkr.pkl'))
     tr_vals, tr_lens, tr_spk, _ = load_len_dataset(f'{data_path}/train.txt', spk_id_dict, args.n_tokens, pad)
@@ -44,8 +46,8 @@ def train(data_path, device='cuda:0', args=None):
     norm_mean, norm_std = valid.mean(), valid.std()
     torch.save((norm_mean, norm_std), out_path + '/len_norm_stats.pth')
     trainer = Trainer('len', init_state_dict('len', args.n_tokens, len(spk_id_dict)), args.learning_rate,
-                      norm=(norm_mean, norm_std), seed=max(args.seed, 0)).to(device)
-    gen = torch.Generator().manual_seed(max(args.seed, 0))
+                      norm=(norm_mean, norm_std), seed=run_seed).to(device)
+    gen = torch.Generator().manual_seed(run_seed)
     log = out_path + '/log.jsonl'
     if os.path.exists(log):
         os.remove(log)
