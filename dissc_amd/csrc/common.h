@@ -142,6 +142,7 @@ struct DevConv {
   int m32 = 0;              // packed for the 32x32x2 kernel
   int prec = 0;             // 1: packed as split-bf16 hi/lo fragments
   double macs_per_t = 0;  // MACs per input time step (algorithmic, zero taps excluded)
+  int wino = 0;           // packed for conv_wino_kernel (Toom-Cook F(4,3) transform-domain weights)
 };
 // Per-call extras of run_conv_ex (strided / valid convolutions with their own output lengths).
 struct ConvIO {
@@ -167,6 +168,18 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
 int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res, float* acc,
                 const ConvIO& io, int B, int C_x_total, int ldx, int ldo, int Lmax_out, float slope,
                 int epi, float mrf_div, hipStream_t stream, float out_slope = 0.f, int dma_in = 0);
+
+// Toom-Cook F(4,3) form of the wide ResBlock convs (conv_wino.hip)
+extern int g_wino;        // "wino" option (read at dissc_gen_create): 1 = C >= wino_min_c ResBlock convs use it
+extern int g_wino_min_c;
+extern int g_wino_dbg;
+extern int g_wino_cpr;
+bool wino_supported(int Cout, int Cin, int KS, int dil);
+int make_wino(const float* w, const float* bias, int C, int KS, int dil, DevConv& dc);
+double wino_executed_macs_per_t(int C, int KS);
+int run_wino(const DevConv& dc, const float* x, float* out, const float* res, float* acc, const int32_t* lengths,
+             int len_default, int len_mul, int B, int ldx, int ldo, int Lmax, float slope, int epi, float mrf_div,
+             hipStream_t stream);
 
 // fused ResBlock1 for narrow stages (resblock_fused.hip)
 bool resblock_fused_supported(int C, int KS, const int* dil);

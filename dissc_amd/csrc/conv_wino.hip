@@ -1,0 +1,510 @@
+// conv_wino_kernel: the stride-1 "same" convolutions of the wide ResBlock stages (C -> C channels, k = 3 / 7 / 11,
+// dilation 1 / 3 / 5; reference sr/models.py:16-41) evaluated with fewer multiplications: Toom-Cook F(4,3) over
+// 3-tap sub-filters, still fp32 operands, fp32 products and fp32 accumulation on v_mfma_f32_32x32x2_f32.
+//
+//   y[n] = sum_i w[i] xa[n - pad + i d],  xa = lrelu(x) inside the utterance, 0 outside.
+//
+// * The k taps are split into NS = ceil(k / 3) sub-filters of 3 taps with tap stride NS (sub-filter j = taps j, j + NS,
+//   j + 2 NS; missing taps are zero).  With D = d NS, sub-filter j is a 3-tap filter on the sequence sampled every D.
+// * F(4,3): 4 outputs of a 3-tap filter from 6 inputs with 6 multiplications: y = A^T [(G g) . (B^T s)], evaluation points
+//   0, 1, -1, 2, -1/2, inf (rows of B^T scaled to exactly representable entries; the scaling is folded into G, which the
+//   host applies to the weights in double precision).  The products of the 6 points are 6 independent GEMMs over the input
+//   channels AND the NS sub-filters (the sums over sub-filters happen in the transform domain):
+//       Y_p[co][tau][rho] = sum_j sum_ci U_pj[co][ci] V_p[ci][tau][rho + d j],     rho in [0, D), j in [0, NS)
+//       V_p[ci][tau][w]   = sum_m B^T[p][m] xa[ci][o + 4 D tau + w + D m],          w in [0, d (2 NS - 1))
+//       y[co][t0 + 4 D tau + rho + D a] = sum_p A^T[a][p] Y_p[co][tau][rho] + bias,  a in [0, 4)
+//   i.e. per point a dilation-d, NS-tap convolution in the transform domain: 6 NS MFMA products per 4 outputs instead of
+//   4 k (k = 3: 6 vs 12, k = 7: 18 vs 28, k = 11: 24 vs 44).
+// * One workgroup = 6 waves = the 6 points of one [64 rows] x [64 transform-domain columns = 240..256 outputs] tile.  All
+//   waves share the activated input window (staged like conv_mfma32_kernel: registers -> lrelu / zero padding -> LDS);
+//   wave p derives ITS V_p from it into a wave-private LDS tile (6 LDS reads + 6 FMAs per entry, coefficients in SGPRs) and
+//   runs the same tap / k-step MFMA loop as conv_mfma32_kernel on it with its own weights U_p (A fragments streamed from
+//   L2 in fragment order).  Two barriers per 16-channel chunk (window ready / window consumed; they are a short transform
+//   apart).  Epilogue: the 6 waves exchange their Y_p through LDS, every thread applies A^T, bias and the residual / MRF
+//   mode of its outputs.
+// The results differ from the direct kernels by fp32 rounding only (measured per layer: rms 3e-7 relative to O(0.4)
+// outputs against 1e-7 for the direct form); the direct kernels remain (option "wino" = 0).
+#include <string.h>
+
+#include "common.h"
+#include "conv_epilogue32.h"
+
+namespace dissc {
+
+int g_wino = 1;          // "wino" option: 1 = wide ResBlock convs through conv_wino_kernel (read per launch)
+int g_wino_min_c = 128;  // "wino_min_c" option: narrowest stage that uses it
+int g_wino_dbg = 0;      // "wino_dbg" option (diagnostics): knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue, 3 staging
+
+struct WinoArgs {
+  const float* x;
+  const float* wpack;   // [6 points][C / 32][nchunk][NS][2][64][4] (pack_conv_weights32 with groups = 6)
+  const float* bias;    // [C]
+  const float* res;
+  float* out;
+  float* acc;
+  const int32_t* lengths;
+  int len_default, len_mul;
+  int C, nchunk, pad;
+  int ldx, ldo;
+  long long x_bstride, o_bstride;
+  float slope, mrf_div;
+  int epi;
+  int dbg;
+};
+
+// B^T rows (point p, input m) and A^T (output a, point p) of F(4,3) at the points 0, 1, -1, 2, -1/2, inf
+__constant__ float kWinoBT[6][6] = {{0.5f, 0.75f, -1.0f, -0.75f, 0.5f, 0.0f}, {0.0f, 1.0f, 2.5f, 0.5f, -1.0f, 0.0f},
+                                    {0.0f, 1.0f, 0.5f, -2.5f, 1.0f, 0.0f},    {0.0f, -0.5f, -1.0f, 0.5f, 1.0f, 0.0f},
+                                    {0.0f, -1.0f, 0.5f, 1.0f, -0.5f, 0.0f},   {0.0f, 0.5f, 0.75f, -1.0f, -0.75f, 0.5f}};
+// G rows matching the scaling of kWinoBT (host, double)
+static const double kWinoG[6][3] = {{2.0, 0.0, 0.0},
+                                    {1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0},
+                                    {1.0 / 3.0, -1.0 / 3.0, 1.0 / 3.0},
+                                    {1.0 / 15.0, 2.0 / 15.0, 4.0 / 15.0},
+                                    {32.0 / 15.0, -16.0 / 15.0, 8.0 / 15.0},
+                                    {0.0, 0.0, 2.0}};
+
+#ifndef DISSC_WINO_LB
+#define DISSC_WINO_LB 3
+#endif
+
+// polyphase row length: indices 0 .. 4 NTU + 7 are touched (the last aligned 16-byte read of a lane starts at
+// 4 (NTU - 1) + 8), rounded up so that RL / 4 makes the 16 lanes of a quarter wave start in 16 different bank groups
+// where that is possible (lane = tau * D + phi reads at phi * RL + 4 tau)
+constexpr int wino_row_len(int D, int NTU, int XRW) {
+  int need = 4 * NTU + 8;
+  const int span = (XRW - 1 + 4 * D) / D + 1;
+  if (span > need) need = span;
+  need = (need + 3) / 4 * 4;
+  if (D == 1) return need;
+  for (int rl = need; rl < need + 64 && 2 * 32 * D * rl * 4 + 12 * 8 * 112 * 4 <= 156 * 1024; rl += 4) {
+    bool ok = true;
+    for (int c0 = 0; c0 < 64 && ok; c0 += 16) {
+      unsigned seen = 0;
+      for (int c = c0; c < c0 + 16; ++c) {
+        const int g = ((c % D) * (rl / 4) + c / D) % 16;
+        if (seen & (1u << g)) ok = false;
+        seen |= 1u << g;
+      }
+    }
+    if (ok) return rl;
+  }
+  return need;
+}
+
+template <int NS, int DIL, int CPR>
+__global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const WinoArgs a) {
+  constexpr int NTH = 768;                    // 12 waves: 6 points x 2 row halves (3 waves on every SIMD)
+  constexpr int D = DIL * NS;                 // sample step of the F(4,3) sequences
+  constexpr int W = DIL * (2 * NS - 1);       // V entries per tile unit
+  constexpr int NTU = 64 / D;                 // tile units per workgroup
+  constexpr int NCOL = NTU * D;               // transform-domain columns in use (<= 64)
+  constexpr int OT = 4 * D * NTU;             // outputs per workgroup tile
+  constexpr int RAW = OT + DIL * (3 * NS - 1);  // input window
+  constexpr int XRW = (RAW + 3 + 3) / 4 * 4;  // staged positions per channel (alignment shift <= 3)
+  constexpr int NV = XRW / 4;
+  constexpr int RL = wino_row_len(D, NTU, XRW);
+  constexpr int CHF = D * RL;                 // floats per channel of the polyphase window
+  constexpr int VROW = NTU * W;               // V entries per channel (<= 112)
+  constexpr int XV = 112;                     // V row stride (112 % 32 == 16: the two k halves of a fragment read hit different banks)
+  constexpr int SV = (CPR * NV + NTH - 1) / NTH;
+  constexpr int YS = 68;                      // row stride of the epilogue exchange (64 columns + 4)
+  static_assert(VROW <= XV && NCOL <= 64, "tile geometry");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // 2 x [CPR][D][RL]: window sample x (position o + x) of a channel at [(x + 4 D) % D][(x + 4 D) / D]
+  float* vbuf = lds + 2 * CPR * CHF;  // [12 waves][8][XV]
+
+  const int b = blockIdx.z;
+  const int len = a.lengths ? a.lengths[b] * a.len_mul : a.len_default;
+  const int t0 = blockIdx.x * OT;
+  if (t0 >= len) return;
+  const int mt = blockIdx.y;  // 128-row tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = wave % 6;   // this wave's evaluation point
+  const int mh = wave / 6;  // ... and 64-row half of the tile
+  const int l31 = lane & 31, h = lane >> 5;
+  const int o = t0 - a.pad;
+  const int tb = o & ~3;
+  const int sh = o - tb;
+  const float slope = a.slope;
+  const float* xb = a.x + (size_t)b * a.x_bstride;
+  const int nround = a.nchunk / (CPR / KC);  // CPR channels per barrier round (the host checks divisibility)
+
+  // ---- window staging: unconditional clamped 16-byte loads; activation, zero padding and the polyphase scatter on the
+  // way to LDS (samples D apart become neighbours, so that a lane's 6-sample groups are two aligned 16-byte reads)
+  const int r0 = tid / NV, v0 = tid - r0 * NV;
+  constexpr int dr = NTH / NV, dv = NTH - dr * NV;
+  f32x4 sv[SV];
+  auto stage_load = [&](int rd) {
+    int r = r0, v = v0;
+#pragma unroll
+    for (int i = 0; i < SV; ++i) {
+      int ci = rd * CPR + (r < CPR ? r : CPR - 1);
+      ci = ci < a.C ? ci : a.C - 1;
+      int t = tb + 4 * v;
+      t = t < 0 ? 0 : (t > a.ldx - 4 ? a.ldx - 4 : t);
+      sv[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)ci * a.ldx + t);
+      v += dv;
+      r += dr;
+      if (v >= NV) { v -= NV; ++r; }
+    }
+  };
+  auto stage_store = [&](float* raw) {
+    int r = r0, v = v0;
+#pragma unroll
+    for (int i = 0; i < SV; ++i) {
+      if (r < CPR) {
+        const int t = tb + 4 * v;
+        const f32x4 val = sv[i];
+        float* rowp = raw + r * CHF;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = (t + e) >= 0 && (t + e) < len;
+          const int xs = 4 * v + e - sh + 4 * D;  // >= 4 D - 3 > 0
+          rowp[(xs % D) * RL + xs / D] = ok ? lrelu(val[e], slope) : 0.f;
+        }
+      }
+      v += dv;
+      r += dr;
+      if (v >= NV) { v -= NV; ++r; }
+    }
+  };
+
+  // ---- transform: lane <-> column (tau, phi); entries w = phi and w = phi + D of unit tau
+  const int tcol = lane < NCOL ? lane : NCOL - 1;
+  const int ttau = tcol / D, tphi = tcol % D;
+  const int toff = tphi * RL + 4 * ttau + 4;       // first of the 8 neighbouring samples (16-byte aligned)
+  const int e0 = ttau * W + tphi;
+  const bool ok1 = tphi + D < W;
+  const int e1 = ok1 ? e0 + D : e0;
+  float bt[6];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) bt[m] = kWinoBT[p][m];
+  float* vp = vbuf + wave * (8 * XV);
+
+  // ---- B fragment offsets: column (ni * 32 + l31) -> (tau, rho) -> tau * W + rho, k half h -> row h
+  int voff[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    int col = ni * 32 + l31;
+    col = col < NCOL ? col : NCOL - 1;
+    voff[ni] = (col / D) * W + (col % D) + h * XV;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  // A fragments: one float4 per lane = the 4 k-steps (8 channels) of one (chunk, tap, half): [chunk][tap][half][lane]
+  const int nsub = a.C / 32;
+  const int nblk = a.nchunk * NS * 2;  // (chunk, half, tap) blocks, walked in this order
+  const f32x4* wp[2];
+  f32x4 av[2], avn[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * 4 + mh * 2 + mi) * (a.nchunk * NS) * 128 + lane;
+  auto wofs = [&](int blk) {  // blk = (chunk * 2 + half) * NS + tap -> float4 offset
+    const int tap = blk % NS, ch2 = blk / NS;
+    return (size_t)((ch2 >> 1) * NS + tap) * 128 + (ch2 & 1) * 64;
+  };
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    av[mi] = wp[mi][wofs(0)];
+  }
+  stage_load(0);
+  stage_store(lds);
+  if (nround > 1) stage_load(1);  // the staging registers always hold the round after the newest one in LDS
+  __syncthreads();
+
+  // One barrier per round: at the top of round rd the window of round rd + 1 goes into the other buffer (every wave
+  // finished reading it before the barrier that closed round rd - 1) and the loads of round rd + 2 are issued; the
+  // barrier at the bottom publishes that window and retires this round's.
+  int blk = 0;
+  for (int rd = 0; rd < nround; ++rd) {
+    const float* raw = lds + (rd & 1) * (CPR * CHF);
+    if (!(a.dbg & 8)) {
+      if (rd + 1 < nround) stage_store(lds + ((rd + 1) & 1) * (CPR * CHF));
+      if (rd + 2 < nround) stage_load(rd + 2);
+    }
+    for (int sc = 0; sc < CPR / 8; ++sc) {
+      // ---- V_p[i][e] of channels sc * 8 + i (branch-free: lanes without a second entry rewrite their first one, lanes
+      // beyond the last column duplicate it)
+      if (!(a.dbg & 1)) {
+        const float* rw = raw + (sc * 8) * CHF + toff;
+#pragma unroll
+        for (int i0 = 0; i0 < 8; i0 += 2) {
+          f32x4 lo[2], hi[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            lo[i] = *reinterpret_cast<const f32x4*>(rw + (i0 + i) * CHF);
+            hi[i] = *reinterpret_cast<const f32x4*>(rw + (i0 + i) * CHF + 4);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            float v0 = bt[0] * lo[i][0];
+            v0 = fmaf(bt[1], lo[i][1], v0);
+            v0 = fmaf(bt[2], lo[i][2], v0);
+            v0 = fmaf(bt[3], lo[i][3], v0);
+            v0 = fmaf(bt[4], hi[i][0], v0);
+            v0 = fmaf(bt[5], hi[i][1], v0);
+            vp[(i0 + i) * XV + e0] = v0;
+            if constexpr (NS > 1) {
+              float v1 = bt[0] * lo[i][1];
+              v1 = fmaf(bt[1], lo[i][2], v1);
+              v1 = fmaf(bt[2], lo[i][3], v1);
+              v1 = fmaf(bt[3], hi[i][0], v1);
+              v1 = fmaf(bt[4], hi[i][1], v1);
+              v1 = fmaf(bt[5], hi[i][2], v1);
+              vp[(i0 + i) * XV + e1] = ok1 ? v1 : v0;
+            }
+          }
+        }
+      }
+      // ---- NS taps x 4 k-steps on V_p; the B fragments of tap j + 1 and the A fragments of block blk + 2 are fetched
+      // behind the MFMAs of tap j
+      if (!(a.dbg & 2)) {
+        const float* bj[2] = {vp + voff[0], vp + voff[1]};
+        float b0[2], b0n[2], bk[3][2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b0[ni] = bj[ni][0];
+#pragma unroll
+        for (int j = 0; j < NS; ++j, ++blk) {
+          const int bn = (blk + 1 < nblk) ? blk + 1 : nblk - 1;
+          const size_t wo = wofs(bn);
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) avn[mi] = wp[mi][wo];
+#pragma unroll
+          for (int s = 1; s < 4; ++s)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bk[s - 1][ni] = bj[ni][s * 2 * XV + j * DIL];
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) b0n[ni] = (j + 1 < NS) ? bj[ni][(j + 1) * DIL] : 0.f;  // next tap's first k-step
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][0], b0[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+          for (int s = 1; s < 4; ++s)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][s], bk[s - 1][ni], acc[mi][ni], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) b0[ni] = b0n[ni];
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) av[mi] = avn[mi];
+        }
+      } else {
+        blk += NS;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: the 6 waves exchange their Y_p through LDS, 32 rows at a time; one thread = 4 consecutive outputs
+  // (16-byte residual / accumulator / output accesses) of one row: output u = 4 g + e of unit tau comes from column
+  // (tau, u % D) with A^T row a = u / D
+  float* yb = lds;  // [6][32][YS]
+  if (a.dbg & 4) {
+    if (acc[0][0][0] == 123.f) a.out[0] = 1.f;
+    return;
+  }
+  const int epi = a.epi;
+  const size_t ob = (size_t)b * a.o_bstride;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {  // 32 rows per pass: (row half, 32-row subtile)
+    const int pmh = ps >> 1, mi = ps & 1;
+    if (ps > 0) __syncthreads();
+    if (mh == pmh) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          yb[(p * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * YS + ni * 32 + l31] = acc[mi][ni][r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * NCOL; idx += NTH) {
+      const int row = idx / NCOL, qi = idx - row * NCOL;
+      const int tau = qi / D, g = qi - tau * D;
+      const int n0 = t0 + 4 * D * tau + 4 * g;
+      if (n0 >= len) continue;
+      const int grow = mt * 128 + ps * 32 + row;
+      const float bz = a.bias[grow];
+      const float* yr = yb + row * YS + tau * D;
+      f32x4 v;
+      if constexpr (D == 1) {
+        const float y0 = yr[0], y1 = yr[32 * YS], y2 = yr[2 * 32 * YS], y3 = yr[3 * 32 * YS], y4 = yr[4 * 32 * YS],
+                    y5 = yr[5 * 32 * YS];
+        const float s12 = y1 + y2, d12 = y1 - y2;
+        v[0] = (y0 + s12) + (y3 + y4) + bz;
+        v[1] = d12 + fmaf(2.f, y3, -0.5f * y4) + bz;
+        v[2] = s12 + fmaf(4.f, y3, 0.25f * y4) + bz;
+        v[3] = d12 + fmaf(8.f, y3, -0.125f * y4) + y5 + bz;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int u = 4 * g + e;
+          const int ao = u / D, rho = u - ao * D;  // A^T row, column within the unit
+          const float* yc = yr + rho;
+          const float y0 = yc[0], y1 = yc[32 * YS], y2 = yc[2 * 32 * YS], y3 = yc[3 * 32 * YS], y4 = yc[4 * 32 * YS],
+                      y5 = yc[5 * 32 * YS];
+          // A^T[ao] = {ao == 0, 1, (-1)^ao, 2^ao, (-1/2)^ao, ao == 3}
+          const float sg = (ao & 1) ? -1.f : 1.f;
+          const float p2 = __int_as_float((127 + ao) << 23), ip2 = __int_as_float((127 - ao) << 23);
+          float x = (ao == 0 ? y0 : 0.f) + y1;
+          x = fmaf(sg, y2, x);
+          x = fmaf(p2, y3, x);
+          x = fmaf(sg * ip2, y4, x);
+          x += (ao == 3 ? y5 : 0.f);
+          v[e] = x + bz;
+        }
+      }
+      const size_t ix = ob + (size_t)grow * a.ldo + n0;
+      if (n0 + 4 <= len) {
+        if (epi == EPI_STORE) {
+          *reinterpret_cast<f32x4*>(a.out + ix) = v;
+        } else {
+          const f32x4 rs = *reinterpret_cast<const f32x4*>(a.res + ix);
+          v[0] += rs[0]; v[1] += rs[1]; v[2] += rs[2]; v[3] += rs[3];
+          if (epi == EPI_RES) {
+            *reinterpret_cast<f32x4*>(a.out + ix) = v;
+          } else if (epi == EPI_MRF_SET) {
+            *reinterpret_cast<f32x4*>(a.acc + ix) = v;
+          } else {
+            const f32x4 ac = *reinterpret_cast<const f32x4*>(a.acc + ix);
+            v[0] = ac[0] + v[0]; v[1] = ac[1] + v[1]; v[2] = ac[2] + v[2]; v[3] = ac[3] + v[3];
+            if (epi == EPI_MRF_DIV) {
+              v[0] = __fdiv_rn(v[0], a.mrf_div); v[1] = __fdiv_rn(v[1], a.mrf_div);
+              v[2] = __fdiv_rn(v[2], a.mrf_div); v[3] = __fdiv_rn(v[3], a.mrf_div);
+            }
+            *reinterpret_cast<f32x4*>(a.acc + ix) = v;
+          }
+        }
+      } else {
+        for (int e = 0; e < len - n0; ++e) {
+          float x = v[e];
+          if (epi == EPI_STORE) {
+            a.out[ix + e] = x;
+          } else {
+            x += a.res[ix + e];
+            if (epi == EPI_RES) {
+              a.out[ix + e] = x;
+            } else if (epi == EPI_MRF_SET) {
+              a.acc[ix + e] = x;
+            } else {
+              x = a.acc[ix + e] + x;
+              if (epi == EPI_MRF_DIV) x = __fdiv_rn(x, a.mrf_div);
+              a.acc[ix + e] = x;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+bool wino_supported(int Cout, int Cin, int KS, int dil) {
+  return Cout == Cin && Cout % 128 == 0 && (KS == 3 || KS == 7 || KS == 11) && (dil == 1 || dil == 3 || dil == 5);
+}
+
+// w: [C][C][KS] -> transform-domain weights U[p][co][ci][j] = sum_i G[p][i] w[co][ci][j + NS i] as a grouped conv tensor
+// [6 C][C][NS] (group = point), packed in A-fragment order for the 32x32x2 kernel
+int make_wino(const float* w, const float* bias, int C, int KS, int dil, DevConv& dc) {
+  const int NS = (KS + 2) / 3;
+  std::vector<float> wt((size_t)6 * C * C * NS);
+  for (int p = 0; p < 6; ++p)
+    for (int co = 0; co < C; ++co)
+      for (int ci = 0; ci < C; ++ci)
+        for (int j = 0; j < NS; ++j) {
+          double u = 0.0;
+          for (int i = 0; i < 3; ++i) {
+            const int tap = j + NS * i;
+            if (tap < KS) u += kWinoG[p][i] * (double)w[((size_t)co * C + ci) * KS + tap];
+          }
+          wt[(((size_t)p * C + co) * C + ci) * NS + j] = (float)u;
+        }
+  std::vector<float> packed;
+  int Mpad, nchunk;
+  pack_conv_weights32(wt.data(), 6 * C, C, NS, packed, Mpad, nchunk, 6);
+  if (Mpad != C) {
+    set_error("make_wino: C = %d is not a multiple of the row tile", C);
+    return DISSC_EINVAL;
+  }
+  std::vector<float> b(C, 0.f);
+  if (bias) memcpy(b.data(), bias, C * sizeof(float));
+  dc.CIN = C; dc.M = C; dc.KS = KS; dc.dil = dil; dc.nchunk = nchunk; dc.up = 1;
+  dc.groups = 1; dc.Mpad = C; dc.stride = 1; dc.pad_left = -1; dc.m32 = 1; dc.prec = 0;
+  dc.macs_per_t = (double)C * C * KS;  // algorithmic (direct-form) MACs
+  dc.wino = 1;
+  int rc = upload(packed, &dc.wpack);
+  if (rc) return rc;
+  return upload(b, &dc.bias);
+}
+
+// MACs the matrix pipe executes per output position (6 NS / 4 per input/output channel pair)
+double wino_executed_macs_per_t(int C, int KS) { return (double)C * C * 6.0 * ((KS + 2) / 3) / 4.0; }
+
+template <int NS, int DIL, int CPR>
+static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream) {
+  constexpr int D = DIL * NS, NTU = 64 / D, OT = 4 * D * NTU, RAW = OT + DIL * (3 * NS - 1), XRW = (RAW + 6) / 4 * 4;
+  constexpr int RL = wino_row_len(D, NTU, XRW);
+  size_t lds_f = (size_t)2 * CPR * D * RL + 12 * 8 * 112;
+  if (lds_f < (size_t)6 * 32 * 68) lds_f = (size_t)6 * 32 * 68;
+  static bool attr_done = false;
+  if (!attr_done) {
+    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, DIL, CPR>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  dim3 grid((Lmax + OT - 1) / OT, a.C / 128, B);
+  hipLaunchKernelGGL((conv_wino_kernel<NS, DIL, CPR>), grid, dim3(768), lds_f * sizeof(float), stream, a);
+  DISSC_HIP_CHECK(hipGetLastError());
+  return DISSC_OK;
+}
+
+int g_wino_cpr = 32;  // "wino_cpr" option: channels per barrier round (16 or 32)
+template <int NS, int DIL>
+static int launch_wino_t(const WinoArgs& a, int B, int Lmax, hipStream_t stream) {
+  if (g_wino_cpr == 32 && a.nchunk % 2 == 0) return launch_wino_c<NS, DIL, 32>(a, B, Lmax, stream);
+  return launch_wino_c<NS, DIL, 16>(a, B, Lmax, stream);
+}
+
+int run_wino(const DevConv& dc, const float* x, float* out, const float* res, float* acc, const int32_t* lengths,
+             int len_default, int len_mul, int B, int ldx, int ldo, int Lmax, float slope, int epi, float mrf_div,
+             hipStream_t stream) {
+  WinoArgs a;
+  a.x = x; a.wpack = dc.wpack; a.bias = dc.bias; a.res = res; a.out = out; a.acc = acc;
+  a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul;
+  a.C = dc.M; a.nchunk = dc.nchunk; a.pad = (dc.KS - 1) * dc.dil / 2;
+  a.ldx = ldx; a.ldo = ldo;
+  a.x_bstride = (long long)dc.M * ldx; a.o_bstride = (long long)dc.M * ldo;
+  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = g_wino_dbg;
+  if (ldx < 4) {
+    set_error("run_wino: rows shorter than 4 floats");
+    return DISSC_EINVAL;
+  }
+  const int ns = (dc.KS + 2) / 3;
+#define DISSC_WINO_CASE(NS_, D_) if (ns == NS_ && dc.dil == D_) return launch_wino_t<NS_, D_>(a, B, Lmax, stream);
+  DISSC_WINO_CASE(1, 1) DISSC_WINO_CASE(1, 3) DISSC_WINO_CASE(1, 5)
+  DISSC_WINO_CASE(3, 1) DISSC_WINO_CASE(3, 3) DISSC_WINO_CASE(3, 5)
+  DISSC_WINO_CASE(4, 1) DISSC_WINO_CASE(4, 3) DISSC_WINO_CASE(4, 5)
+#undef DISSC_WINO_CASE
+  set_error("run_wino: k = %d, dilation %d unsupported", dc.KS, dc.dil);
+  return DISSC_EINVAL;
+}
+
+}  // namespace dissc

@@ -247,7 +247,9 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         if ((rc = get(name, {ch, ch, rk}, &w))) return fail(rc);
         snprintf(name, sizeof(name), "resblocks.%d.convs1.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
-        if ((rc = make_conv(w, b, ch, ch, rk, d, g->rb1[idx]))) return fail(rc);
+        const bool wino = g_wino && prec == 0 && ch >= g_wino_min_c && wino_supported(ch, ch, rk, d);
+        if ((rc = wino ? make_wino(w, b, ch, rk, d, g->rb1[idx]) : make_conv(w, b, ch, ch, rk, d, g->rb1[idx])))
+          return fail(rc);
         if (bf3) {
           w6[2 * m] = w;
           fb.insert(fb.end(), b, b + ch);
@@ -263,7 +265,9 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         if ((rc = get(name, {ch, ch, rk}, &w))) return fail(rc);
         snprintf(name, sizeof(name), "resblocks.%d.convs2.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
-        if ((rc = make_conv(w, b, ch, ch, rk, 1, g->rb2[idx]))) return fail(rc);
+        const bool wino2 = g_wino && prec == 0 && ch >= g_wino_min_c && wino_supported(ch, ch, rk, 1);
+        if ((rc = wino2 ? make_wino(w, b, ch, rk, 1, g->rb2[idx]) : make_conv(w, b, ch, ch, rk, 1, g->rb2[idx])))
+          return fail(rc);
         if (bf3) {
           w6[2 * m + 1] = w;
           fb.insert(fb.end(), b, b + ch);
@@ -545,6 +549,20 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
       for (int m = 0; m < 3; ++m) {
         const size_t idx = ((size_t)i * nk + j) * 3 + m;
         const float* xin = (m == 0) ? X : XKc;
+        if (g->rb1[idx].wino && g->rb2[idx].wino) {
+          // Toom-Cook F(4,3) form (conv_wino.hip): t = conv_d(lrelu(x)); x = x + conv_1(lrelu(t)) / MRF update
+          if ((rc = run_wino(g->rb1[idx], xin, TMPc, nullptr, nullptr, lengths, L, mul, B, ld, ld, L, 0.1f, EPI_STORE,
+                             1.f, sj)))
+            return rc;
+          int epiw = EPI_RES;
+          if (m == 2) {
+            epiw = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET) : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
+            if (multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));
+          }
+          if ((rc = run_wino(g->rb2[idx], TMPc, XKc, xin, ACC, lengths, L, mul, B, ld, ld, L, 0.1f, epiw, (float)nk, sj)))
+            return rc;
+          continue;
+        }
         // wide stages: the first conv stores lrelu(t) with zero tails (EPI_STORE_ACT) so that the second one -- the only
         // reader of t -- stages its windows by LDS-DMA: no staging registers, no masks, one more wave per SIMD
         const bool dma2 = g_pair_dma && g->rb1[idx].m32 && g->rb2[idx].m32 && !g->rb1[idx].prec && !g->rb2[idx].prec &&
@@ -605,6 +623,17 @@ int dissc_conv1d(const float* x, const float* w_host, const float* bias_host, fl
     return DISSC_EINVAL;
   }
   DevConv dc;
+  if (g_wino >= 2 && wino_supported(Cout, Cin, k, dilation)) {  // "wino" = 2: the stand-alone entry uses it too (tests)
+    int rc = make_wino(w_host, bias_host, Cout, k, dilation, dc);
+    if (rc) return rc;
+    rc = run_wino(dc, x, y, nullptr, nullptr, lengths, Lmax, 1, B, ldx, ldo, Lmax, in_slope, EPI_STORE, 1.f,
+                  (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    free_conv(dc);
+    if (rc) return rc;
+    DISSC_HIP_CHECK(e);
+    return DISSC_OK;
+  }
   int rc = make_conv(w_host, bias_host, Cout, Cin, k, dilation, dc);
   if (rc) return rc;
   return conv_once(dc, x, y, lengths, B, ldx, ldo, Lmax, in_slope, (hipStream_t)stream);
@@ -637,6 +666,7 @@ int dissc_get_option(const char* key, int* value) {
   if (strcmp(key, "stream_prio") == 0) { *value = g_stream_prio; return DISSC_OK; }
   if (strcmp(key, "par_ups") == 0) { *value = g_par_ups; return DISSC_OK; }
   if (strcmp(key, "pair_max_c") == 0) { *value = g_pair_max_c; return DISSC_OK; }
+  if (strcmp(key, "wino") == 0) { *value = g_wino; return DISSC_OK; }
   set_error("dissc_get_option: '%s' cannot be read back", key);
   return DISSC_EINVAL;
 }
@@ -669,6 +699,10 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "lin_dma") == 0) { g_lin_dma = value; return DISSC_OK; }
   if (strcmp(key, "pos48") == 0) { g_pos48 = value; return DISSC_OK; }
   if (strcmp(key, "pair_dma") == 0) { g_pair_dma = value; return DISSC_OK; }
+  if (strcmp(key, "wino") == 0) { g_wino = value; return DISSC_OK; }
+  if (strcmp(key, "wino_min_c") == 0) { g_wino_min_c = value; return DISSC_OK; }
+  if (strcmp(key, "wino_dbg") == 0) { g_wino_dbg = value; return DISSC_OK; }
+  if (strcmp(key, "wino_cpr") == 0) { g_wino_cpr = value; return DISSC_OK; }
   if (strcmp(key, "c64_wide") == 0) { g_c64_wide = value; return DISSC_OK; }
   if (strcmp(key, "conv2_dma") == 0) { g_conv2_dma = value; return DISSC_OK; }
   if (strcmp(key, "mfma32") == 0) { g_use_mfma32 = value; return DISSC_OK; }
@@ -708,7 +742,9 @@ int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int e
   }
   DevConv dc;
   g_conv_prec = g_precision;  // diagnostics follow the "precision" option like the generator does
-  int rc = make_conv(w.data(), bias.data(), Cout, Cin, k, dilation, dc);
+  const bool wino = (flags & 2) && wino_supported(Cout, Cin, k, dilation);
+  int rc = wino ? make_wino(w.data(), bias.data(), Cout, k, dilation, dc)
+                : make_conv(w.data(), bias.data(), Cout, Cin, k, dilation, dc);
   g_conv_prec = 0;
   if (rc) return rc;
   const int ld = (L + 3) / 4 * 4;
@@ -731,11 +767,13 @@ int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int e
   DISSC_HIP_CHECK(hipEventCreate(&e1));
   const int saved_cls = (flags >> 16) & 0xf;
   if (flags & 0x8000) conv_set_cfg(saved_cls, (flags >> 8) & 0x3f);
-  for (int it = 0; it < 2 && !rc; ++it)
-    rc = run_conv(dc, x, y, r, a, nullptr, L, 1, B, Cin, ld, ld, L, (flags & 1) ? 1.0f : 0.1f, epi, 3.f, nullptr);
+  auto once = [&]() {
+    return wino ? run_wino(dc, x, y, r, a, nullptr, L, 1, B, ld, ld, L, (flags & 1) ? 1.0f : 0.1f, epi, 3.f, nullptr)
+                : run_conv(dc, x, y, r, a, nullptr, L, 1, B, Cin, ld, ld, L, (flags & 1) ? 1.0f : 0.1f, epi, 3.f, nullptr);
+  };
+  for (int it = 0; it < 2 && !rc; ++it) rc = once();
   DISSC_HIP_CHECK(hipEventRecord(e0, nullptr));
-  for (int it = 0; it < iters && !rc; ++it)
-    rc = run_conv(dc, x, y, r, a, nullptr, L, 1, B, Cin, ld, ld, L, (flags & 1) ? 1.0f : 0.1f, epi, 3.f, nullptr);
+  for (int it = 0; it < iters && !rc; ++it) rc = once();
   DISSC_HIP_CHECK(hipEventRecord(e1, nullptr));
   hipError_t e = hipEventSynchronize(e1);
   float ms = 0.f;
