@@ -65,6 +65,8 @@ def _load():
     L.dissc_gen_workspace_bytes.restype = ctypes.c_size_t
     L.dissc_gen_flops.argtypes = [vp, ctypes.c_int64]
     L.dissc_gen_flops.restype = ctypes.c_double
+    L.dissc_gen_flops_executed.argtypes = [vp, ctypes.c_int64]
+    L.dissc_gen_flops_executed.restype = ctypes.c_double
     L.dissc_gen_forward.argtypes = [vp, i64p, vp, i64p, vp, i32, i32, vp, vp, ctypes.c_size_t, vp]
     L.dissc_conv1d.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                                ctypes.c_float, vp]

@@ -175,6 +175,8 @@ extern int g_wino_min_c;
 extern int g_wino_dbg;
 extern int g_wino_cpr;
 bool wino_supported(int Cout, int Cin, int KS, int dil);
+bool wino_wanted(int C, int KS);
+extern int g_wino_c64_kmin;
 int make_wino(const float* w, const float* bias, int C, int KS, int dil, DevConv& dc);
 double wino_executed_macs_per_t(int C, int KS);
 int run_wino(const DevConv& dc, const float* x, float* out, const float* res, float* acc, const int32_t* lengths,

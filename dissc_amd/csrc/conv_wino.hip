@@ -31,8 +31,11 @@
 
 namespace dissc {
 
-int g_wino = 1;          // "wino" option: 1 = wide ResBlock convs through conv_wino_kernel (read per launch)
-int g_wino_min_c = 128;  // "wino_min_c" option: narrowest stage that uses it
+int g_wino = 1;          // "wino" option: 1 = wide ResBlock convs through conv_wino_kernel (read at dissc_gen_create);
+                         // 2 = the stand-alone dissc_conv1d entry uses it too (tests)
+int g_wino_min_c = 64;   // "wino_min_c" option: narrowest stage that uses it
+int g_wino_c64_kmin = 11;  // "wino_c64_kmin" option: smallest kernel size that uses it in a 64-channel stage (measured: k = 3 / 7
+                         // are break-even or slower there, the 4-chunk K loop is too short to amortise the transforms)
 int g_wino_dbg = 0;      // "wino_dbg" option (diagnostics): knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue, 3 staging
 
 struct WinoArgs {
@@ -50,6 +53,7 @@ struct WinoArgs {
   float slope, mrf_div;
   int epi;
   int dbg;
+  int gx, gy, B;  // time tiles, 128-row tiles, utterances
 };
 
 // B^T rows (point p, input m) and A^T (output a, point p) of F(4,3) at the points 0, 1, -1, 2, -1/2, inf
@@ -92,18 +96,19 @@ constexpr int wino_row_len(int D, int NTU, int XRW) {
   return need;
 }
 
-template <int NS, int DIL, int CPR>
+template <int NS, int DIL, int CPR, int RH>
 __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const WinoArgs a) {
   constexpr int NTH = 768;                    // 12 waves: 6 points x 2 row halves (3 waves on every SIMD)
   constexpr int D = DIL * NS;                 // sample step of the F(4,3) sequences
   constexpr int W = DIL * (2 * NS - 1);       // V entries per tile unit
-  constexpr int NTU = 64 / D;                 // tile units per workgroup
-  constexpr int NCOL = NTU * D;               // transform-domain columns in use (<= 64)
-  constexpr int OT = 4 * D * NTU;             // outputs per workgroup tile
+  constexpr int CHV = 3 - RH;                 // column halves per workgroup (RH = 2 row halves -> 1, RH = 1 -> 2)
+  constexpr int NTU = 64 / D;                 // tile units per wave
+  constexpr int NCOL = NTU * D;               // transform-domain columns of a wave in use (<= 64)
+  constexpr int OT = 4 * D * NTU * CHV;       // outputs per workgroup tile
   constexpr int RAW = OT + DIL * (3 * NS - 1);  // input window
   constexpr int XRW = (RAW + 3 + 3) / 4 * 4;  // staged positions per channel (alignment shift <= 3)
   constexpr int NV = XRW / 4;
-  constexpr int RL = wino_row_len(D, NTU, XRW);
+  constexpr int RL = wino_row_len(D, NTU * CHV, XRW);
   constexpr int CHF = D * RL;                 // floats per channel of the polyphase window
   constexpr int VROW = NTU * W;               // V entries per channel (<= 112)
   constexpr int XV = 112;                     // V row stride (112 % 32 == 16: the two k halves of a fragment read hit different banks)
@@ -114,16 +119,24 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   // 2 x [CPR][D][RL]: window sample x (position o + x) of a channel at [(x + 4 D) % D][(x + 4 D) / D]
   float* vbuf = lds + 2 * CPR * CHF;  // [12 waves][8][XV]
 
-  const int b = blockIdx.z;
+  // 1-D grid, XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2; the 128-row tiles
+  // (their transform-domain weights are 6 NS / k times the direct form's: 3.1 MB per tile for C = 256, k = 11) are
+  // pinned to XCD groups so that an L2 holds ONE tile's weights, and the time tiles / utterances are spread inside a group
+  const int per = 8 / a.gy;
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int mt = xcd / per;  // row tile (64 RH rows)
+  const int lin = (xcd - mt * per) + per * kq;
+  if (lin >= a.gx * a.B) return;
+  const int b = lin / a.gx;
   const int len = a.lengths ? a.lengths[b] * a.len_mul : a.len_default;
-  const int t0 = blockIdx.x * OT;
+  const int t0 = (lin - b * a.gx) * OT;
   if (t0 >= len) return;
-  const int mt = blockIdx.y;  // 128-row tile
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = wave % 6;   // this wave's evaluation point
-  const int mh = wave / 6;  // ... and 64-row half of the tile
+  const int mh = RH == 2 ? wave / 6 : 0;   // ... its 64-row half of the tile (RH = 2)
+  const int chh = RH == 2 ? 0 : wave / 6;  // ... or its 64-column half (RH = 1)
   const int l31 = lane & 31, h = lane >> 5;
   const int o = t0 - a.pad;
   const int tb = o & ~3;
@@ -175,7 +188,7 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   // ---- transform: lane <-> column (tau, phi); entries w = phi and w = phi + D of unit tau
   const int tcol = lane < NCOL ? lane : NCOL - 1;
   const int ttau = tcol / D, tphi = tcol % D;
-  const int toff = tphi * RL + 4 * ttau + 4;       // first of the 8 neighbouring samples (16-byte aligned)
+  const int toff = tphi * RL + 4 * (chh * NTU + ttau) + 4;  // first of the 8 neighbouring samples (16-byte aligned)
   const int e0 = ttau * W + tphi;
   const bool ok1 = tphi + D < W;
   const int e1 = ok1 ? e0 + D : e0;
@@ -208,7 +221,7 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   f32x4 av[2], avn[2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
-    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * 4 + mh * 2 + mi) * (a.nchunk * NS) * 128 + lane;
+    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * (2 * RH) + mh * 2 + mi) * (a.nchunk * NS) * 128 + lane;
   auto wofs = [&](int blk) {  // blk = (chunk * 2 + half) * NS + tap -> float4 offset
     const int tap = blk % NS, ch2 = blk / NS;
     return (size_t)((ch2 >> 1) * NS + tap) * 128 + (ch2 & 1) * 64;
@@ -323,10 +336,10 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   const int epi = a.epi;
   const size_t ob = (size_t)b * a.o_bstride;
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {  // 32 rows per pass: (row half, 32-row subtile)
-    const int pmh = ps >> 1, mi = ps & 1;
+  for (int ps = 0; ps < 4; ++ps) {  // 32 rows x 64 columns per pass: (row or column half, 32-row subtile)
+    const int phalf = ps >> 1, mi = ps & 1;
     if (ps > 0) __syncthreads();
-    if (mh == pmh) {
+    if ((RH == 2 ? mh : chh) == phalf) {
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -337,9 +350,9 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
     for (int idx = tid; idx < 32 * NCOL; idx += NTH) {
       const int row = idx / NCOL, qi = idx - row * NCOL;
       const int tau = qi / D, g = qi - tau * D;
-      const int n0 = t0 + 4 * D * tau + 4 * g;
+      const int n0 = t0 + 4 * D * ((RH == 2 ? 0 : phalf * NTU) + tau) + 4 * g;
       if (n0 >= len) continue;
-      const int grow = mt * 128 + ps * 32 + row;
+      const int grow = mt * (64 * RH) + (RH == 2 ? ps * 32 : mi * 32) + row;
       const float bz = a.bias[grow];
       const float* yr = yb + row * YS + tau * D;
       f32x4 v;
@@ -417,8 +430,15 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// the generator's policy (per ResBlock): which (C, k) run in the transform domain
+bool wino_wanted(int C, int KS) {
+  if (!g_wino || C < g_wino_min_c) return false;
+  if (C < 128 && KS < g_wino_c64_kmin) return false;
+  return wino_supported(C, C, KS, 1);
+}
+
 bool wino_supported(int Cout, int Cin, int KS, int dil) {
-  return Cout == Cin && Cout % 128 == 0 && (KS == 3 || KS == 7 || KS == 11) && (dil == 1 || dil == 3 || dil == 5);
+  return Cout == Cin && (Cout == 64 || (Cout % 128 == 0 && 8 % (Cout / 128) == 0)) && (KS == 3 || KS == 7 || KS == 11) && (dil == 1 || dil == 3 || dil == 5);
 }
 
 // w: [C][C][KS] -> transform-domain weights U[p][co][ci][j] = sum_i G[p][i] w[co][ci][j + NS i] as a grouped conv tensor
@@ -458,20 +478,30 @@ int make_wino(const float* w, const float* bias, int C, int KS, int dil, DevConv
 // MACs the matrix pipe executes per output position (6 NS / 4 per input/output channel pair)
 double wino_executed_macs_per_t(int C, int KS) { return (double)C * C * 6.0 * ((KS + 2) / 3) / 4.0; }
 
-template <int NS, int DIL, int CPR>
+template <int NS, int DIL, int CPR, int RH>
 static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream) {
-  constexpr int D = DIL * NS, NTU = 64 / D, OT = 4 * D * NTU, RAW = OT + DIL * (3 * NS - 1), XRW = (RAW + 6) / 4 * 4;
-  constexpr int RL = wino_row_len(D, NTU, XRW);
+  constexpr int CHV = 3 - RH;
+  constexpr int D = DIL * NS, NTU = 64 / D, OT = 4 * D * NTU * CHV, RAW = OT + DIL * (3 * NS - 1), XRW = (RAW + 6) / 4 * 4;
+  constexpr int RL = wino_row_len(D, NTU * CHV, XRW);
   size_t lds_f = (size_t)2 * CPR * D * RL + 12 * 8 * 112;
   if (lds_f < (size_t)6 * 32 * 68) lds_f = (size_t)6 * 32 * 68;
   static bool attr_done = false;
   if (!attr_done) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, DIL, CPR>),
+    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, DIL, CPR, RH>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  dim3 grid((Lmax + OT - 1) / OT, a.C / 128, B);
-  hipLaunchKernelGGL((conv_wino_kernel<NS, DIL, CPR>), grid, dim3(768), lds_f * sizeof(float), stream, a);
+  WinoArgs aa = a;
+  aa.gx = (Lmax + OT - 1) / OT;
+  aa.gy = a.C / (64 * RH);
+  aa.B = B;
+  if (8 % aa.gy != 0) {
+    set_error("launch_wino: %d row tiles do not divide the 8 XCDs", aa.gy);
+    return DISSC_EINVAL;
+  }
+  const int per = 8 / aa.gy;
+  dim3 grid(8 * ((aa.gx * B + per - 1) / per));
+  hipLaunchKernelGGL((conv_wino_kernel<NS, DIL, CPR, RH>), grid, dim3(768), lds_f * sizeof(float), stream, aa);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
@@ -479,8 +509,9 @@ static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
 int g_wino_cpr = 32;  // "wino_cpr" option: channels per barrier round (16 or 32)
 template <int NS, int DIL>
 static int launch_wino_t(const WinoArgs& a, int B, int Lmax, hipStream_t stream) {
-  if (g_wino_cpr == 32 && a.nchunk % 2 == 0) return launch_wino_c<NS, DIL, 32>(a, B, Lmax, stream);
-  return launch_wino_c<NS, DIL, 16>(a, B, Lmax, stream);
+  if (a.C % 128 != 0) return launch_wino_c<NS, DIL, 16, 1>(a, B, Lmax, stream);  // 64 rows x 128 columns
+  if (g_wino_cpr == 32 && a.nchunk % 2 == 0) return launch_wino_c<NS, DIL, 32, 2>(a, B, Lmax, stream);
+  return launch_wino_c<NS, DIL, 16, 2>(a, B, Lmax, stream);
 }
 
 int run_wino(const DevConv& dc, const float* x, float* out, const float* res, float* acc, const int32_t* lengths,

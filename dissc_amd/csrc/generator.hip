@@ -247,7 +247,7 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         if ((rc = get(name, {ch, ch, rk}, &w))) return fail(rc);
         snprintf(name, sizeof(name), "resblocks.%d.convs1.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
-        const bool wino = g_wino && prec == 0 && ch >= g_wino_min_c && wino_supported(ch, ch, rk, d);
+        const bool wino = prec == 0 && wino_wanted(ch, rk) && wino_supported(ch, ch, rk, d);
         if ((rc = wino ? make_wino(w, b, ch, rk, d, g->rb1[idx]) : make_conv(w, b, ch, ch, rk, d, g->rb1[idx])))
           return fail(rc);
         if (bf3) {
@@ -265,7 +265,7 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         if ((rc = get(name, {ch, ch, rk}, &w))) return fail(rc);
         snprintf(name, sizeof(name), "resblocks.%d.convs2.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
-        const bool wino2 = g_wino && prec == 0 && ch >= g_wino_min_c && wino_supported(ch, ch, rk, 1);
+        const bool wino2 = wino;
         if ((rc = wino2 ? make_wino(w, b, ch, rk, 1, g->rb2[idx]) : make_conv(w, b, ch, ch, rk, 1, g->rb2[idx])))
           return fail(rc);
         if (bf3) {
@@ -351,6 +351,23 @@ double dissc_gen_flops(dissc_gen_t g, int64_t frames) {
     mul = g->stage_mul[i];
     for (int j = 0; j < nk * 3; ++j)
       macs += (g->rb1[(size_t)i * nk * 3 + j].macs_per_t + g->rb2[(size_t)i * nk * 3 + j].macs_per_t) * mul;
+  }
+  macs += (double)g->post_C * g->post_KS * mul;
+  return 2.0 * macs * (double)frames;
+}
+
+// multiply-adds the matrix pipe actually executes: the layers that run in the Toom-Cook transform domain (conv_wino.hip)
+// do 6 ceil(k / 3) / 4 products per output and channel pair instead of k
+double dissc_gen_flops_executed(dissc_gen_t g, int64_t frames) {
+  if (!g) return 0;
+  double macs = g->conv_pre.macs_per_t;
+  int mul = 1;
+  const int nk = g->cfg.num_kernels;
+  auto ex = [](const DevConv& c) { return c.wino ? wino_executed_macs_per_t(c.M, c.KS) : c.macs_per_t; };
+  for (int i = 0; i < g->cfg.num_upsamples; ++i) {
+    for (auto& c : g->ups[i]) macs += c.macs_per_t * mul;
+    mul = g->stage_mul[i];
+    for (int j = 0; j < nk * 3; ++j) macs += (ex(g->rb1[(size_t)i * nk * 3 + j]) + ex(g->rb2[(size_t)i * nk * 3 + j])) * mul;
   }
   macs += (double)g->post_C * g->post_KS * mul;
   return 2.0 * macs * (double)frames;
@@ -703,6 +720,7 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "wino_min_c") == 0) { g_wino_min_c = value; return DISSC_OK; }
   if (strcmp(key, "wino_dbg") == 0) { g_wino_dbg = value; return DISSC_OK; }
   if (strcmp(key, "wino_cpr") == 0) { g_wino_cpr = value; return DISSC_OK; }
+  if (strcmp(key, "wino_c64_kmin") == 0) { g_wino_c64_kmin = value; return DISSC_OK; }
   if (strcmp(key, "c64_wide") == 0) { g_c64_wide = value; return DISSC_OK; }
   if (strcmp(key, "conv2_dma") == 0) { g_conv2_dma = value; return DISSC_OK; }
   if (strcmp(key, "mfma32") == 0) { g_use_mfma32 = value; return DISSC_OK; }

@@ -180,8 +180,15 @@ class CodeGenerator:
             pass
 
     def flops(self, frames):
+        """algorithmic FLOPs (2 x multiply-adds of the direct form) for `frames` code frames"""
         self._ensure()
         return lib.dissc_gen_flops(self._handle, int(frames))
+
+    def flops_executed(self, frames):
+        """FLOPs the matrix pipe executes: fewer than flops() where ResBlock convs run in the Toom-Cook F(4,3)
+        transform domain (csrc/conv_wino.hip)"""
+        self._ensure()
+        return lib.dissc_gen_flops_executed(self._handle, int(frames))
 
     def _workspace(self, B, T):
         need = lib.dissc_gen_workspace_bytes(self._handle, B, T)

@@ -94,6 +94,10 @@ int dissc_gen_hop(dissc_gen_t g);
 size_t dissc_gen_workspace_bytes(dissc_gen_t g, int B, int Tmax);
 /* FLOPs (2*MAC) of one forward for `frames` total valid frames (roofline accounting) */
 double dissc_gen_flops(dissc_gen_t g, int64_t frames);
+/* 2 * multiply-adds the matrix pipe EXECUTES for `frames` code frames: equal to dissc_gen_flops unless ResBlock convs
+ * run in the Toom-Cook F(4,3) transform domain (csrc/conv_wino.hip; option "wino", default on for the C >= 64 stages),
+ * which do 6 ceil(k / 3) / 4 products per output and channel pair instead of k. */
+double dissc_gen_flops_executed(dissc_gen_t g, int64_t frames);
 /*
  * code    i64 [B,Tmax]   unit ids in [0,num_embeddings)
  * f0      f32 [B,Tmax]   one value per frame (reference shape [B,1,T])

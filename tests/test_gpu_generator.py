@@ -77,6 +77,75 @@ def test_conv1d_matches_torch(env, C, k, d):
         assert (y[i, :, n:] == -7.0).all()  # nothing written beyond the utterance
 
 
+@pytest.mark.parametrize("C,k,d", [(64, 11, 1), (64, 3, 5), (64, 7, 3), (128, 7, 3), (128, 3, 1), (128, 11, 5),
+                                   (256, 11, 1), (256, 7, 1), (256, 3, 3)])
+def test_toom_cook_conv_matches_torch_and_the_direct_kernel(env, C, k, d):
+    """conv_wino_kernel (Toom-Cook F(4,3) over 3-tap sub-filters, csrc/conv_wino.hip) through the stand-alone entry
+    (option "wino" = 2): same bar against F.conv1d as the direct kernel, rms error within 2x of the direct kernel's,
+    ragged lengths incl. 1 and tile-boundary cases, NaN-poisoned padding, nothing written beyond an utterance."""
+    lib = env["lib"]
+    rs = np.random.RandomState(C * 100 + k * 10 + d)
+    lengths = [1000, 1, 255, 256, 257, 613, 240, 241]
+    B, L = len(lengths), 1000
+    x = torch.from_numpy(rs.standard_normal((B, C, L)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(C).astype(np.float32))
+    out = {}
+    try:
+        for mode in (0, 2):
+            assert lib.dissc_set_option(b"wino", mode) == 0
+            out[mode] = _run_conv(env, x, w, b, lengths, k, d, 0.1)
+    finally:
+        lib.dissc_set_option(b"wino", 1)
+    assert not torch.equal(out[0], out[2])  # really another evaluation order
+    se = {0: 0.0, 2: 0.0}
+    cnt = 0
+    for i, n in enumerate(lengths):
+        ref = F.conv1d(F.leaky_relu(x[i:i + 1, :, :n].double(), 0.1), w.double(), b.double(), padding=(k - 1) * d // 2,
+                       dilation=d)[0]
+        for mode in (0, 2):
+            y = out[mode]
+            e = (y[i, :, :n].double() - ref)
+            assert e.abs().max().item() <= 2e-5, (mode, i, e.abs().max().item())
+            assert (y[i, :, n:] == -7.0).all()  # nothing written beyond the utterance
+            se[mode] += float((e ** 2).sum())
+        cnt += ref.numel()
+    r0, r2 = (se[0] / cnt) ** 0.5, (se[2] / cnt) ** 0.5
+    print(f"C={C} k={k} d={d}: rms error direct {r0:.2e}, transform domain {r2:.2e}")
+    assert r2 <= 2.0 * r0 + 1e-8
+
+
+def test_toom_cook_generator_agrees_with_the_direct_generator(env):
+    """The default generator (wide ResBlock convs in the transform domain) against an instance built with option
+    "wino" = 0 (every conv direct, the round-2 path): same waveform to fp32 rounding on a ragged batch and at the
+    BASELINE size; the direct instance stays available and bit-identical to itself across batch shapes."""
+    import dissc_amd
+    lib, g, synth = env["lib"], env["g"], env["synth"]
+    try:
+        assert lib.dissc_set_option(b"wino", 0) == 0
+        gd = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
+        gd.load_state_dict(synth.synth_generator_state_dict(seed=0))
+        gd.eval().remove_weight_norm()
+        c1, f1, s1, _ = synth.synth_generator_inputs(1, 3, seed=1)
+        gd(code=torch.from_numpy(c1), f0=torch.from_numpy(f1), spkr=torch.from_numpy(s1))  # the native handle is built here
+    finally:
+        lib.dissc_set_option(b"wino", 1)
+    code, f0, spkr, lengths = synth.synth_generator_inputs(6, 41, seed=21, ragged=True)
+    lengths = lengths.copy()
+    lengths[1], lengths[2] = 1, 41
+    for (c, f, s_, ln) in ((code, f0, spkr, lengths), synth.synth_generator_inputs(32, 500, seed=1234)):
+        kw = dict(code=torch.from_numpy(c), f0=torch.from_numpy(f), spkr=torch.from_numpy(s_), lengths=torch.from_numpy(ln))
+        yw, yd = g(**kw).cpu(), gd(**kw).cpu()
+        assert torch.isfinite(yw).all() and not torch.equal(yw, yd)
+        e = (yw - yd).double()
+        rms, ref = float(e.pow(2).mean().sqrt()), float(yd.double().pow(2).mean().sqrt())
+        print(f"B={c.shape[0]} T={c.shape[1]}: transform-domain vs direct generator: rms {rms:.2e} (signal rms {ref:.2f}), "
+              f"max {float(e.abs().max()):.2e}")
+        assert rms <= 5e-6 and float(e.abs().max()) <= 1e-4
+        assert torch.equal(gd(code=kw["code"][:1], f0=kw["f0"][:1], spkr=kw["spkr"][:1], lengths=kw["lengths"][:1]).cpu()[0],
+                           yd[0])
+
+
 def test_conv1d_rect_and_identity_slope(env):
     rs = np.random.RandomState(3)
     x = torch.from_numpy(rs.standard_normal((2, 257, 130)).astype(np.float32))

@@ -66,7 +66,8 @@ if "check" in what:
 
 if "time" in what:
     shapes = [(256, 11, 1, 2500), (256, 7, 1, 2500), (256, 3, 1, 2500), (256, 11, 5, 2500), (256, 3, 5, 2500), (128, 11, 1, 10000),
-              (128, 7, 3, 10000), (128, 3, 1, 10000), (64, 11, 1, 40000), (64, 7, 1, 40000), (64, 3, 1, 40000), (64, 11, 5, 40000)]
+              (128, 7, 3, 10000), (128, 3, 1, 10000), (64, 11, 1, 40000), (64, 7, 1, 40000), (64, 3, 1, 40000), (64, 11, 5, 40000),
+              (64, 7, 3, 40000), (64, 3, 5, 40000)]
     Bb = int(os.environ.get("WINO_B", "32"))
     for C, k, d, Ln in shapes:
         res = []
