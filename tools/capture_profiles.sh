@@ -9,7 +9,7 @@ OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/$1
 WHAT=$2
 mkdir -p "$OUT"
 if [ "$WHAT" = gen ]; then
-  CMD="python ${GRAFT_REPO_ROOT:-$PWD}/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-split-bf16 --no-pipeline"
+  CMD="python ${GRAFT_REPO_ROOT:-$PWD}/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-split-bf16 --no-pipeline --no-strong --no-d2h"
 else
   CMD="python ${GRAFT_REPO_ROOT:-$PWD}/tools/encode_bench.py --iters 3"
 fi

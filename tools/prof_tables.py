@@ -133,7 +133,7 @@ def main():
     fe = fold(counters_by_dispatch(a.fetch), n, a.skip) if a.fetch else None
     wr = fold(counters_by_dispatch(a.write), n, a.skip) if a.write else None
     med = lambda xs: sorted(xs)[len(xs) // 2]
-    hdr = ["#", "layer", "kernel", "us", "GFLOP", "TFLOP/s", "alg. GB", "alg. GB/s"]
+    hdr = ["#", "layer", "kernel", "us", "GFLOP", "TFLOP/s", "exec. TFLOP/s", "alg. GB", "alg. GB/s"]
     if sq:
         hdr += ["MFMA busy", "wait_any", "wait_inst", "active"]
     if fe and wr:
@@ -143,14 +143,22 @@ def main():
     groups = defaultdict(lambda: defaultdict(float))
     for i, (name, fl, by) in enumerate(layers):
         d = med(dur[i])
+        # layers that ran in the Toom-Cook transform domain execute 6 ceil(k / 3) / 4 products per output instead of k
+        fx = fl
+        if "conv_wino_kernel" in names[i][0]:
+            import re
+            k = int(re.search(r" k(\d+) ", name + " ").group(1))
+            fx = fl * 6.0 * ((k + 2) // 3) / (4.0 * k)
         row = [str(i), name, names[i][0][:44], f"{d:.0f}", f"{fl / 1e9:.1f}", f"{fl / d / 1e6:.1f}" if fl else "-",
-               f"{by / 1e9:.3f}", f"{by / d / 1e3:.0f}"]
+               f"{fx / d / 1e6:.1f}" if fl else "-", f"{by / 1e9:.3f}", f"{by / d / 1e3:.0f}"]
         g = name.split()[0] if a.what == "gen" else ("attention" if "attention" in name else "linear" if ("->" in name and "conv" not in name)
                                                       else "feature conv" if name.startswith("conv") and "conv0" not in name else "other")
         groups[g]["us"] += d
         groups[g]["fl"] += fl
+        groups[g]["fx"] += fx
         tot["us"] += d
         tot["fl"] += fl
+        tot["fx"] += fx
         tot["by"] += by
         if sq:
             c = {k: med([x.get(k, 0.0) for x in sq[i]]) for k in sq[i][0]}
@@ -172,17 +180,18 @@ def main():
             groups[g]["hbm"] += rb + wb
         lines.append("| " + " | ".join(row) + " |")
     lines.append("")
-    lines.append(f"**total**: {tot['us']:.0f} us per forward (serial launches), {tot['fl'] / 1e9:.0f} GFLOP -> "
-                 f"{tot['fl'] / tot['us'] / 1e6:.1f} TFLOP/s = {tot['fl'] / tot['us'] / 1e6 / 157.3:.3f} of the fp32 MFMA peak (157.3)"
+    lines.append(f"**total**: {tot['us']:.0f} us per forward (serial launches), {tot['fl'] / 1e9:.0f} GFLOP algorithmic -> "
+                 f"{tot['fl'] / tot['us'] / 1e6:.1f} TFLOP/s; {tot['fx'] / 1e9:.0f} GFLOP executed on the matrix pipe -> "
+                 f"{tot['fx'] / tot['us'] / 1e6:.1f} TFLOP/s = {tot['fx'] / tot['us'] / 1e6 / 157.3:.3f} of the fp32 MFMA peak (157.3)"
                  + (f"; MFMA busy {tot['mfma'] / tot['simd']:.2f} of SIMD cycles" if sq else "")
                  + (f"; HBM traffic (PMC) {(tot['rb'] + tot['wb']) / 1e9:.2f} GB = read {tot['rb'] / 1e9:.2f} + write {tot['wb'] / 1e9:.2f} "
                     f"-> {(tot['rb'] + tot['wb']) / tot['us'] / 1e3:.0f} GB/s = {(tot['rb'] + tot['wb']) / tot['us'] / 1e3 / 8000:.3f} of 8 TB/s; "
                     f"algorithmic per-layer bytes {tot['by'] / 1e9:.2f} GB" if fe and wr else ""))
     lines.append("")
-    gh = ["group", "us", "share", "TFLOP/s"] + (["MFMA busy"] if sq else []) + (["HBM GB", "GB/s"] if fe and wr else [])
+    gh = ["group", "us", "share", "TFLOP/s", "exec. TFLOP/s"] + (["MFMA busy"] if sq else []) + (["HBM GB", "GB/s"] if fe and wr else [])
     lines += ["| " + " | ".join(gh) + " |", "|" + "---|" * len(gh)]
     for g, v in groups.items():
-        r = [g, f"{v['us']:.0f}", f"{100 * v['us'] / tot['us']:.1f}%", f"{v['fl'] / v['us'] / 1e6:.1f}"]
+        r = [g, f"{v['us']:.0f}", f"{100 * v['us'] / tot['us']:.1f}%", f"{v['fl'] / v['us'] / 1e6:.1f}", f"{v['fx'] / v['us'] / 1e6:.1f}"]
         if sq:
             r.append(f"{v['mfma'] / v['simd']:.2f}" if v["simd"] else "-")
         if fe and wr:
@@ -193,8 +202,15 @@ def main():
     if a.md:
         open(a.md, "w").write(txt + "\n")
     if a.json and fe and wr:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import kernel_source_hash
         json.dump({"bytes_per_step_B32_T500": tot["rb"] + tot["wb"], "read_bytes": tot["rb"], "write_bytes": tot["wb"],
-                   "algorithmic_bytes_per_layer_model": tot["by"], "kernel_us_serial": tot["us"]}, open(a.json, "w"), indent=1)
+                   "algorithmic_bytes_per_layer_model": tot["by"], "kernel_us_serial": tot["us"],
+                   "flops_algorithmic": tot["fl"], "flops_executed": tot["fx"],
+                   "kernel_source_hash": kernel_source_hash(),
+                   "kernel_version": "PMC capture (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950, serial "
+                                     "launches) of the kernel sources with this hash"}, open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
