@@ -26,6 +26,8 @@
 // outputs against 1e-7 for the direct form); the direct kernels remain (option "wino" = 0).
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "conv_epilogue32.h"
 
@@ -56,8 +58,9 @@ struct WinoArgs {
   int gx, gy, B;  // time tiles, 128-row tiles, utterances
 };
 
-// B^T rows (point p, input m) and A^T (output a, point p) of F(4,3) at the points 0, 1, -1, 2, -1/2, inf
-__constant__ float kWinoBT[6][6] = {{0.5f, 0.75f, -1.0f, -0.75f, 0.5f, 0.0f}, {0.0f, 1.0f, 2.5f, 0.5f, -1.0f, 0.0f},
+// B^T rows (point p, input m) of F(4,3) at the points 0, 1, -1, 2, -1/2, inf (documentation: the kernel evaluates them
+// through wino_bt<P> below); A^T is written out in the epilogue
+[[maybe_unused]] static const float kWinoBT[6][6] = {{0.5f, 0.75f, -1.0f, -0.75f, 0.5f, 0.0f}, {0.0f, 1.0f, 2.5f, 0.5f, -1.0f, 0.0f},
                                     {0.0f, 1.0f, 0.5f, -2.5f, 1.0f, 0.0f},    {0.0f, -0.5f, -1.0f, 0.5f, 1.0f, 0.0f},
                                     {0.0f, -1.0f, 0.5f, 1.0f, -0.5f, 0.0f},   {0.0f, 0.5f, 0.75f, -1.0f, -0.75f, 0.5f}};
 // G rows matching the scaling of kWinoBT (host, double)
@@ -67,6 +70,19 @@ static const double kWinoG[6][3] = {{2.0, 0.0, 0.0},
                                     {1.0 / 15.0, 2.0 / 15.0, 4.0 / 15.0},
                                     {32.0 / 15.0, -16.0 / 15.0, 8.0 / 15.0},
                                     {0.0, 0.0, 2.0}};
+
+// row P of B^T applied to six neighbouring samples, written out per point (3-5 operations instead of 6: the rows have
+// 4-5 non-zero entries, half of them +-1)
+template <int P>
+__device__ __forceinline__ float wino_bt(float r0, float r1, float r2, float r3, float r4, float r5) {
+  if constexpr (P == 0) return fmaf(0.75f, r1 - r3, 0.5f * (r0 + r4)) - r2;
+  if constexpr (P == 1) return fmaf(0.5f, r3, fmaf(2.5f, r2, r1 - r4));
+  if constexpr (P == 2) return fmaf(-2.5f, r3, fmaf(0.5f, r2, r1 + r4));
+  if constexpr (P == 3) return fmaf(0.5f, r3 - r1, r4 - r2);
+  if constexpr (P == 4) return fmaf(0.5f, r2 - r4, r3 - r1);
+  if constexpr (P == 5) return fmaf(0.75f, r2 - r4, 0.5f * (r1 + r5)) - r3;
+  return 0.f;
+}
 
 #ifndef DISSC_WINO_LB
 #define DISSC_WINO_LB 3
@@ -192,9 +208,6 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   const int e0 = ttau * W + tphi;
   const bool ok1 = tphi + D < W;
   const int e1 = ok1 ? e0 + D : e0;
-  float bt[6];
-#pragma unroll
-  for (int m = 0; m < 6; ++m) bt[m] = kWinoBT[p][m];
   float* vp = vbuf + wave * (8 * XV);
 
   // ---- B fragment offsets: column (ni * 32 + l31) -> (tau, rho) -> tau * W + rho, k half h -> row h
@@ -251,33 +264,34 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
       // beyond the last column duplicate it)
       if (!(a.dbg & 1)) {
         const float* rw = raw + (sc * 8) * CHF + toff;
+        auto transform8 = [&](auto pc) {
+          constexpr int P = decltype(pc)::value;
 #pragma unroll
-        for (int i0 = 0; i0 < 8; i0 += 2) {
-          f32x4 lo[2], hi[2];
+          for (int i0 = 0; i0 < 8; i0 += 2) {
+            f32x4 lo[2], hi[2];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            lo[i] = *reinterpret_cast<const f32x4*>(rw + (i0 + i) * CHF);
-            hi[i] = *reinterpret_cast<const f32x4*>(rw + (i0 + i) * CHF + 4);
-          }
+            for (int i = 0; i < 2; ++i) {
+              lo[i] = *reinterpret_cast<const f32x4*>(rw + (i0 + i) * CHF);
+              hi[i] = *reinterpret_cast<const f32x4*>(rw + (i0 + i) * CHF + 4);
+            }
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            float v0 = bt[0] * lo[i][0];
-            v0 = fmaf(bt[1], lo[i][1], v0);
-            v0 = fmaf(bt[2], lo[i][2], v0);
-            v0 = fmaf(bt[3], lo[i][3], v0);
-            v0 = fmaf(bt[4], hi[i][0], v0);
-            v0 = fmaf(bt[5], hi[i][1], v0);
-            vp[(i0 + i) * XV + e0] = v0;
-            if constexpr (NS > 1) {
-              float v1 = bt[0] * lo[i][1];
-              v1 = fmaf(bt[1], lo[i][2], v1);
-              v1 = fmaf(bt[2], lo[i][3], v1);
-              v1 = fmaf(bt[3], hi[i][0], v1);
-              v1 = fmaf(bt[4], hi[i][1], v1);
-              v1 = fmaf(bt[5], hi[i][2], v1);
-              vp[(i0 + i) * XV + e1] = ok1 ? v1 : v0;
+            for (int i = 0; i < 2; ++i) {
+              const float v0 = wino_bt<P>(lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1]);
+              vp[(i0 + i) * XV + e0] = v0;
+              if constexpr (NS > 1) {
+                const float v1 = wino_bt<P>(lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2]);
+                vp[(i0 + i) * XV + e1] = ok1 ? v1 : v0;
+              }
             }
           }
+        };
+        switch (p) {  // uniform per wave
+          case 0: transform8(std::integral_constant<int, 0>{}); break;
+          case 1: transform8(std::integral_constant<int, 1>{}); break;
+          case 2: transform8(std::integral_constant<int, 2>{}); break;
+          case 3: transform8(std::integral_constant<int, 3>{}); break;
+          case 4: transform8(std::integral_constant<int, 4>{}); break;
+          default: transform8(std::integral_constant<int, 5>{}); break;
         }
       }
       // ---- NS taps x 4 k-steps on V_p; the B fragments of tap j + 1 and the A fragments of block blk + 2 are fetched

@@ -7,7 +7,7 @@ from dissc_amd._lib import check
 L = dissc_amd.lib
 shapes = [(256, 11, 1, 2500), (256, 7, 1, 2500), (256, 3, 1, 2500), (128, 11, 5, 10000)]
 for C, k, d, Ln in shapes:
-  for cpr in (16, 32):
+  for cpr in (32,):
     check(L.dissc_set_option(b"wino_cpr", cpr), "opt")
     out = [f"cpr{cpr}"]
     for dbg in (0, 1, 2, 4, 8, 1 | 8, 1 | 4 | 8, 2 | 4, 1 | 2 | 8, 15):
@@ -15,7 +15,7 @@ for C, k, d, Ln in shapes:
         ms = ctypes.c_float()
         best = 1e9
         for rep in range(2):
-            check(L.dissc_conv_bench(32, C, C, k, d, Ln, 0, 20, 2, ctypes.byref(ms)), "bench")
+            check(L.dissc_conv_bench(int(os.environ.get("WINO_B", "32")), C, C, k, d, Ln, 0, 20, 2, ctypes.byref(ms)), "bench")
             best = min(best, ms.value)
         out.append(f"dbg{dbg}: {best*1e3:6.0f}")
     print(f"C{C} k{k} d{d} (us): " + " | ".join(out), flush=True)
