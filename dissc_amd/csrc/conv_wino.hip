@@ -255,11 +255,12 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   int blk = 0;
   for (int rd = 0; rd < nround; ++rd) {
     const float* raw = lds + (rd & 1) * (CPR * CHF);
-    if (!(a.dbg & 8)) {
-      if (rd + 1 < nround) stage_store(lds + ((rd + 1) & 1) * (CPR * CHF));
-      if (rd + 2 < nround) stage_load(rd + 2);
-    }
+    if (!(a.dbg & 8) && rd + 1 < nround) stage_store(lds + ((rd + 1) & 1) * (CPR * CHF));
     for (int sc = 0; sc < CPR / 8; ++sc) {
+      // The loads of round rd + 2 are issued at a DIFFERENT sub-chunk by each of the three waves of a SIMD: vmcnt retires
+      // in order, so a wave cannot consume a weight fragment fetched after its window loads before those have landed
+      // (~2 us from HBM) -- staggered, the other two waves of the SIMD keep the matrix pipe busy meanwhile
+      if (!(a.dbg & 8) && rd + 2 < nround && sc == (wave >> 2) % (CPR / 8)) stage_load(rd + 2);
       // ---- V_p[i][e] of channels sc * 8 + i (branch-free: lanes without a second entry rewrite their first one, lanes
       // beyond the last column duplicate it)
       if (!(a.dbg & 1)) {
