@@ -114,3 +114,20 @@ def test_bench_on_rccl_world_size_one():
     st = j["strong"]
     assert st["jobs"] == 1024 and st["exchange"]["collectives"] == 1 and st["value"] > 200
     assert st["exchange"]["sent_bytes_per_rank"] <= 1.1 * st["exchange"]["payload_bytes_this_rank"]
+
+
+def test_bench_two_ranks_sharing_this_gpu():
+    """bench.py --gpus 2 on the HIP path with both ranks on this box's one GPU (gloo stages the device tensors through
+    the host; RCCL needs one GPU per rank): the weak-scaling step with its all-gather, and the strong-scaling leg with
+    the job list really split over two ranks -- per-rank compute times, one collective, LPT imbalance close to 1."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-split-bf16", "--no-pipeline", "--no-d2h"],
+                       env=_env(DISSC_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "gloo" in j["config"]["collective"]
+    st = j["strong"]
+    assert st["jobs"] == 1024 and len(st["per_rank_compute_ms"]) == 2 and st["exchange"]["collectives"] == 1
+    assert 1.0 <= st["load_imbalance"] < 1.01 and st["value"] > 200
+    # each rank sends its half of the waveforms (plus table and 16-byte row padding), not a dense matrix
+    assert st["exchange"]["sent_bytes_per_rank"] <= 0.55 * 4 * 16000 * st["audio_sec"]
