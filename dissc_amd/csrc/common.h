@@ -99,8 +99,6 @@ extern int g_small_grid;
 void conv32_set_cfg(int bm_class, int cfg);
 void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
                          int& Mpad, int& nchunk, int groups);
-extern int g_stream16;
-int try_launch_conv16_stream(const ConvArgs& a, int B, int Lmax, int stride, hipStream_t stream);
 extern int g_attn_fused;
 extern int g_lin_tile;
 extern int g_cpb2;
@@ -182,14 +180,6 @@ double wino_executed_macs_per_t(int C, int KS);
 int run_wino(const DevConv& dc, const float* x, float* out, const float* res, float* acc, const int32_t* lengths,
              int len_default, int len_mul, int B, int ldx, int ldo, int Lmax, float slope, int epi, float mrf_div,
              hipStream_t stream);
-
-// fused ResBlock1 for narrow stages (resblock_fused.hip)
-bool resblock_fused_supported(int C, int KS, const int* dil);
-void fused_set_option(int which, int value);  // 0: BN for C=16, 1: BN for C=32, 2: max C (0 = off)
-int launch_resblock_fused(int C, const float* x, float* acc, const float* wpack, const float* bias,
-                          const int32_t* lengths, int len_default, int len_mul, int KS, const int* dil,
-                          int B, int Lmax, int ld, float slope, int epi, float mrf_div,
-                          hipStream_t stream);
 
 // one residual pair y = x + conv_1(lrelu(conv_d(lrelu(x)))) per launch, exact fp32 (respair.hip)
 extern int g_pair_pad_lds;

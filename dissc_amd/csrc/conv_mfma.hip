@@ -406,10 +406,6 @@ int launch_conv(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t 
   }
   if (a.m32) return launch_conv32(a, B, Lmax_out, stride, stream);
   // (the 16x16x4 kernel ignores a.mfast)
-  {
-    const int r = try_launch_conv16_stream(a, B, Lmax_out, stride, stream);  // C=16 streaming kernel
-    if (r != 0) return r < 0 ? r : DISSC_OK;
-  }
   const int cfg = conv_cfg(a.M);
   if (stride == 2 && span <= MAX_TAP_SPAN && a.up == 1) {
     // HuBERT feature convs (512 -> 512, k3/k2 s2): only the 256x64 tile is instantiated

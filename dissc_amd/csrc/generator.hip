@@ -71,8 +71,8 @@ struct dissc_gen {
   DevConv conv_pre;
   std::vector<std::vector<DevConv>> ups;  // per stage: one conv per phase group
   std::vector<DevConv> rb1, rb2;  // [stage*nk*3 + j*3 + m]
-  std::vector<float*> fused_w, fused_b;  // [stage*nk + j]: 6 packed convs / biases of a fused ResBlock
-  std::vector<char> fused_bf3;           // ... packed for the split-bf16 kernel (resblock_bf3.hip)
+  std::vector<float*> fused_w, fused_b;  // [stage*nk + j]: 6 packed convs / biases of a split-bf16 fused ResBlock
+  std::vector<char> fused_bf3;           // ... (resblock_bf3.hip; precision = 1 only)
   float* post_w = nullptr;
   float* post_b = nullptr;
   int post_C = 0, post_KS = 0;
@@ -237,7 +237,6 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         return fail(DISSC_EINVAL);
       }
       const bool bf3 = prec == 1 && resblock_bf3_supported(ch, rk, cfg->resblock_dilations[j]);
-      const bool fuse = !bf3 && resblock_fused_supported(ch, rk, cfg->resblock_dilations[j]);
       std::vector<float> fw, fb;
       const float* w6[6];
       for (int m = 0; m < 3; ++m) {
@@ -254,13 +253,6 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
           w6[2 * m] = w;
           fb.insert(fb.end(), b, b + ch);
         }
-        if (fuse) {
-          std::vector<float> pk;
-          int mp, nc;
-          pack_conv_weights(w, ch, ch, rk, pk, mp, nc);
-          fw.insert(fw.end(), pk.begin(), pk.end());
-          fb.insert(fb.end(), b, b + ch);
-        }
         snprintf(name, sizeof(name), "resblocks.%d.convs2.%d.weight", i * nk + j, m);
         if ((rc = get(name, {ch, ch, rk}, &w))) return fail(rc);
         snprintf(name, sizeof(name), "resblocks.%d.convs2.%d.bias", i * nk + j, m);
@@ -272,19 +264,12 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
           w6[2 * m + 1] = w;
           fb.insert(fb.end(), b, b + ch);
         }
-        if (fuse) {
-          std::vector<float> pk;
-          int mp, nc;
-          pack_conv_weights(w, ch, ch, rk, pk, mp, nc);
-          fw.insert(fw.end(), pk.begin(), pk.end());
-          fb.insert(fb.end(), b, b + ch);
-        }
       }
       if (bf3) {
         pack_resblock_bf3(ch, rk, w6, fw);
         g->fused_bf3[(size_t)i * nk + j] = 1;
       }
-      if (fuse || bf3) {
+      if (bf3) {
         if ((rc = upload(fw, &g->fused_w[(size_t)i * nk + j]))) return fail(rc);
         if ((rc = upload(fb, &g->fused_b[(size_t)i * nk + j]))) return fail(rc);
       }
@@ -519,9 +504,7 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
         const float* fb = g->fused_b[(size_t)i * nk + j];
         const int rk = c.resblock_kernel_sizes[j];
         const int* dl = c.resblock_dilations[j];
-        if (!g->fused_bf3[(size_t)i * nk + j]) {
-          rc = launch_resblock_fused(ch, X, ACC, fw, fb, lengths, L, mul, rk, dl, B, L, ld, 0.1f, epi, (float)nk, sj);
-        } else if (!pairs) {
+        if (!pairs) {
           rc = launch_resblock_bf3(ch, X, ACC, fw, fb, lengths, L, mul, rk, dl, B, L, ld, 0.1f, epi, (float)nk, 0, 3, sj);
         } else {  // X -> XK -> TMP -> MRF update of ACC, one launch per residual pair
           float* xk = multi ? XKj[j] : XKj[0];
@@ -700,15 +683,12 @@ int dissc_set_option(const char* key, int value) {
     conv_set_cfg(cls, value);
     return DISSC_OK;
   }
-  if (strcmp(key, "fused_bn16") == 0) { fused_set_option(0, value); return DISSC_OK; }
-  if (strcmp(key, "fused_bn32") == 0) { fused_set_option(1, value); return DISSC_OK; }
   if (strcmp(key, "precision") == 0) { g_precision = value; return DISSC_OK; }
   if (strcmp(key, "par_ups") == 0) { g_par_ups = value; return DISSC_OK; }
   if (strcmp(key, "small_grid") == 0) { g_small_grid = value; return DISSC_OK; }
   if (strcmp(key, "bf3_pairs") == 0) { resblock_bf3_set_pairs(value); return DISSC_OK; }
   if (strcmp(key, "stream_prio") == 0) { g_stream_prio = value; return DISSC_OK; }
   if (strcmp(key, "multistream") == 0) { g_multistream = value; return DISSC_OK; }
-  if (strcmp(key, "stream16") == 0) { g_stream16 = value; return DISSC_OK; }
   if (strcmp(key, "attn_fused") == 0) { g_attn_fused = value; return DISSC_OK; }
   if (strcmp(key, "lin_tile") == 0) { g_lin_tile = value; return DISSC_OK; }
   if (strcmp(key, "cpb2") == 0) { g_cpb2 = value; return DISSC_OK; }
@@ -731,16 +711,11 @@ int dissc_set_option(const char* key, int value) {
     conv32_set_cfg(cls, value);
     return DISSC_OK;
   }
-  if (strcmp(key, "fused_max_c") == 0) { fused_set_option(2, value); return DISSC_OK; }
   if (strcmp(key, "pair_max_c") == 0) { g_pair_max_c = value; return DISSC_OK; }
   if (strcmp(key, "pair_pad_lds") == 0) { g_pair_pad_lds = value; return DISSC_OK; }
   if (strcmp(key, "conv_pad_lds") == 0) { g_conv_pad_lds = value; return DISSC_OK; }
   if (strcmp(key, "pair_lds") == 0) { g_pair_lds_mode = value; return DISSC_OK; }
-  if (strcmp(key, "fused_variant") == 0) {
-    fused_set_option(3, value);
-    resblock_bf3_set_variant(value);
-    return DISSC_OK;
-  }
+  if (strcmp(key, "fused_variant") == 0) { resblock_bf3_set_variant(value); return DISSC_OK; }
   set_error("dissc_set_option: unknown key %s", key);
   return DISSC_EINVAL;
 }

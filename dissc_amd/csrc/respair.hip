@@ -11,7 +11,7 @@
 // intermediate (<= 5), so nothing worth mentioning is recomputed, the LDS footprint stays at
 // ~40 KB (3-4 workgroups per CU overlap each other's staging, MFMA and store phases) and the three
 // chains of a stage keep running concurrently on their streams (only a chain's LAST pair waits for
-// the MRF accumulator).  The whole-block kernel (resblock_fused.hip) recomputes a 60-column halo per
+// the MRF accumulator).  The whole-block kernel (resblock_fused.hip, rounds 1-2, removed) recomputed a 60-column halo per
 // side and was break-even.
 //
 // fp32 VALU work steals issue slots from fp32 MFMAs on gfx950 (tools/pipe_overlap.py), so the tap

@@ -26,6 +26,6 @@ e1.record(); torch.cuda.synchronize()
 print(json.dumps(opts), round(e0.elapsed_time(e1) / 10, 3), "ms/step")
 ''' % ROOT
 import json
-SETS = [json.loads(x) for x in sys.argv[1:]] or [{"fused_max_c": 0}, {"fused_max_c": 16}]
+SETS = [json.loads(x) for x in sys.argv[1:]] or [{"wino": 1}, {"wino": 0}]
 for opts in SETS:
     subprocess.run([sys.executable, "-c", CODE, json.dumps(opts)], check=False)
