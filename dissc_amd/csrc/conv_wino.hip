@@ -38,6 +38,7 @@ int g_wino = 1;          // "wino" option: 1 = wide ResBlock convs through conv_
 int g_wino_min_c = 64;   // "wino_min_c" option: narrowest stage that uses it
 int g_wino_c64_kmin = 11;  // "wino_c64_kmin" option: smallest kernel size that uses it in a 64-channel stage (measured: k = 3 / 7
                          // are break-even or slower there, the 4-chunk K loop is too short to amortise the transforms)
+int g_wino_small = 96;   // "wino_small" option: launches with fewer 64 x 64-tile workgroups than this use 32 x 32 wave tiles
 int g_wino_dbg = 0;      // "wino_dbg" option (diagnostics): knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue, 3 staging
 
 struct WinoArgs {
@@ -112,14 +113,16 @@ constexpr int wino_row_len(int D, int NTU, int XRW) {
   return need;
 }
 
-template <int NS, int DIL, int CPR, int RH>
+template <int NS, int DIL, int CPR, int RH, int TW>
 __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const WinoArgs a) {
   constexpr int NTH = 768;                    // 12 waves: 6 points x 2 row halves (3 waves on every SIMD)
   constexpr int D = DIL * NS;                 // sample step of the F(4,3) sequences
   constexpr int W = DIL * (2 * NS - 1);       // V entries per tile unit
   constexpr int CHV = 3 - RH;                 // column halves per workgroup (RH = 2 row halves -> 1, RH = 1 -> 2)
-  constexpr int NTU = 64 / D;                 // tile units per wave
-  constexpr int NCOL = NTU * D;               // transform-domain columns of a wave in use (<= 64)
+  constexpr int MI = TW, NI = TW;             // wave tile = (32 MI) rows x (32 NI) columns: 64 x 64, or 32 x 32 on small grids
+  constexpr int TC = 32 * NI;                 // columns per wave
+  constexpr int NTU = TC / D;                 // tile units per wave
+  constexpr int NCOL = NTU * D;               // transform-domain columns of a wave in use (<= TC)
   constexpr int OT = 4 * D * NTU * CHV;       // outputs per workgroup tile
   constexpr int RAW = OT + DIL * (3 * NS - 1);  // input window
   constexpr int XRW = (RAW + 3 + 3) / 4 * 4;  // staged positions per channel (alignment shift <= 3)
@@ -129,8 +132,8 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   constexpr int VROW = NTU * W;               // V entries per channel (<= 112)
   constexpr int XV = 112;                     // V row stride (112 % 32 == 16: the two k halves of a fragment read hit different banks)
   constexpr int SV = (CPR * NV + NTH - 1) / NTH;
-  constexpr int YS = 68;                      // row stride of the epilogue exchange (64 columns + 4)
-  static_assert(VROW <= XV && NCOL <= 64, "tile geometry");
+  constexpr int YS = TC + 4;                  // row stride of the epilogue exchange
+  static_assert(VROW <= XV && NCOL <= TC && NTU >= 1, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // 2 x [CPR][D][RL]: window sample x (position o + x) of a channel at [(x + 4 D) % D][(x + 4 D) / D]
   float* vbuf = lds + 2 * CPR * CHF;  // [12 waves][8][XV]
@@ -140,7 +143,7 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   // pinned to XCD groups so that an L2 holds ONE tile's weights, and the time tiles / utterances are spread inside a group
   const int per = 8 / a.gy;
   const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
-  const int mt = xcd / per;  // row tile (64 RH rows)
+  const int mt = xcd / per;  // row tile (32 MI RH rows)
   const int lin = (xcd - mt * per) + per * kq;
   if (lin >= a.gx * a.B) return;
   const int b = lin / a.gx;
@@ -211,39 +214,37 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   float* vp = vbuf + wave * (8 * XV);
 
   // ---- B fragment offsets: column (ni * 32 + l31) -> (tau, rho) -> tau * W + rho, k half h -> row h
-  int voff[2];
+  int voff[NI];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
+  for (int ni = 0; ni < NI; ++ni) {
     int col = ni * 32 + l31;
     col = col < NCOL ? col : NCOL - 1;
     voff[ni] = (col / D) * W + (col % D) + h * XV;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
   // A fragments: one float4 per lane = the 4 k-steps (8 channels) of one (chunk, tap, half): [chunk][tap][half][lane]
   const int nsub = a.C / 32;
   const int nblk = a.nchunk * NS * 2;  // (chunk, half, tap) blocks, walked in this order
-  const f32x4* wp[2];
-  f32x4 av[2], avn[2];
+  const f32x4* wp[MI];
+  f32x4 av[MI], avn[MI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * (2 * RH) + mh * 2 + mi) * (a.nchunk * NS) * 128 + lane;
+  for (int mi = 0; mi < MI; ++mi)
+    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * (MI * RH) + mh * MI + mi) * (a.nchunk * NS) * 128 + lane;
   auto wofs = [&](int blk) {  // blk = (chunk * 2 + half) * NS + tap -> float4 offset
     const int tap = blk % NS, ch2 = blk / NS;
     return (size_t)((ch2 >> 1) * NS + tap) * 128 + (ch2 & 1) * 64;
   };
 
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    av[mi] = wp[mi][wofs(0)];
-  }
+  for (int mi = 0; mi < MI; ++mi) av[mi] = wp[mi][wofs(0)];
   stage_load(0);
   stage_store(lds);
   if (nround > 1) stage_load(1);  // the staging registers always hold the round after the newest one in LDS
@@ -298,40 +299,43 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
       // ---- NS taps x 4 k-steps on V_p; the B fragments of tap j + 1 and the A fragments of block blk + 2 are fetched
       // behind the MFMAs of tap j
       if (!(a.dbg & 2)) {
-        const float* bj[2] = {vp + voff[0], vp + voff[1]};
-        float b0[2], b0n[2], bk[3][2];
+        const float* bj[NI];
+        float b0[NI], b0n[NI], bk[3][NI];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) b0[ni] = bj[ni][0];
+        for (int ni = 0; ni < NI; ++ni) {
+          bj[ni] = vp + voff[ni];
+          b0[ni] = bj[ni][0];
+        }
 #pragma unroll
         for (int j = 0; j < NS; ++j, ++blk) {
           const int bn = (blk + 1 < nblk) ? blk + 1 : nblk - 1;
           const size_t wo = wofs(bn);
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) avn[mi] = wp[mi][wo];
+          for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][wo];
 #pragma unroll
           for (int s = 1; s < 4; ++s)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bk[s - 1][ni] = bj[ni][s * 2 * XV + j * DIL];
+            for (int ni = 0; ni < NI; ++ni) bk[s - 1][ni] = bj[ni][s * 2 * XV + j * DIL];
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) b0n[ni] = (j + 1 < NS) ? bj[ni][(j + 1) * DIL] : 0.f;  // next tap's first k-step
+          for (int ni = 0; ni < NI; ++ni) b0n[ni] = (j + 1 < NS) ? bj[ni][(j + 1) * DIL] : 0.f;  // next tap's first k-step
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+          for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][0], b0[ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
           for (int s = 1; s < 4; ++s)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-              for (int ni = 0; ni < 2; ++ni)
+              for (int ni = 0; ni < NI; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][s], bk[s - 1][ni], acc[mi][ni], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) b0[ni] = b0n[ni];
+          for (int ni = 0; ni < NI; ++ni) b0[ni] = b0n[ni];
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) av[mi] = avn[mi];
+          for (int mi = 0; mi < MI; ++mi) av[mi] = avn[mi];
         }
       } else {
         blk += NS;
@@ -351,12 +355,12 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   const int epi = a.epi;
   const size_t ob = (size_t)b * a.o_bstride;
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {  // 32 rows x 64 columns per pass: (row or column half, 32-row subtile)
-    const int phalf = ps >> 1, mi = ps & 1;
+  for (int ps = 0; ps < 2 * MI; ++ps) {  // 32 rows x TC columns per pass: (row or column half, 32-row subtile)
+    const int phalf = ps / MI, mi = ps % MI;
     if (ps > 0) __syncthreads();
     if ((RH == 2 ? mh : chh) == phalf) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           yb[(p * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * YS + ni * 32 + l31] = acc[mi][ni][r];
@@ -367,7 +371,7 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
       const int tau = qi / D, g = qi - tau * D;
       const int n0 = t0 + 4 * D * ((RH == 2 ? 0 : phalf * NTU) + tau) + 4 * g;
       if (n0 >= len) continue;
-      const int grow = mt * (64 * RH) + (RH == 2 ? ps * 32 : mi * 32) + row;
+      const int grow = mt * (32 * MI * RH) + (RH == 2 ? ps * 32 : mi * 32) + row;
       const float bz = a.bias[grow];
       const float* yr = yb + row * YS + tau * D;
       f32x4 v;
@@ -493,22 +497,22 @@ int make_wino(const float* w, const float* bias, int C, int KS, int dil, DevConv
 // MACs the matrix pipe executes per output position (6 NS / 4 per input/output channel pair)
 double wino_executed_macs_per_t(int C, int KS) { return (double)C * C * 6.0 * ((KS + 2) / 3) / 4.0; }
 
-template <int NS, int DIL, int CPR, int RH>
+template <int NS, int DIL, int CPR, int RH, int TW>
 static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream) {
   constexpr int CHV = 3 - RH;
-  constexpr int D = DIL * NS, NTU = 64 / D, OT = 4 * D * NTU * CHV, RAW = OT + DIL * (3 * NS - 1), XRW = (RAW + 6) / 4 * 4;
+  constexpr int D = DIL * NS, NTU = 32 * TW / D, OT = 4 * D * NTU * CHV, RAW = OT + DIL * (3 * NS - 1), XRW = (RAW + 6) / 4 * 4;
   constexpr int RL = wino_row_len(D, NTU * CHV, XRW);
   size_t lds_f = (size_t)2 * CPR * D * RL + 12 * 8 * 112;
-  if (lds_f < (size_t)6 * 32 * 68) lds_f = (size_t)6 * 32 * 68;
+  if (lds_f < (size_t)6 * 32 * (32 * TW + 4)) lds_f = (size_t)6 * 32 * (32 * TW + 4);
   static bool attr_done = false;
   if (!attr_done) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, DIL, CPR, RH>),
+    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, DIL, CPR, RH, TW>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   WinoArgs aa = a;
   aa.gx = (Lmax + OT - 1) / OT;
-  aa.gy = a.C / (64 * RH);
+  aa.gy = a.C / (32 * TW * RH);
   aa.B = B;
   if (8 % aa.gy != 0) {
     set_error("launch_wino: %d row tiles do not divide the 8 XCDs", aa.gy);
@@ -516,7 +520,7 @@ static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
   }
   const int per = 8 / aa.gy;
   dim3 grid(8 * ((aa.gx * B + per - 1) / per));
-  hipLaunchKernelGGL((conv_wino_kernel<NS, DIL, CPR, RH>), grid, dim3(768), lds_f * sizeof(float), stream, aa);
+  hipLaunchKernelGGL((conv_wino_kernel<NS, DIL, CPR, RH, TW>), grid, dim3(768), lds_f * sizeof(float), stream, aa);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
@@ -524,9 +528,21 @@ static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
 int g_wino_cpr = 32;  // "wino_cpr" option: channels per barrier round (16 or 32)
 template <int NS, int DIL>
 static int launch_wino_t(const WinoArgs& a, int B, int Lmax, hipStream_t stream) {
-  if (a.C % 128 != 0) return launch_wino_c<NS, DIL, 16, 1>(a, B, Lmax, stream);  // 64 rows x 128 columns
-  if (g_wino_cpr == 32 && a.nchunk % 2 == 0) return launch_wino_c<NS, DIL, 32, 2>(a, B, Lmax, stream);
-  return launch_wino_c<NS, DIL, 16, 2>(a, B, Lmax, stream);
+  // Small grids (a short or single utterance: the reference's one-at-a-time mode) step down to 32 x 32 wave tiles: four
+  // times the workgroups.  Every output element sees the same MFMA sequence and the same transforms for either tile,
+  // so the result is bit-identical and an utterance's samples stay independent of the batch it runs in.
+  constexpr int D = DIL * NS;
+  const bool c64 = a.C % 128 != 0;
+  const int ot = 4 * D * (64 / D) * (c64 ? 2 : 1);
+  const long long nwg = (long long)((Lmax + ot - 1) / ot) * (c64 ? a.C / 64 : a.C / 128) * B;
+  const bool small = g_small_grid && nwg < (long long)g_wino_small;
+  if (c64) {
+    if (small) return launch_wino_c<NS, DIL, 16, 1, 1>(a, B, Lmax, stream);  // 32 rows x 64 columns
+    return launch_wino_c<NS, DIL, 16, 1, 2>(a, B, Lmax, stream);            // 64 rows x 128 columns
+  }
+  if (small) return launch_wino_c<NS, DIL, 16, 2, 1>(a, B, Lmax, stream);    // 64 rows x 32 columns
+  if (g_wino_cpr == 32 && a.nchunk % 2 == 0) return launch_wino_c<NS, DIL, 32, 2, 2>(a, B, Lmax, stream);
+  return launch_wino_c<NS, DIL, 16, 2, 2>(a, B, Lmax, stream);
 }
 
 int run_wino(const DevConv& dc, const float* x, float* out, const float* res, float* acc, const int32_t* lengths,

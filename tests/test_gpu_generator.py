@@ -95,8 +95,14 @@ def test_toom_cook_conv_matches_torch_and_the_direct_kernel(env, C, k, d):
         for mode in (0, 2):
             assert lib.dissc_set_option(b"wino", mode) == 0
             out[mode] = _run_conv(env, x, w, b, lengths, k, d, 0.1)
+        # this launch is small (8 utterances x 1000 columns): it ran on 32 x 32 wave tiles.  The 64 x 64 tiles of a
+        # chip-filling launch ("small_grid" = 0 forces them) must give the same bits.
+        assert lib.dissc_set_option(b"small_grid", 0) == 0
+        big = _run_conv(env, x, w, b, lengths, k, d, 0.1)
     finally:
         lib.dissc_set_option(b"wino", 1)
+        lib.dissc_set_option(b"small_grid", 1)
+    assert torch.equal(big, out[2])
     assert not torch.equal(out[0], out[2])  # really another evaluation order
     se = {0: 0.0, 2: 0.0}
     cnt = 0

@@ -14,7 +14,7 @@ g.load_state_dict(synth.synth_generator_state_dict(0))
 g.eval().remove_weight_norm()
 print("| B | ms/forward | audio-sec/sec | TFLOP/s |")
 print("|---|---|---|---|")
-for B in (1, 2, 4, 8, 16, 32, 64):
+for B in [int(v) for v in os.environ.get("BATCHES", "1,2,4,8,16,32,64").split(",")]:
     code, f0, spkr, _ = synth.synth_generator_inputs(B, 500, seed=1)
     c, f, s = torch.from_numpy(code).cuda(), torch.from_numpy(f0).cuda(), torch.from_numpy(spkr).cuda()
     for _ in range(3):
