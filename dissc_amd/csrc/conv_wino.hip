@@ -357,6 +357,23 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
 #pragma unroll
   for (int ps = 0; ps < 2 * MI; ++ps) {  // 32 rows x TC columns per pass: (row or column half, 32-row subtile)
     const int phalf = ps / MI, mi = ps % MI;
+    // this thread's residual quads of the pass are fetched BEFORE the exchange (one workgroup fills the CU:
+    // nothing else would cover their HBM latency); ragged tails take the scalar path below
+    constexpr int NIT = (32 * NCOL + NTH - 1) / NTH;
+    f32x4 pres[NIT];
+    if (epi != EPI_STORE) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NTH;
+        const int row = idx / NCOL, qi = idx - row * NCOL;
+        const int tau = qi / D, g = qi - tau * D;
+        const int n0 = t0 + 4 * D * ((RH == 2 ? 0 : phalf * NTU) + tau) + 4 * g;
+        if (idx < 32 * NCOL && n0 + 4 <= len) {
+          const size_t ix = ob + (size_t)(mt * (32 * MI * RH) + (RH == 2 ? ps * 32 : mi * 32) + row) * a.ldo + n0;
+          pres[it] = *reinterpret_cast<const f32x4*>(a.res + ix);
+        }
+      }
+    }
     if (ps > 0) __syncthreads();
     if ((RH == 2 ? mh : chh) == phalf) {
 #pragma unroll
@@ -366,7 +383,10 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
           yb[(p * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * YS + ni * 32 + l31] = acc[mi][ni][r];
     }
     __syncthreads();
-    for (int idx = tid; idx < 32 * NCOL; idx += NTH) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * NTH;
+      if (idx >= 32 * NCOL) continue;
       const int row = idx / NCOL, qi = idx - row * NCOL;
       const int tau = qi / D, g = qi - tau * D;
       const int n0 = t0 + 4 * D * ((RH == 2 ? 0 : phalf * NTU) + tau) + 4 * g;
@@ -407,7 +427,7 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
         if (epi == EPI_STORE) {
           *reinterpret_cast<f32x4*>(a.out + ix) = v;
         } else {
-          const f32x4 rs = *reinterpret_cast<const f32x4*>(a.res + ix);
+          const f32x4 rs = pres[it];
           v[0] += rs[0]; v[1] += rs[1]; v[2] += rs[2]; v[3] += rs[3];
           if (epi == EPI_RES) {
             *reinterpret_cast<f32x4*>(a.out + ix) = v;
@@ -541,7 +561,9 @@ static int launch_wino_t(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
     return launch_wino_c<NS, DIL, 16, 1, 2>(a, B, Lmax, stream);            // 64 rows x 128 columns
   }
   if (small) return launch_wino_c<NS, DIL, 16, 2, 1>(a, B, Lmax, stream);    // 64 rows x 32 columns
-  if (g_wino_cpr == 32 && a.nchunk % 2 == 0) return launch_wino_c<NS, DIL, 32, 2, 2>(a, B, Lmax, stream);
+  // (k = 11, d = 5 with 32 channels per round needs more registers than three waves per SIMD leave: 16 there)
+  if (g_wino_cpr == 32 && a.nchunk % 2 == 0 && !(NS == 4 && DIL == 5))
+    return launch_wino_c<NS, DIL, 32, 2, 2>(a, B, Lmax, stream);
   return launch_wino_c<NS, DIL, 16, 2, 2>(a, B, Lmax, stream);
 }
 
