@@ -525,9 +525,8 @@ def main():
                          "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": hbm_traffic(B, T)[0], "traffic_source": hbm_traffic(B, T)[1],
                          "kernel": "all generator convs: conv_wino_kernel (Toom-Cook F(4,3) over 3-tap sub-filters, fp32 v_mfma_f32_32x32x2) "
-                                   "on the C >= 128 ResBlocks and the k = 11 ResBlock of the C = 64 stage, conv_mfma32_kernel (direct, "
-                                   "same MFMA) elsewhere on the C >= 64 stages, respair32/respair16 fused residual pairs on the "
-                                   "C = 32 / 16 stages",
+                                   "on the ResBlocks of the C >= 64 stages, conv_mfma32_kernel (direct, same MFMA) for conv_pre and the "
+                                   "ConvTranspose layers, respair32/respair16 fused residual pairs on the C = 32 / 16 stages",
                          "algorithmic_tflops": round(ach_alg, 2),
                          "note": "achieved / frac = EXECUTED matrix-pipe FLOPs / time (<= peak by construction); "
                                  "algorithmic_tflops = direct-form FLOPs (SURVEY 8d: 321.664 MFLOP per frame) / time",

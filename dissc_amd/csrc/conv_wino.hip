@@ -36,8 +36,8 @@ namespace dissc {
 int g_wino = 1;          // "wino" option: 1 = wide ResBlock convs through conv_wino_kernel (read at dissc_gen_create);
                          // 2 = the stand-alone dissc_conv1d entry uses it too (tests)
 int g_wino_min_c = 64;   // "wino_min_c" option: narrowest stage that uses it
-int g_wino_c64_kmin = 11;  // "wino_c64_kmin" option: smallest kernel size that uses it in a 64-channel stage (measured: k = 3 / 7
-                         // are break-even or slower there, the 4-chunk K loop is too short to amortise the transforms)
+int g_wino_c64_kmin = 3;   // "wino_c64_kmin" option: smallest kernel size that uses it in a 64-channel stage (in the generator k = 3 /
+                         // 7 gain 2 % per forward there; in isolation they are break-even against the DMA-staged direct pair)
 int g_wino_small = 96;   // "wino_small" option: launches with fewer 64 x 64-tile workgroups than this use 32 x 32 wave tiles
 int g_wino_dbg = 0;      // "wino_dbg" option (diagnostics): knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue, 3 staging
 

@@ -146,8 +146,8 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   bf3_pairs (-1)       split-bf16 fused ResBlocks as three launches of one residual pair each: -1 = for >= 64
  *                        channels only, 0 = never, 1 = always
  *   fused_variant (0)    split-bf16 fused ResBlocks: 0 = 512-column windows, 1 = 1024
- *   wino (1)             read at dissc_gen_create: 1 = ResBlock convs with C >= wino_min_c (64; at C = 64 only k >=
- *                        wino_c64_kmin = 11) run in the Toom-Cook F(4,3) transform domain (conv_wino.hip), 0 = all direct,
+ *   wino (1)             read at dissc_gen_create: 1 = ResBlock convs with C >= wino_min_c (64; at C = 64 those with k >=
+ *                        wino_c64_kmin = 3) run in the Toom-Cook F(4,3) transform domain (conv_wino.hip), 0 = all direct,
  *                        2 = dissc_conv1d uses it too (tests)
  *   attn_fused (1)       HuBERT attention as one fused kernel (0: batched GEMM -> softmax -> batched GEMM)
  *   mfast (0)            M-fastest block order for convs with many M tiles

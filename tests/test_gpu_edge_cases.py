@@ -37,18 +37,27 @@ def test_batch_with_empty_and_single_frame_utterances(env):
 
 
 def test_dma_handover_of_wide_residual_pairs_on_a_poisoned_workspace(env):
-    """option "pair_dma" (default on): the first conv of a wide residual pair stores lrelu(t) with zero tails and the second
-    stages its windows by LDS-DMA without masks, relying on those zeros (a row's tail is the next row's left halo).  With
-    the scratch memory filled with NaN beforehand, a ragged batch must still give the bits of the masked path."""
-    g, synth, lib = env["g"], env["synth"], env["lib"]
+    """Direct path (a generator built with option "wino" = 0), option "pair_dma" (default on): the first conv of a wide
+    residual pair stores lrelu(t) with zero tails and the second stages its windows by LDS-DMA without masks, relying on
+    those zeros (a row's tail is the next row's left halo).  With the scratch memory filled with NaN beforehand, a ragged
+    batch must still give the bits of the masked path."""
+    import dissc_amd
+    synth, lib = env["synth"], env["lib"]
     B, T = 5, 70
     code, f0, spkr, _ = synth.synth_generator_inputs(B, T, seed=11)
     kw = dict(code=torch.from_numpy(code).cuda(), f0=torch.from_numpy(f0).cuda(), spkr=torch.from_numpy(spkr).cuda())
     lens = torch.tensor([70, 64, 33, 1, 17], dtype=torch.int32).cuda()
+    try:
+        assert lib.dissc_set_option(b"wino", 0) == 0
+        g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
+        g.load_state_dict(synth.synth_generator_state_dict(seed=0))
+        g.eval().remove_weight_norm()
+        g(**kw, lengths=lens)  # builds the native handle (every conv direct) and sizes the workspace
+    finally:
+        lib.dissc_set_option(b"wino", 1)
     outs = {}
     for v in (0, 1):
         assert lib.dissc_set_option(b"pair_dma", v) == 0
-        g(**kw, lengths=lens)  # sizes the workspace
         g._ws.view(torch.float32)[: g._ws.numel() // 4].fill_(float("nan"))
         outs[v] = g(**kw, lengths=lens).clone()
         assert torch.isfinite(outs[v]).all(), v
@@ -57,6 +66,15 @@ def test_dma_handover_of_wide_residual_pairs_on_a_poisoned_workspace(env):
     hop = outs[0].shape[-1] // T
     for b, n in enumerate([70, 64, 33, 1, 17]):
         assert not outs[1][b, 0, n * hop:].any()
+    # the default generator (transform-domain convs) on a poisoned workspace: finite, nothing beyond the utterances
+    gw = env["g"]
+    gw(**kw, lengths=lens)
+    gw._ws.view(torch.float32)[: gw._ws.numel() // 4].fill_(float("nan"))
+    yw = gw(**kw, lengths=lens)
+    assert torch.isfinite(yw).all()
+    for b, n in enumerate([70, 64, 33, 1, 17]):
+        assert not yw[b, 0, n * hop:].any()
+    assert float((yw - outs[1]).abs().max()) <= 1e-4
 
 
 def test_hipgraph_replay_is_bit_identical(env):
