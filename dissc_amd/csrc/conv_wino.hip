@@ -403,6 +403,24 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
         v[1] = d12 + fmaf(2.f, y3, -0.5f * y4) + bz;
         v[2] = s12 + fmaf(4.f, y3, 0.25f * y4) + bz;
         v[3] = d12 + fmaf(8.f, y3, -0.125f * y4) + y5 + bz;
+      } else if constexpr (D % 4 == 0) {
+        // k = 11 (D = 4 d): the 4 outputs are 4 neighbouring columns of ONE A^T row -> six 16-byte LDS reads
+        const int ao = (4 * g) / D, rho = 4 * g - ao * D;
+        const float* yc = yr + rho;  // (tau D + rho) % 4 == 0 and YS % 4 == 0: aligned
+        const f32x4 y0 = *reinterpret_cast<const f32x4*>(yc), y1 = *reinterpret_cast<const f32x4*>(yc + 32 * YS),
+                    y2 = *reinterpret_cast<const f32x4*>(yc + 2 * 32 * YS), y3 = *reinterpret_cast<const f32x4*>(yc + 3 * 32 * YS),
+                    y4 = *reinterpret_cast<const f32x4*>(yc + 4 * 32 * YS), y5 = *reinterpret_cast<const f32x4*>(yc + 5 * 32 * YS);
+        const float sg = (ao & 1) ? -1.f : 1.f;
+        const float p2 = __int_as_float((127 + ao) << 23), c4 = sg * __int_as_float((127 - ao) << 23);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = (ao == 0 ? y0[e] : 0.f) + y1[e];
+          x = fmaf(sg, y2[e], x);
+          x = fmaf(p2, y3[e], x);
+          x = fmaf(c4, y4[e], x);
+          x += (ao == 3 ? y5[e] : 0.f);
+          v[e] = x + bz;
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
