@@ -43,7 +43,7 @@ int g_wino_dbg = 0;      // "wino_dbg" option (diagnostics): knock-outs, bit 0 t
 
 struct WinoArgs {
   const float* x;
-  const float* wpack;   // [6 points][C / 32][nchunk][NS][2][64][4] (pack_conv_weights32 with groups = 6)
+  const float* wpack;   // [6 points][C / 32][nchunk][2 halves][NS taps][64 lanes][4 k-steps] (make_wino)
   const float* bias;    // [C]
   const float* res;
   float* out;
@@ -230,21 +230,17 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  // A fragments: one float4 per lane = the 4 k-steps (8 channels) of one (chunk, tap, half): [chunk][tap][half][lane]
+  // A fragments: one float4 per lane = the 4 k-steps (8 channels) of one (chunk, half, tap) block, packed in the order
+  // the loop walks them: [point][32-row subtile][block][lane] -- one pointer step per tap
   const int nsub = a.C / 32;
-  const int nblk = a.nchunk * NS * 2;  // (chunk, half, tap) blocks, walked in this order
+  const int nblk = a.nchunk * NS * 2;
   const f32x4* wp[MI];
   f32x4 av[MI], avn[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
-    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * (MI * RH) + mh * MI + mi) * (a.nchunk * NS) * 128 + lane;
-  auto wofs = [&](int blk) {  // blk = (chunk * 2 + half) * NS + tap -> float4 offset
-    const int tap = blk % NS, ch2 = blk / NS;
-    return (size_t)((ch2 >> 1) * NS + tap) * 128 + (ch2 & 1) * 64;
-  };
-
+    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * (MI * RH) + mh * MI + mi) * nblk * 64 + lane;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) av[mi] = wp[mi][wofs(0)];
+  for (int mi = 0; mi < MI; ++mi) av[mi] = wp[mi][0];
   stage_load(0);
   stage_store(lds);
   if (nround > 1) stage_load(1);  // the staging registers always hold the round after the newest one in LDS
@@ -309,9 +305,8 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
 #pragma unroll
         for (int j = 0; j < NS; ++j, ++blk) {
           const int bn = (blk + 1 < nblk) ? blk + 1 : nblk - 1;
-          const size_t wo = wofs(bn);
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][wo];
+          for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][(size_t)bn * 64];
 #pragma unroll
           for (int s = 1; s < 4; ++s)
 #pragma unroll
@@ -514,13 +509,25 @@ int make_wino(const float* w, const float* bias, int C, int KS, int dil, DevConv
           }
           wt[(((size_t)p * C + co) * C + ci) * NS + j] = (float)u;
         }
-  std::vector<float> packed;
-  int Mpad, nchunk;
-  pack_conv_weights32(wt.data(), 6 * C, C, NS, packed, Mpad, nchunk, 6);
-  if (Mpad != C) {
+  // A-fragment order of the 32x32x2 MFMA, blocks in the order the kernel walks them:
+  // [point][32-row subtile][chunk][half][tap][lane][k-step e]: W[32 ms + (lane & 31)][16 c + 8 half + 2 e + (lane >> 5)][tap]
+  if (C % 32 != 0 || C % KC != 0) {
     set_error("make_wino: C = %d is not a multiple of the row tile", C);
     return DISSC_EINVAL;
   }
+  const int nchunk = C / KC, nsub = C / 32;
+  std::vector<float> packed((size_t)6 * nsub * nchunk * 2 * NS * 64 * 4);
+  size_t o = 0;
+  for (int p = 0; p < 6; ++p)
+    for (int ms = 0; ms < nsub; ++ms)
+      for (int c = 0; c < nchunk; ++c)
+        for (int hf = 0; hf < 2; ++hf)
+          for (int j = 0; j < NS; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 4; ++e) {
+                const int co = ms * 32 + (lane & 31), ci = c * KC + 8 * hf + 2 * e + (lane >> 5);
+                packed[o++] = wt[(((size_t)p * C + co) * C + ci) * NS + j];
+              }
   std::vector<float> b(C, 0.f);
   if (bias) memcpy(b.data(), bias, C * sizeof(float));
   dc.CIN = C; dc.M = C; dc.KS = KS; dc.dil = dil; dc.nchunk = nchunk; dc.up = 1;
