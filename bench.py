@@ -528,8 +528,10 @@ def main():
                                    "on the ResBlocks of the C >= 64 stages, conv_mfma32_kernel (direct, same MFMA) for conv_pre and the "
                                    "ConvTranspose layers, respair32/respair16 fused residual pairs on the C = 32 / 16 stages",
                          "algorithmic_tflops": round(ach_alg, 2),
-                         "note": "achieved / frac = EXECUTED matrix-pipe FLOPs / time (<= peak by construction); "
-                                 "algorithmic_tflops = direct-form FLOPs (SURVEY 8d: 321.664 MFLOP per frame) / time",
+                         "algorithmic_frac": round(ach_alg / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "note": "achieved / frac = EXECUTED matrix-pipe FLOPs / time (<= peak by construction; the Toom-Cook layers "
+                                 "execute 6 ceil(k/3) / 4 products per output instead of k); algorithmic_tflops / algorithmic_frac = "
+                                 "direct-form FLOPs (SURVEY 8d: 321.664 MFLOP per frame) / time -- an effective rate, not pipe utilisation",
                          "flops_per_step": flops_step, "flops_executed": flops_exec,
                          "kernel_ms_per_step": round(kern_s * 1e3, 3)},
         }
