@@ -212,6 +212,18 @@ class CodeGenerator:
                 'Padding condition signal - misalignment between condition features.')
         return signal.repeat_interleave(rep, dim=2)
 
+    def validate_host_ids(self, code=None, spkr=None):
+        """IndexError for unit / speaker ids outside the embedding tables, like nn.Embedding in the reference
+        (host arrays or tensors; callers that upload ids themselves, e.g. dissc_amd.harness, call this first)."""
+        for name, t, rows in (("code", code, int(self.h.num_embeddings)), ("spkr", spkr if self.multispkr else None, 200)):
+            if t is None:
+                continue
+            t = torch.as_tensor(t)
+            if t.numel():
+                lo, hi = int(t.min()), int(t.max())
+                if lo < 0 or hi >= rows:
+                    raise IndexError(f"{name} id out of range: [{lo}, {hi}] not within [0, {rows})")
+
     def forward(self, **kwargs):
         self._ensure()
         extra = [k for k in kwargs if k not in ("code", "f0", "spkr", "lengths")]
@@ -238,14 +250,10 @@ class CodeGenerator:
             f0 = f0.reshape(code.shape[0], -1).contiguous()
         code = code.contiguous()
         B, T = code.shape
-        for name, t, rows in (("code", kwargs["code"], int(self.h.num_embeddings)),
-                              ("spkr", kwargs.get("spkr") if self.multispkr else None, 200)):
-            # nn.Embedding raises IndexError on a bad id (reference sr/models.py:189,207); checked for
-            # host tensors (ids read from files), device-resident ids come from our own kernels
-            if t is not None and t.device.type == "cpu" and t.numel():
-                lo, hi = int(t.min()), int(t.max())
-                if lo < 0 or hi >= rows:
-                    raise IndexError(f"{name} id out of range: [{lo}, {hi}] not within [0, {rows})")
+        # nn.Embedding raises IndexError on a bad id (reference sr/models.py:189,207); checked for
+        # host tensors (ids read from files), device-resident ids come from our own kernels
+        self.validate_host_ids(kwargs["code"] if kwargs["code"].device.type == "cpu" else None,
+                               kwargs.get("spkr") if self.multispkr and kwargs["spkr"].device.type == "cpu" else None)
         spkr = None
         if self.multispkr:
             spkr = kwargs["spkr"].to(dev, torch.int64).reshape(-1).contiguous()

@@ -49,9 +49,10 @@ def imbalance(lengths, parts):
     return max(loads) / mean if mean > 0 else 1.0
 
 
-def make_batches(job_ids, lengths, max_batch=32, max_frames=32 * 500):
+def make_batches(job_ids, lengths, max_batch=64, max_frames=32 * 500):
     """Length-sorted batches of at most ``max_batch`` jobs and ``max_frames`` padded frames
-    (Tmax * B), so padding waste stays small and the workspace bounded."""
+    (Tmax * B), so padding waste stays small and the workspace bounded (16 000 frames = the 32 x 10 s
+    of the headline batch; short utterances ride 64 to a batch, which keeps the launch grids full)."""
     ids = sorted(job_ids, key=lambda i: (-int(lengths[i]), i))
     batches, cur = [], []
     for i in ids:
@@ -340,7 +341,7 @@ def init_distributed(default_port, backend_env="DISSC_DIST_BACKEND"):
     return rank, local_rank, world, dist
 
 
-def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist=None, max_batch=32,
+def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist=None, max_batch=64,
                     max_frames=32 * 500, postprocess=None, unpack_ranks=(0,), sink=None,
                     round_floats=ROUND_FLOATS, stats=None):
     """jobs: list of dicts {code: int array [T], f0: float array [T], spkr: int}.
@@ -364,30 +365,51 @@ def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist
     for shares in rounds:
         t0 = time.perf_counter()
         store = WaveStore(dev)
-        for batch in make_batches(shares[rank], lengths, max_batch, max_frames):
-            B = len(batch)
-            T = max(lengths[i] for i in batch)
+        batches = make_batches(shares[rank], lengths, max_batch, max_frames)
+        # ONE upload per round: the padded inputs of every batch go into one host buffer each (page-locked on a GPU) and
+        # over with four copies; the batches are views of the device copies.  (A pageable per-batch .to(device) is
+        # ordered behind the previous batch's kernels on the stream and blocks the host until they are done: host
+        # batching and GPU compute then alternate instead of overlapping.)
+        shapes = [(len(bt), max((lengths[i] for i in bt), default=0)) for bt in batches]
+        tot = sum(B * T for B, T in shapes)
+        nrow = sum(B for B, _ in shapes)
+        pin = dev.type == "cuda"
+        h_code = torch.zeros(max(tot, 1), dtype=torch.int64, pin_memory=pin)
+        h_f0 = torch.zeros(max(tot, 1), dtype=torch.float32, pin_memory=pin)
+        h_spkr = torch.zeros(max(nrow, 1), dtype=torch.int64, pin_memory=pin)
+        h_lens = torch.zeros(max(nrow, 1), dtype=torch.int32, pin_memory=pin)
+        n_code, n_f0, n_spkr, n_lens = h_code.numpy(), h_f0.numpy(), h_spkr.numpy(), h_lens.numpy()
+        o = r = 0
+        for bt, (B, T) in zip(batches, shapes):
+            for k, i in enumerate(bt):
+                n = lengths[i]
+                n_code[o + k * T:o + k * T + n] = jobs[i]["code"]
+                n_f0[o + k * T:o + k * T + n] = jobs[i]["f0"]
+                n_spkr[r + k] = jobs[i]["spkr"]
+                n_lens[r + k] = n
+            o += B * T
+            r += B
+        if hasattr(generator, "validate_host_ids"):
+            generator.validate_host_ids(h_code[:tot], h_spkr[:nrow])
+        d_code, d_f0 = h_code.to(dev, non_blocking=True), h_f0.to(dev, non_blocking=True)
+        d_spkr, d_lens = h_spkr.to(dev, non_blocking=True), h_lens.to(dev, non_blocking=True)
+        o = r = 0
+        for bt, (B, T) in zip(batches, shapes):
             if T == 0:
                 # empty `units` lines: empty waveforms (the generator rejects T = 0).  Never abort one rank
                 # here -- the others would wait in the all-gather forever.
-                store.add_empty(batch)
+                store.add_empty(bt)
+                r += B
                 continue
-            code = np.zeros((B, T), dtype=np.int64)
-            f0 = np.zeros((B, 1, T), dtype=np.float32)
-            spkr = np.zeros((B, 1), dtype=np.int64)
-            lens = np.zeros(B, dtype=np.int32)
-            for k, i in enumerate(batch):
-                n = lengths[i]
-                code[k, :n] = jobs[i]["code"]
-                f0[k, 0, :n] = jobs[i]["f0"]
-                spkr[k, 0] = jobs[i]["spkr"]
-                lens[k] = n
-            y = generator(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
-                          lengths=torch.from_numpy(lens))
+            lens = d_lens[r:r + B]
+            y = generator(code=d_code[o:o + B * T].view(B, T), f0=d_f0[o:o + B * T].view(B, 1, T),
+                          spkr=d_spkr[r:r + B].view(B, 1), lengths=lens)
             assert y.shape[-1] == hop * T
             if postprocess is not None:
-                postprocess(y, torch.from_numpy(lens * hop).to(dev))
-            store.add(y, lens * hop, batch)
+                postprocess(y, lens * hop)
+            store.add(y, n_lens[r:r + B].astype(np.int64) * hop, bt)
+            o += B * T
+            r += B
         if stats is not None and dev.type == "cuda":
             torch.cuda.synchronize(dev)
         t_compute += time.perf_counter() - t0
