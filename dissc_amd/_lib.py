@@ -93,6 +93,7 @@ def _load():
     L.dissc_hubert_workspace_bytes.restype = ctypes.c_size_t
     L.dissc_hubert_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, ctypes.c_size_t, vp]
     L.dissc_mfma_peak.argtypes = [i32, ctypes.POINTER(ctypes.c_float)]
+    L.dissc_erf_check.argtypes = [vp, vp, i32, vp]
     L.dissc_set_option.argtypes = [ctypes.c_char_p, i32]
     L.dissc_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     L.dissc_conv_bench.argtypes = [i32] * 9 + [ctypes.POINTER(ctypes.c_float)]

@@ -8,7 +8,7 @@ namespace dissc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
-__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + erf_1ulp(v * 0.70710678118654752440f)); }
 
 // EPI_STORE_ACT: zeros for the columns tcol .. tcol+3 of one row that lie in [olen, olen + ZERO_TAIL) or [ldo - ZERO_TAIL, ldo)
 __device__ __forceinline__ void zero_tail4(const ConvArgs& a, size_t rowoff, int tcol, int olen) {

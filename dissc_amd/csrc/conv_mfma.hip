@@ -24,7 +24,7 @@ namespace dissc {
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + erf_1ulp(v * 0.70710678118654752440f)); }
 
 // STRIDE: input step per output position (1; 2 for HuBERT's strided feature convs).
 // SPAN: largest (KS-1)*dil the staging registers are sized for.

@@ -227,6 +227,25 @@ __global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters) {
 }
 }  // namespace dissc
 
+namespace dissc {
+__global__ void erf_check_kernel(const float* __restrict__ x, float* __restrict__ y, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = erf_1ulp(x[i]);
+}
+}  // namespace dissc
+
+// Diagnostics: y[i] = the device erf used inside the GELU epilogues (device pointers)
+extern "C" int dissc_erf_check(const float* x, float* y, int n, void* stream) {
+  if (!x || !y || n < 0) {
+    dissc::set_error("dissc_erf_check: bad argument");
+    return DISSC_EINVAL;
+  }
+  if (n == 0) return DISSC_OK;
+  hipLaunchKernelGGL(dissc::erf_check_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  DISSC_HIP_CHECK(hipGetLastError());
+  return DISSC_OK;
+}
+
 extern "C" int dissc_mfma_peak(int iters, float* tflops) {
   using namespace dissc;
   if (!tflops || iters == 0) return DISSC_EINVAL;

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) conv0_apply_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < 10; ++j) x = fmaf(w[c * 10 + j], s[5 * e + j], x);
       x = (x - mean) * rstd * ga + be;
-      y[e] = 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+      y[e] = 0.5f * x * (1.f + erf_1ulp(x * 0.70710678118654752440f));
     }
     if (t + 3 < T0) {
       *reinterpret_cast<f32x4*>(ob + (size_t)c * ld0) = y;

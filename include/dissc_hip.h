@@ -244,6 +244,9 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
 /* Diagnostics: sustained fp32 v_mfma_f32_16x16x4_f32 rate (TFLOP/s) of this GPU at its
  * real clocks -- the practical ceiling the conv kernels are compared with. */
 int dissc_mfma_peak(int iters, float* tflops);
+/* Diagnostics: y[i] = erf(x[i]) as the GELU epilogues evaluate it (branch-free, < 1 ulp; HuBERT's exact-erf GELU,
+ * arch per HF:154-213,371-445 [3P]); x, y: device f32 [n]. */
+int dissc_erf_check(const float* x, float* y, int n, void* stream);
 /* Diagnostics: ms[0] a pure-MFMA kernel alone, ms[1] a pure-fp32-VALU kernel alone, ms[2] both
  * at once on two streams (do the two pipes overlap on this part?). */
 int dissc_pipe_overlap(int mfma_iters, int valu_iters, float* ms);

@@ -184,3 +184,25 @@ def test_long_input_is_chunked_like_textless(env, monkeypatch):
     want = torch.cat(pieces)
     assert int(out["frames"][0]) == want.numel() == 49 + 49 + 24
     np.testing.assert_array_equal(out["units"][0].cpu().numpy(), want.cpu().numpy())
+
+
+def test_device_erf_is_within_one_ulp():
+    """the branch-free erf of the GELU epilogues (csrc/common.h erf_1ulp) against float64 on a dense sample"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scipy.special import erf
+    from dissc_amd._lib import check, lib
+    rs = np.random.RandomState(0)
+    x = np.concatenate([rs.uniform(-6, 6, 400000), rs.uniform(-1, 1, 200000), np.linspace(0.92, 0.935, 50000),
+                        10.0 ** rs.uniform(-30, 0, 50000), [0.0, -0.0, 1e-40, 20.0, -20.0]]).astype(np.float32)
+    d = torch.from_numpy(x).cuda()
+    y = torch.empty_like(d)
+    check(lib.dissc_erf_check(d.data_ptr(), y.data_ptr(), d.numel(), None), "erf_check")
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().astype(np.float64)
+    ref = erf(x.astype(np.float64))
+    ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    err = np.abs(got - ref) / np.maximum(ulp, 1e-45)
+    print("erf max error", err.max(), "ulp at", x[err.argmax()])
+    assert err.max() <= 1.05
+    assert got[-2] == 1.0 and got[-1] == -1.0 and got[-5] == 0.0
