@@ -602,8 +602,14 @@ int run_wino(const DevConv& dc, const float* x, float* out, const float* res, fl
   a.ldx = ldx; a.ldo = ldo;
   a.x_bstride = (long long)dc.M * ldx; a.o_bstride = (long long)dc.M * ldo;
   a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = g_wino_dbg;
-  if (ldx < 4) {
-    set_error("run_wino: rows shorter than 4 floats");
+  // the window staging, the residual / accumulator reads and the stores are 16-byte accesses
+  auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
+  if (ldx < 4 || ldx % 4 || ldo % 4 || misaligned(x) || misaligned(out) || misaligned(res) || misaligned(acc)) {
+    set_error("run_wino: rows must be 16-byte aligned (ldx %d, ldo %d: multiples of 4 floats, ldx >= 4)", ldx, ldo);
+    return DISSC_EINVAL;
+  }
+  if (B <= 0 || Lmax <= 0) {
+    set_error("run_wino: empty batch (B %d, Lmax %d)", B, Lmax);
     return DISSC_EINVAL;
   }
   const int ns = (dc.KS + 2) / 3;

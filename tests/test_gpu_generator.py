@@ -121,6 +121,31 @@ def test_toom_cook_conv_matches_torch_and_the_direct_kernel(env, C, k, d):
     assert r2 <= 2.0 * r0 + 1e-8
 
 
+def test_toom_cook_conv_rejects_unaligned_rows(env):
+    """conv_wino_kernel moves 16 bytes at a time: a row stride that is not a multiple of 4 floats (or a base pointer
+    off a 16-byte boundary) is refused with DISSC_EINVAL and a message, never launched."""
+    lib, _lib = env["lib"], env["_lib"]
+    C, k, L = 64, 7, 64
+    w = torch.zeros(C, C, k)
+    b = torch.zeros(C)
+    x = torch.zeros(1, C, 72, device="cuda")
+    y = torch.zeros(1, C, 72, device="cuda")
+    try:
+        assert lib.dissc_set_option(b"wino", 2) == 0
+        for ldx, ldo, xoff in ((66, 68, 0), (68, 66, 0), (68, 68, 4)):
+            rc = lib.dissc_conv1d(x.data_ptr() + xoff, w.data_ptr(), b.data_ptr(), y.data_ptr(), None, 1, C, C, k, 1,
+                                  ldx, ldo, L, ctypes.c_float(0.1), None)
+            assert rc != 0
+            assert b"16-byte" in lib.dissc_last_error()
+        rc = lib.dissc_conv1d(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, 1, C, C, k, 1, 68, 68, L,
+                              ctypes.c_float(0.1), None)
+        _lib.check(rc, "conv")
+    finally:
+        lib.dissc_set_option(b"wino", 1)
+    torch.cuda.synchronize()
+    assert (y == 0).all()
+
+
 def test_toom_cook_generator_agrees_with_the_direct_generator(env):
     """The default generator (wide ResBlock convs in the transform domain) against an instance built with option
     "wino" = 0 (every conv direct, the round-2 path): same waveform to fp32 rounding on a ragged batch and at the
