@@ -197,6 +197,7 @@ extern int g_wino;        // "wino" option (read at dissc_gen_create): 1 = C >= 
 extern int g_wino_min_c;
 extern int g_wino_dbg;
 extern int g_wino_cpr;
+extern int g_wino_sv;
 extern int g_wino_small;
 bool wino_supported(int Cout, int Cin, int KS, int dil);
 bool wino_wanted(int C, int KS);

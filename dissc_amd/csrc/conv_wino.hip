@@ -113,8 +113,9 @@ constexpr int wino_row_len(int D, int NTU, int XRW) {
   return need;
 }
 
-template <int NS, int DIL, int CPR, int RH, int TW>
+template <int NS, int DIL, int CPR, int RH, int TW, int SHV = 0>
 __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const WinoArgs a) {
+  static_assert(SHV == 0 || RH == 2, "the shared transform is for the row-half form");
   constexpr int NTH = 768;                    // 12 waves: 6 points x 2 row halves (3 waves on every SIMD)
   constexpr int D = DIL * NS;                 // sample step of the F(4,3) sequences
   constexpr int W = DIL * (2 * NS - 1);       // V entries per tile unit
@@ -249,7 +250,126 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   // One barrier per round: at the top of round rd the window of round rd + 1 goes into the other buffer (every wave
   // finished reading it before the barrier that closed round rd - 1) and the loads of round rd + 2 are issued; the
   // barrier at the bottom publishes that window and retires this round's.
+  // ---- NS taps x 4 k-steps on one point's V tile; the B fragments of tap j + 1 and the A fragments of block blk + 2 are
+  // fetched behind the MFMAs of tap j
   int blk = 0;
+  auto run_taps = [&](const float* vt) {
+      if (!(a.dbg & 2)) {
+        const float* bj[NI];
+        float b0[NI], b0n[NI], bk[3][NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          bj[ni] = vt + voff[ni];
+          b0[ni] = bj[ni][0];
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j, ++blk) {
+          const int bn = (blk + 1 < nblk) ? blk + 1 : nblk - 1;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][(size_t)bn * 64];
+#pragma unroll
+          for (int s = 1; s < 4; ++s)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bk[s - 1][ni] = bj[ni][s * 2 * XV + j * DIL];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) b0n[ni] = (j + 1 < NS) ? bj[ni][(j + 1) * DIL] : 0.f;  // next tap's first k-step
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][0], b0[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+          for (int s = 1; s < 4; ++s)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][s], bk[s - 1][ni], acc[mi][ni], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) b0[ni] = b0n[ni];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) av[mi] = avn[mi];
+        }
+      } else {
+        blk += NS;
+      }
+  };
+
+  if constexpr (SHV) {
+    // ---- shared transform (row-half form): the 12 waves split a sub-chunk's 8 channels x 6 points as (channel pair,
+    // point pair) -- every window sample is read from LDS once per point pair instead of once per wave (4x fewer
+    // 16-byte reads, half the transform arithmetic: the two row halves used to form the same V_p twice) -- into a
+    // double-buffered V [2][6][8][XV]: the tile of sub-chunk g + 1 is formed while g is multiplied; one barrier each
+    constexpr int VSZ = 6 * 8 * XV;
+    const int chp = wave & 3, pp = wave >> 2;
+    f32x4 lo[2], hi[2];
+    auto tsv_load = [&](const float* rawbuf, int sc) {
+      const float* rw = rawbuf + (sc * 8 + 2 * chp) * CHF + toff;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        lo[i] = *reinterpret_cast<const f32x4*>(rw + i * CHF);
+        hi[i] = *reinterpret_cast<const f32x4*>(rw + i * CHF + 4);
+      }
+    };
+    auto tsv_finish = [&](float* vdst) {
+      auto two = [&](auto pc) {
+        constexpr int P0 = decltype(pc)::value, P1 = P0 + 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float* d0 = vdst + (P0 * 8 + 2 * chp + i) * XV;
+          float* d1 = vdst + (P1 * 8 + 2 * chp + i) * XV;
+          const float a0 = wino_bt<P0>(lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1]);
+          const float c0 = wino_bt<P1>(lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1]);
+          d0[e0] = a0;
+          d1[e0] = c0;
+          if constexpr (NS > 1) {
+            const float a1 = wino_bt<P0>(lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2]);
+            const float c1 = wino_bt<P1>(lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2]);
+            d0[e1] = ok1 ? a1 : a0;
+            d1[e1] = ok1 ? c1 : c0;
+          }
+        }
+      };
+      switch (pp) {  // uniform per wave
+        case 0: two(std::integral_constant<int, 0>{}); break;
+        case 1: two(std::integral_constant<int, 2>{}); break;
+        default: two(std::integral_constant<int, 4>{}); break;
+      }
+    };
+    if (!(a.dbg & 1)) {
+      tsv_load(lds, 0);
+      tsv_finish(vbuf);
+    }
+    __syncthreads();
+    int g = 0;
+    for (int rd = 0; rd < nround; ++rd) {
+      const float* raw = lds + (rd & 1) * (CPR * CHF);
+      float* rawn = lds + ((rd + 1) & 1) * (CPR * CHF);
+      // window rd + 1 goes into the other buffer at the top of the round (its last readers -- the transforms of round
+      // rd - 1's last sub-chunk -- finished two barriers ago); the barrier of sub-chunk 0 publishes it before the last
+      // sub-chunk of this round transforms its first 8 channels
+      if (!(a.dbg & 8) && rd + 1 < nround) stage_store(rawn);
+      for (int sc = 0; sc < CPR / 8; ++sc, ++g) {
+        if (!(a.dbg & 8) && rd + 2 < nround && sc == (wave >> 2) % (CPR / 8)) stage_load(rd + 2);
+        float* vnxt = vbuf + ((g + 1) & 1) * VSZ;
+        // (issuing these window reads behind the first tap's fragment reads and finishing them behind its MFMAs, so that
+        // their latency never sits in front of a matrix instruction, measured 3-8 % SLOWER: +20 registers)
+        if (!(a.dbg & 1)) {
+          if (sc + 1 < CPR / 8) {
+            tsv_load(raw, sc + 1);
+            tsv_finish(vnxt);
+          } else if (rd + 1 < nround) {
+            tsv_load(rawn, 0);
+            tsv_finish(vnxt);
+          }
+        }
+        run_taps(vbuf + (g & 1) * VSZ + p * (8 * XV));
+        __syncthreads();
+      }
+    }
+  } else {
   for (int rd = 0; rd < nround; ++rd) {
     const float* raw = lds + (rd & 1) * (CPR * CHF);
     if (!(a.dbg & 8) && rd + 1 < nround) stage_store(lds + ((rd + 1) & 1) * (CPR * CHF));
@@ -292,51 +412,10 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
           default: transform8(std::integral_constant<int, 5>{}); break;
         }
       }
-      // ---- NS taps x 4 k-steps on V_p; the B fragments of tap j + 1 and the A fragments of block blk + 2 are fetched
-      // behind the MFMAs of tap j
-      if (!(a.dbg & 2)) {
-        const float* bj[NI];
-        float b0[NI], b0n[NI], bk[3][NI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          bj[ni] = vp + voff[ni];
-          b0[ni] = bj[ni][0];
-        }
-#pragma unroll
-        for (int j = 0; j < NS; ++j, ++blk) {
-          const int bn = (blk + 1 < nblk) ? blk + 1 : nblk - 1;
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][(size_t)bn * 64];
-#pragma unroll
-          for (int s = 1; s < 4; ++s)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bk[s - 1][ni] = bj[ni][s * 2 * XV + j * DIL];
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) b0n[ni] = (j + 1 < NS) ? bj[ni][(j + 1) * DIL] : 0.f;  // next tap's first k-step
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][0], b0[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-          for (int s = 1; s < 4; ++s)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < NI; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][s], bk[s - 1][ni], acc[mi][ni], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) b0[ni] = b0n[ni];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) av[mi] = avn[mi];
-        }
-      } else {
-        blk += NS;
-      }
+      run_taps(vp);
     }
     __syncthreads();
+  }
   }
 
   // ---- epilogue: the 6 waves exchange their Y_p through LDS, 32 rows at a time; one thread = 4 consecutive outputs
@@ -542,7 +621,7 @@ int make_wino(const float* w, const float* bias, int C, int KS, int dil, DevConv
 // MACs the matrix pipe executes per output position (6 NS / 4 per input/output channel pair)
 double wino_executed_macs_per_t(int C, int KS) { return (double)C * C * 6.0 * ((KS + 2) / 3) / 4.0; }
 
-template <int NS, int DIL, int CPR, int RH, int TW>
+template <int NS, int DIL, int CPR, int RH, int TW, int SHV = 0>
 static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream) {
   constexpr int CHV = 3 - RH;
   constexpr int D = DIL * NS, NTU = 32 * TW / D, OT = 4 * D * NTU * CHV, RAW = OT + DIL * (3 * NS - 1), XRW = (RAW + 6) / 4 * 4;
@@ -551,7 +630,7 @@ static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
   if (lds_f < (size_t)6 * 32 * (32 * TW + 4)) lds_f = (size_t)6 * 32 * (32 * TW + 4);
   static bool attr_done = false;
   if (!attr_done) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, DIL, CPR, RH, TW>),
+    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, DIL, CPR, RH, TW, SHV>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -565,12 +644,13 @@ static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
   }
   const int per = 8 / aa.gy;
   dim3 grid(8 * ((aa.gx * B + per - 1) / per));
-  hipLaunchKernelGGL((conv_wino_kernel<NS, DIL, CPR, RH, TW>), grid, dim3(768), lds_f * sizeof(float), stream, aa);
+  hipLaunchKernelGGL((conv_wino_kernel<NS, DIL, CPR, RH, TW, SHV>), grid, dim3(768), lds_f * sizeof(float), stream, aa);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
 
 int g_wino_cpr = 32;  // "wino_cpr" option: channels per barrier round (16 or 32)
+int g_wino_sv = 1;    // "wino_sv" option: shared transform in the row-half form (C >= 128)
 template <int NS, int DIL>
 static int launch_wino_t(const WinoArgs& a, int B, int Lmax, hipStream_t stream) {
   // Small grids (a short or single utterance: the reference's one-at-a-time mode) step down to 32 x 32 wave tiles: four
@@ -587,8 +667,13 @@ static int launch_wino_t(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
   }
   if (small) return launch_wino_c<NS, DIL, 16, 2, 1>(a, B, Lmax, stream);    // 64 rows x 32 columns
   // (k = 11, d = 5 with 32 channels per round needs more registers than three waves per SIMD leave: 16 there)
-  if (g_wino_cpr == 32 && a.nchunk % 2 == 0 && !(NS == 4 && DIL == 5))
-    return launch_wino_c<NS, DIL, 32, 2, 2>(a, B, Lmax, stream);
+  const bool r32 = g_wino_cpr == 32 && a.nchunk % 2 == 0 && !(NS == 4 && DIL == 5);
+  if (g_wino_sv) {
+    // (with 32 channels per round the k = 7 / 11 instances spill a few registers; k = 3 has room)
+    if (NS == 1 && r32) return launch_wino_c<NS, DIL, 32, 2, 2, 1>(a, B, Lmax, stream);
+    return launch_wino_c<NS, DIL, 16, 2, 2, 1>(a, B, Lmax, stream);
+  }
+  if (r32) return launch_wino_c<NS, DIL, 32, 2, 2>(a, B, Lmax, stream);
   return launch_wino_c<NS, DIL, 16, 2, 2>(a, B, Lmax, stream);
 }
 

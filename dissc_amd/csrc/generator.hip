@@ -700,6 +700,7 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "wino_min_c") == 0) { g_wino_min_c = value; return DISSC_OK; }
   if (strcmp(key, "wino_dbg") == 0) { g_wino_dbg = value; return DISSC_OK; }
   if (strcmp(key, "wino_cpr") == 0) { g_wino_cpr = value; return DISSC_OK; }
+  if (strcmp(key, "wino_sv") == 0) { g_wino_sv = value; return DISSC_OK; }
   if (strcmp(key, "wino_small") == 0) { g_wino_small = value; return DISSC_OK; }
   if (strcmp(key, "wino_c64_kmin") == 0) { g_wino_c64_kmin = value; return DISSC_OK; }
   if (strcmp(key, "c64_wide") == 0) { g_c64_wide = value; return DISSC_OK; }

@@ -149,6 +149,8 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   wino (1)             read at dissc_gen_create: 1 = ResBlock convs with C >= wino_min_c (64; at C = 64 those with k >=
  *                        wino_c64_kmin = 3) run in the Toom-Cook F(4,3) transform domain (conv_wino.hip), 0 = all direct,
  *                        2 = dissc_conv1d uses it too (tests)
+ *   wino_sv (1)          conv_wino.hip, C >= 128: the 12 waves of a workgroup share the input transform (one barrier per
+ *                        8 channels) instead of every wave forming its own tile; bit-identical, faster (0 = private tiles)
  *   attn_fused (1)       HuBERT attention as one fused kernel (0: batched GEMM -> softmax -> batched GEMM)
  *   mfast (0)            M-fastest block order for convs with many M tiles
  * Unknown keys return DISSC_EINVAL. */

@@ -99,10 +99,16 @@ def test_toom_cook_conv_matches_torch_and_the_direct_kernel(env, C, k, d):
         # chip-filling launch ("small_grid" = 0 forces them) must give the same bits.
         assert lib.dissc_set_option(b"small_grid", 0) == 0
         big = _run_conv(env, x, w, b, lengths, k, d, 0.1)
+        # ... and so must the form in which every wave transforms its own V tile (C >= 128 shares the transform between
+        # the waves by default, option "wino_sv")
+        assert lib.dissc_set_option(b"wino_sv", 0) == 0
+        private = _run_conv(env, x, w, b, lengths, k, d, 0.1)
     finally:
         lib.dissc_set_option(b"wino", 1)
         lib.dissc_set_option(b"small_grid", 1)
+        lib.dissc_set_option(b"wino_sv", 1)
     assert torch.equal(big, out[2])
+    assert torch.equal(private, out[2])
     assert not torch.equal(out[0], out[2])  # really another evaluation order
     se = {0: 0.0, 2: 0.0}
     cnt = 0
