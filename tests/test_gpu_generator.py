@@ -10,6 +10,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+WINO_SV_DEFAULT = 1  # csrc/conv_wino.hip g_wino_sv
+
 
 @pytest.fixture(scope="module")
 def env():
@@ -99,16 +101,19 @@ def test_toom_cook_conv_matches_torch_and_the_direct_kernel(env, C, k, d):
         # chip-filling launch ("small_grid" = 0 forces them) must give the same bits.
         assert lib.dissc_set_option(b"small_grid", 0) == 0
         big = _run_conv(env, x, w, b, lengths, k, d, 0.1)
-        # ... and so must the form in which every wave transforms its own V tile (C >= 128 shares the transform between
-        # the waves by default, option "wino_sv")
-        assert lib.dissc_set_option(b"wino_sv", 0) == 0
-        private = _run_conv(env, x, w, b, lengths, k, d, 0.1)
+        # ... and so must both forms of the input transform (option "wino_sv": 0 = each wave its own V tile, 1 = shared
+        # between the waves for C >= 128)
+        forms = []
+        for sv in (0, 1):
+            assert lib.dissc_set_option(b"wino_sv", sv) == 0
+            forms.append(_run_conv(env, x, w, b, lengths, k, d, 0.1))
     finally:
         lib.dissc_set_option(b"wino", 1)
         lib.dissc_set_option(b"small_grid", 1)
-        lib.dissc_set_option(b"wino_sv", 1)
+        lib.dissc_set_option(b"wino_sv", WINO_SV_DEFAULT)
     assert torch.equal(big, out[2])
-    assert torch.equal(private, out[2])
+    for f in forms:
+        assert torch.equal(f, out[2])
     assert not torch.equal(out[0], out[2])  # really another evaluation order
     se = {0: 0.0, 2: 0.0}
     cnt = 0
