@@ -157,6 +157,18 @@ def test_toom_cook_conv_rejects_unaligned_rows(env):
     assert (y == 0).all()
 
 
+def test_toom_cook_conv_random_shapes(env):
+    """tools/wino_fuzz.py: random (C, k, d, B, row length, ragged utterance lengths) -- both transform forms and both tile
+    sizes bit-identical, within fp32 rounding of the direct kernel, nothing written beyond an utterance."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "wino_fuzz.py"), "24", "3"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "24 cases ok" in r.stdout
+
+
 def test_toom_cook_generator_agrees_with_the_direct_generator(env):
     """The default generator (wide ResBlock convs in the transform domain) against an instance built with option
     "wino" = 0 (every conv direct, the round-2 path): same waveform to fp32 rounding on a ragged batch and at the
