@@ -15,13 +15,17 @@
 //       y[co][t0 + 4 D tau + rho + D a] = sum_p A^T[a][p] Y_p[co][tau][rho] + bias,  a in [0, 4)
 //   i.e. per point a dilation-d, NS-tap convolution in the transform domain: 6 NS MFMA products per 4 outputs instead of
 //   4 k (k = 3: 6 vs 12, k = 7: 18 vs 28, k = 11: 24 vs 44).
-// * One workgroup = 6 waves = the 6 points of one [64 rows] x [64 transform-domain columns = 240..256 outputs] tile.  All
-//   waves share the activated input window (staged like conv_mfma32_kernel: registers -> lrelu / zero padding -> LDS);
-//   wave p derives ITS V_p from it into a wave-private LDS tile (6 LDS reads + 6 FMAs per entry, coefficients in SGPRs) and
-//   runs the same tap / k-step MFMA loop as conv_mfma32_kernel on it with its own weights U_p (A fragments streamed from
-//   L2 in fragment order).  Two barriers per 16-channel chunk (window ready / window consumed; they are a short transform
-//   apart).  Epilogue: the 6 waves exchange their Y_p through LDS, every thread applies A^T, bias and the residual / MRF
-//   mode of its outputs.
+// * One workgroup = 12 waves = 6 points x 2 halves (three waves on every SIMD; one workgroup fills a CU): for C >= 128 the
+//   halves are the 64-row halves of a [128 rows] x [64 transform-domain columns = 240..256 outputs] tile, for C = 64 the
+//   64-column halves of a [64 rows] x [128 columns] tile.  All waves share the activated input window of 16 / 32 channels
+//   (staged like conv_mfma32_kernel: registers -> lrelu / zero padding -> LDS, double-buffered, loads two rounds ahead),
+//   kept in a polyphase layout [channel][x mod D][x div D] so that the 6 samples of an F(4,3) group are two aligned
+//   16-byte reads.  V_p is formed 8 channels at a time -- C = 64: by wave (p, half) for itself; C >= 128: by all 12 waves
+//   together, (channel pair, point pair) each, one sub-chunk ahead of the MFMAs into a double-buffered shared tile set,
+//   one barrier per sub-chunk -- and multiplied by the same tap / k-step MFMA loop as conv_mfma32_kernel with the point's
+//   weights U_p (A fragments streamed from L2 in the order the loop walks them).  Epilogue: the 6 waves of a half
+//   exchange their Y_p through LDS 32 rows at a time, one thread applies A^T, bias and the residual / MRF mode to 4
+//   consecutive outputs.  DESIGN.md section 4 has the measurements and the versions that led here.
 // The results differ from the direct kernels by fp32 rounding only (measured per layer: rms 3e-7 relative to O(0.4)
 // outputs against 1e-7 for the direct form); the direct kernels remain (option "wino" = 0).
 #include <string.h>
@@ -137,7 +141,7 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   static_assert(VROW <= XV && NCOL <= TC && NTU >= 1, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // 2 x [CPR][D][RL]: window sample x (position o + x) of a channel at [(x + 4 D) % D][(x + 4 D) / D]
-  float* vbuf = lds + 2 * CPR * CHF;  // [12 waves][8][XV]
+  float* vbuf = lds + 2 * CPR * CHF;  // V tiles: [12 waves][8][XV], or [2][6 points][8][XV] in the shared form
 
   // 1-D grid, XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2; the 128-row tiles
   // (their transform-domain weights are 6 NS / k times the direct form's: 3.1 MB per tile for C = 256, k = 11) are
