@@ -32,7 +32,7 @@ for case in range(n_cases):
     C = int(rs.choice([64, 128, 256]))
     k = int(rs.choice([3, 7, 11]))
     d = int(rs.choice([1, 3, 5]))
-    B = int(rs.choice([1, 2, 3, 5, 9, 17, 40]))
+    B = int(rs.choice([1, 2, 3, 5, 9, 17, 40, 70, 130]))  # > 64: the tile search walks the utterances 64 at a time
     Lmax = int(rs.choice([1, 5, 63, 240, 256, 257, 511, 777, 1024, 2500, 4099]))
     lengths = rs.randint(1, Lmax + 1, size=B).astype(np.int32)
     lengths[rs.randint(B)] = Lmax
