@@ -26,6 +26,7 @@ import torch
 HDR = 4               # header floats (16 B)
 ENT = 4               # table floats per row (16 B): job id, sample count, offset lo, offset hi
 ROUND_FLOATS = 1 << 28
+MAX_FRAMES = 48 * 500  # padded frames (B x Tmax) per generator call, see make_batches
 
 
 def lpt_shard(lengths, world_size):
@@ -49,10 +50,13 @@ def imbalance(lengths, parts):
     return max(loads) / mean if mean > 0 else 1.0
 
 
-def make_batches(job_ids, lengths, max_batch=64, max_frames=32 * 500):
+def make_batches(job_ids, lengths, max_batch=64, max_frames=MAX_FRAMES):
     """Length-sorted batches of at most ``max_batch`` jobs and ``max_frames`` padded frames
-    (Tmax * B), so padding waste stays small and the workspace bounded (16 000 frames = the 32 x 10 s
-    of the headline batch; short utterances ride 64 to a batch, which keeps the launch grids full)."""
+    (Tmax * B), so padding waste stays small and the workspace bounded (it grows with the PADDED frames, about 0.4 MB
+    each; the kernels themselves skip what lies beyond an utterance's end).  24 000 = the 32 x 10 s of the headline batch
+    with room for a rhythm model that stretches some of its utterances by half -- at 16 000 such a batch was cut into
+    25 + 7 utterances and the small second call cost 8 % of the conversion; short utterances ride 64 to a batch, which
+    keeps the launch grids full."""
     ids = sorted(job_ids, key=lambda i: (-int(lengths[i]), i))
     batches, cur = [], []
     for i in ids:
@@ -342,7 +346,7 @@ def init_distributed(default_port, backend_env="DISSC_DIST_BACKEND"):
 
 
 def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist=None, max_batch=64,
-                    max_frames=32 * 500, postprocess=None, unpack_ranks=(0,), sink=None,
+                    max_frames=MAX_FRAMES, postprocess=None, unpack_ranks=(0,), sink=None,
                     round_floats=ROUND_FLOATS, stats=None):
     """jobs: list of dicts {code: int array [T], f0: float array [T], spkr: int}.
     Every rank runs its LPT share in length-bucketed batches, one all-gather per round (one round unless a
