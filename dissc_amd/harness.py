@@ -50,13 +50,14 @@ def imbalance(lengths, parts):
     return max(loads) / mean if mean > 0 else 1.0
 
 
-def make_batches(job_ids, lengths, max_batch=64, max_frames=MAX_FRAMES):
+def make_batches(job_ids, lengths, max_batch=128, max_frames=MAX_FRAMES):
     """Length-sorted batches of at most ``max_batch`` jobs and ``max_frames`` padded frames
     (Tmax * B), so padding waste stays small and the workspace bounded (it grows with the PADDED frames, about 0.4 MB
     each; the kernels themselves skip what lies beyond an utterance's end).  24 000 = the 32 x 10 s of the headline batch
     with room for a rhythm model that stretches some of its utterances by half -- at 16 000 such a batch was cut into
-    25 + 7 utterances and the small second call cost 8 % of the conversion; short utterances ride 64 to a batch, which
-    keeps the launch grids full."""
+    25 + 7 utterances and the small second call cost 8 % of the conversion; short utterances ride up to 128 to a batch,
+    which keeps the launch grids full (1 024 jobs of 2-5 s: 462 ms at 64 x 16 000, 447 ms at 128 x 24 000,
+    `tools/strong_ab.py`)."""
     ids = sorted(job_ids, key=lambda i: (-int(lengths[i]), i))
     batches, cur = [], []
     for i in ids:
@@ -345,7 +346,7 @@ def init_distributed(default_port, backend_env="DISSC_DIST_BACKEND"):
     return rank, local_rank, world, dist
 
 
-def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist=None, max_batch=64,
+def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist=None, max_batch=128,
                     max_frames=MAX_FRAMES, postprocess=None, unpack_ranks=(0,), sink=None,
                     round_floats=ROUND_FLOATS, stats=None):
     """jobs: list of dicts {code: int array [T], f0: float array [T], spkr: int}.

@@ -56,7 +56,7 @@ def normalize_f0_(f0, lengths, mean, std, fill_median=False):
 
 class Converter:
     def __init__(self, encoder, len_model, pitch_model, generator, norm_pitch=True, n_tokens=100,
-                 postprocess=True, max_batch=64, max_frames=harness.MAX_FRAMES, encode_seconds=640.0, f0_median=False):
+                 postprocess=True, max_batch=128, max_frames=harness.MAX_FRAMES, encode_seconds=640.0, f0_median=False):
         self.encoder, self.len_model, self.pitch_model, self.generator = encoder, len_model, pitch_model, generator
         self.norm_pitch, self.n_tokens, self.postprocess = norm_pitch, n_tokens, postprocess
         self.max_batch, self.max_frames, self.encode_seconds = max_batch, max_frames, encode_seconds
