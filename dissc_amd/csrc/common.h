@@ -125,6 +125,7 @@ void conv32_set_cfg(int bm_class, int cfg);
 void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
                          int& Mpad, int& nchunk, int groups);
 extern int g_attn_fused;
+extern int g_hubert_split;
 extern int g_lin_tile;
 extern int g_cpb2;
 extern int g_conv2_dma;

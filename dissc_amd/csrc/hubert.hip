@@ -542,6 +542,8 @@ using namespace dissc;
 
 namespace dissc {
 int g_attn_fused = 1;  // "attn_fused" option: 0 = S=QK^T -> softmax -> PV through HBM (3 kernels)
+int g_hubert_split = 1;  // "hubert_split" option: batches of >= 16 utterances run as two halves on two streams (0 never, 1 unless
+                         // the batch fills whole workgroup rounds by itself, 2 always)
 }
 
 struct dissc_hubert {
@@ -559,7 +561,12 @@ struct dissc_hubert {
   };
   std::vector<Layer> layers;
   float* cnorm = nullptr;
+  hipStream_t side = nullptr;  // second half of a split batch (dissc_hubert_forward)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   ~dissc_hubert() {
+    if (side) (void)hipStreamDestroy(side);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     for (float* p : {w0, gn_g, gn_b, ln0_g, ln0_b, eln_g, eln_b, cnorm})
       if (p) (void)hipFree(p);
     for (auto& c : fconv) free_conv(c);
@@ -745,10 +752,20 @@ static HubertWs carve(const dissc_hubert* m, int B, int Nmax, void* base_) {
   return w;
 }
 
+constexpr int HUBERT_SPLIT_MIN_B = 16;
+
 size_t dissc_hubert_workspace_bytes(dissc_hubert_t m, int B, int Nmax) {
   if (!m || B <= 0 || Nmax <= 0) return 0;
-  return carve(m, B, Nmax, nullptr).bytes;
+  size_t whole = carve(m, B, Nmax, nullptr).bytes;
+  if (B >= HUBERT_SPLIT_MIN_B) {  // two halves side by side (whatever the option says when the forward runs)
+    const size_t halves = 2 * rup(carve(m, (B + 1) / 2, Nmax, nullptr).bytes, 256) + 256;
+    if (halves > whole) whole = halves;
+  }
+  return whole;
 }
+
+static int hubert_forward_part(dissc_hubert_t m, const float* wav, const int32_t* n_samples, int B, int Nmax,
+                               float* dense_out, int64_t* units_out, void* workspace, hipStream_t st);
 
 int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_samples, int B, int Nmax,
                          float* dense_out, int64_t* units_out, void* workspace, size_t ws_bytes,
@@ -763,6 +780,50 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
     return DISSC_ENOMEM;
   }
   hipStream_t st = (hipStream_t)stream_;
+  // "hubert_split": 0 never, 2 always, 1 (default) unless the whole batch already fills whole rounds: with rows of T frames
+  // the linears launch B ceil(T / 64) column tiles per M tile, and when that is a multiple of the CU count (32 x 10 s: 8 x 32 =
+  // 256) every round is full and splitting only costs (28.0 -> 28.9 ms).  The lengths live on the device, so the rows decide.
+  bool split = g_hubert_split != 0 && B >= HUBERT_SPLIT_MIN_B;
+  if (split && g_hubert_split == 1) {
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      DISSC_HIP_CHECK(hipGetDevice(&dev));
+      DISSC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int tiles = B * ((frames_of(Nmax) + 63) / 64);
+    if (tiles % n_cu == 0) split = false;
+  }
+  if (!split) return hubert_forward_part(m, wav, n_samples, B, Nmax, dense_out, units_out, workspace, st);
+  // Two halves on two streams.  The layers of one batch depend on each other, so every launch ends in a partly filled
+  // round of workgroups that nothing covers -- and only special shapes avoid it (32 x 10 s: 8 column tiles x 32 = exactly one
+  // workgroup per CU and M tile; the same audio in rows of 10.5 s, or ragged, costs 10-15 % more).  Two independent halves
+  // fill each other's tails: ragged 32.1 -> 30.4 ms per 320 s, the lucky shape 28.0 -> 28.6 (tools/encode_ragged.py).
+  // Utterances are independent (per-utterance GroupNorm statistics, masked attention), so the units do not change.
+  if (!m->side) {
+    DISSC_HIP_CHECK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    DISSC_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    DISSC_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+  }
+  const int B0 = (B + 1) / 2, B1 = B - B0;
+  const int T = frames_of(Nmax);
+  const size_t ldT = rup(T > 0 ? T : 1, 4);
+  const size_t half = rup(carve(m, B0, Nmax, nullptr).bytes, 256);
+  DISSC_HIP_CHECK(hipEventRecord(m->ev_fork, st));
+  DISSC_HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+  int rc = hubert_forward_part(m, wav, n_samples, B0, Nmax, dense_out, units_out, workspace, st);
+  const int rc1 = hubert_forward_part(m, wav + (size_t)B0 * Nmax, n_samples ? n_samples + B0 : nullptr, B1, Nmax,
+                                      dense_out ? dense_out + (size_t)B0 * m->D * ldT : nullptr,
+                                      units_out ? units_out + (size_t)B0 * T : nullptr, (char*)workspace + half, m->side);
+  DISSC_HIP_CHECK(hipEventRecord(m->ev_join, m->side));
+  DISSC_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
+  return rc ? rc : rc1;
+}
+
+static int hubert_forward_part(dissc_hubert_t m, const float* wav, const int32_t* n_samples, int B, int Nmax,
+                               float* dense_out, int64_t* units_out, void* workspace, hipStream_t st) {
   HubertWs w = carve(m, B, Nmax, workspace);
   const int T0 = frames_after(Nmax, 0), T = frames_of(Nmax);
   if (T <= 0) {

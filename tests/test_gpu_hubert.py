@@ -109,6 +109,33 @@ def test_hubert_batch32_ragged_2_to_10s_against_oracle(env):
         np.testing.assert_array_equal(one["units"][0].cpu().numpy(), units[i, :T])
 
 
+def test_split_batch_forward_is_bit_identical(env):
+    """dissc_hubert_forward runs batches of >= 16 utterances as two halves on two streams (option "hubert_split": they fill
+    each other's partly filled workgroup rounds): same units and the same dense features, bit for bit, as the whole batch
+    on one stream -- ragged lengths, NaN in the padding, an odd batch size."""
+    from dissc_amd import _lib
+    synth = env["synth"]
+    rs = np.random.RandomState(5)
+    ns = [int(v) for v in rs.randint(20000, 90001, size=21)]
+    wav = torch.full((21, max(ns) + 320), float("nan"))
+    for i, n in enumerate(ns):
+        wav[i, :n] = torch.from_numpy(synth.synth_waveform(n, seed=900 + i))
+    outs = []
+    try:
+        for mode in (0, 2, 1):
+            assert _lib.lib.dissc_set_option(b"hubert_split", mode) == 0
+            o = env["enc"](wav, n_samples=torch.tensor(ns))
+            outs.append((o["units"].cpu(), o["dense"].cpu(), o["frames"].cpu()))
+    finally:
+        _lib.lib.dissc_set_option(b"hubert_split", 1)
+    for u, d, f in outs[1:]:
+        assert torch.equal(f, outs[0][2])
+        for i in range(21):
+            T = int(f[i])
+            assert torch.equal(u[i, :T], outs[0][0][i, :T])
+            assert torch.equal(d[i, :T], outs[0][1][i, :T])
+
+
 def test_units_differ_from_the_oracle_only_at_constructed_near_ties(env):
     """Centres built so that many frames sit (almost) exactly between two centres: the HIP units may
     then differ from the oracle's -- but only on those frames.  (With the random synthetic centres no
