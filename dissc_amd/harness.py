@@ -216,17 +216,31 @@ def _pinned(n_floats):
 
 
 def _to_host(t):
-    """1-D device f32 tensor -> numpy copy, through the cached page-locked staging buffer in <= 64 MB chunks
-    (a pageable ``.cpu()`` of the 20 MB of a 32-utterance batch takes 1.7 ms, this 0.7 ms)."""
+    """1-D device f32 tensor -> numpy copy, through the cached page-locked staging buffer (a pageable ``.cpu()`` of the
+    20 MB of a 32-utterance batch takes 1.7 ms, this 0.7 ms).  Above 32 MB the buffer works as two halves: the D2H of
+    chunk i + 1 runs while the host copies chunk i out of the other half (226 MB: 34 -> 27 ms)."""
     n = t.numel()
     out = np.empty(n, dtype=np.float32)
     stage = _pinned(n)
-    cap = stage.numel()
-    for o in range(0, n, cap):
-        k = min(cap, n - o)
-        stage[:k].copy_(t[o:o + k], non_blocking=True)
+    if n <= stage.numel() and n <= _PIN_MAX_FLOATS // 2:
+        stage[:n].copy_(t, non_blocking=True)
         torch.cuda.current_stream(t.device).synchronize()
-        out[o:o + k] = stage[:k].numpy()
+        out[:] = stage[:n].numpy()
+        return out
+    cap = stage.numel() // 2
+    halves = (stage[:cap], stage[cap:2 * cap])
+    events = (torch.cuda.Event(), torch.cuda.Event())
+    chunks = [(o, min(cap, n - o)) for o in range(0, n, cap)]
+    for i, (o, k) in enumerate(chunks[:1]):
+        halves[0][:k].copy_(t[o:o + k], non_blocking=True)
+        events[0].record()
+    for i, (o, k) in enumerate(chunks):
+        if i + 1 < len(chunks):
+            o2, k2 = chunks[i + 1]
+            halves[(i + 1) & 1][:k2].copy_(t[o2:o2 + k2], non_blocking=True)
+            events[(i + 1) & 1].record()
+        events[i & 1].synchronize()
+        out[o:o + k] = halves[i & 1][:k].numpy()
     return out
 
 
