@@ -188,7 +188,8 @@ class Converter:
         samples x targets (the output length is data-dependent with a rhythm model; the input length is the proxy
         all ranks can agree on without talking).  Returns {(utt_index, target_id): samples} on ``unpack_ranks``
         (None = all), {} elsewhere -- or, with ``sink``, calls ``sink({(utt, target): samples})`` per round there
-        and returns the number of waveforms delivered."""
+        and returns the number of waveforms delivered (the arrays a sink receives are views of a reused page-locked
+        buffer: valid until it returns)."""
         target_ids = list(target_ids)
         nt = max(len(target_ids), 1)
         parts = harness.lpt_shard(n_samples, world_size)
@@ -199,7 +200,8 @@ class Converter:
             self._run_local(shares[rank], n_samples, load, target_ids, store, f0_stats)
             n_cap = max(len(p) for p in shares) * len(target_ids)
             _, data_cap = harness.agree_geometry(store.n, store.data_floats, world_size, self.generator.device, dist)
-            got = harness.gather_store(store, n_cap, data_cap, rank, world_size, dist, unpack_ranks, stats)
+            got = harness.gather_store(store, n_cap, data_cap, rank, world_size, dist, unpack_ranks, stats,
+                                       transient=sink is not None)
             store.clear()
             got = self._decode(got, target_ids)
             if sink is not None:
