@@ -542,8 +542,8 @@ using namespace dissc;
 
 namespace dissc {
 int g_attn_fused = 1;  // "attn_fused" option: 0 = S=QK^T -> softmax -> PV through HBM (3 kernels)
-int g_hubert_split = 1;  // "hubert_split" option: batches of >= 16 utterances run as two halves on two streams (0 never, 1 unless
-                         // the batch fills whole workgroup rounds by itself, 2 always)
+int g_hubert_split = 1;  // "hubert_split" option: batches of >= 16 utterances run as 2-4 parts on streams of their own (0 never, 1
+                         // unless the batch fills whole workgroup rounds by itself, N >= 2: always N parts)
 }
 
 struct dissc_hubert {
@@ -561,12 +561,15 @@ struct dissc_hubert {
   };
   std::vector<Layer> layers;
   float* cnorm = nullptr;
-  hipStream_t side = nullptr;  // second half of a split batch (dissc_hubert_forward)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  static constexpr int MAX_PARTS = 4;
+  hipStream_t side[MAX_PARTS - 1] = {};  // the other parts of a split batch (dissc_hubert_forward)
+  hipEvent_t ev_fork = nullptr, ev_join[MAX_PARTS - 1] = {};
   ~dissc_hubert() {
-    if (side) (void)hipStreamDestroy(side);
+    for (auto st : side)
+      if (st) (void)hipStreamDestroy(st);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
+    for (auto e : ev_join)
+      if (e) (void)hipEventDestroy(e);
     for (float* p : {w0, gn_g, gn_b, ln0_g, ln0_b, eln_g, eln_b, cnorm})
       if (p) (void)hipFree(p);
     for (auto& c : fconv) free_conv(c);
@@ -757,10 +760,11 @@ constexpr int HUBERT_SPLIT_MIN_B = 16;
 size_t dissc_hubert_workspace_bytes(dissc_hubert_t m, int B, int Nmax) {
   if (!m || B <= 0 || Nmax <= 0) return 0;
   size_t whole = carve(m, B, Nmax, nullptr).bytes;
-  if (B >= HUBERT_SPLIT_MIN_B) {  // two halves side by side (whatever the option says when the forward runs)
-    const size_t halves = 2 * rup(carve(m, (B + 1) / 2, Nmax, nullptr).bytes, 256) + 256;
-    if (halves > whole) whole = halves;
-  }
+  if (B >= HUBERT_SPLIT_MIN_B)  // the parts of a split batch side by side (whatever the option says when the forward runs)
+    for (int np = 2; np <= dissc_hubert::MAX_PARTS; ++np) {
+      const size_t parts = np * rup(carve(m, (B + np - 1) / np, Nmax, nullptr).bytes, 256) + 256;
+      if (parts > whole) whole = parts;
+    }
   return whole;
 }
 
@@ -797,29 +801,42 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
     if (tiles % n_cu == 0) split = false;
   }
   if (!split) return hubert_forward_part(m, wav, n_samples, B, Nmax, dense_out, units_out, workspace, st);
-  // Two halves on two streams.  The layers of one batch depend on each other, so every launch ends in a partly filled
+  // Parts on streams of their own.  The layers of one batch depend on each other, so every launch ends in a partly filled
   // round of workgroups that nothing covers -- and only special shapes avoid it (32 x 10 s: 8 column tiles x 32 = exactly one
-  // workgroup per CU and M tile; the same audio in rows of 10.5 s, or ragged, costs 10-15 % more).  Two independent halves
-  // fill each other's tails: ragged 32.1 -> 30.4 ms per 320 s, the lucky shape 28.0 -> 28.6 (tools/encode_ragged.py).
+  // workgroup per CU and M tile; the same audio in rows of 10.5 s, or ragged, costs 10-15 % more).  Independent parts
+  // fill each other's tails: ragged 32.0 -> 30.2 ms per 320 s, the lucky shape 28.0 -> 28.8 (tools/encode_ragged.py).
   // Utterances are independent (per-utterance GroupNorm statistics, masked attention), so the units do not change.
-  if (!m->side) {
-    DISSC_HIP_CHECK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-    DISSC_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-    DISSC_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
-  }
-  const int B0 = (B + 1) / 2, B1 = B - B0;
+  // parts of >= 8 utterances, at most 4 (32 ragged utterances of 8-12 s: 32.0 ms whole, 31.0 / 30.6 / 30.2 in 2 / 3 / 4 parts)
+  int nparts = g_hubert_split >= 2 ? g_hubert_split : B / 8;
+  if (nparts < 2) nparts = 2;
+  if (nparts > dissc_hubert::MAX_PARTS) nparts = dissc_hubert::MAX_PARTS;
+  if (!m->ev_fork) DISSC_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+  for (int i = 0; i + 1 < nparts; ++i)
+    if (!m->side[i]) {
+      DISSC_HIP_CHECK(hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking));
+      DISSC_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
+    }
+  const int Bp = (B + nparts - 1) / nparts;
   const int T = frames_of(Nmax);
   const size_t ldT = rup(T > 0 ? T : 1, 4);
-  const size_t half = rup(carve(m, B0, Nmax, nullptr).bytes, 256);
+  const size_t part_ws = rup(carve(m, Bp, Nmax, nullptr).bytes, 256);
   DISSC_HIP_CHECK(hipEventRecord(m->ev_fork, st));
-  DISSC_HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-  int rc = hubert_forward_part(m, wav, n_samples, B0, Nmax, dense_out, units_out, workspace, st);
-  const int rc1 = hubert_forward_part(m, wav + (size_t)B0 * Nmax, n_samples ? n_samples + B0 : nullptr, B1, Nmax,
-                                      dense_out ? dense_out + (size_t)B0 * m->D * ldT : nullptr,
-                                      units_out ? units_out + (size_t)B0 * T : nullptr, (char*)workspace + half, m->side);
-  DISSC_HIP_CHECK(hipEventRecord(m->ev_join, m->side));
-  DISSC_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
-  return rc ? rc : rc1;
+  int rc = DISSC_OK;
+  for (int i = 0; i < nparts; ++i) {
+    const int b0 = i * Bp, bn = (b0 + Bp <= B ? Bp : B - b0);
+    if (bn <= 0) break;
+    hipStream_t si = i == 0 ? st : m->side[i - 1];
+    if (i > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(si, m->ev_fork, 0));
+    const int r = hubert_forward_part(m, wav + (size_t)b0 * Nmax, n_samples ? n_samples + b0 : nullptr, bn, Nmax,
+                                      dense_out ? dense_out + (size_t)b0 * m->D * ldT : nullptr,
+                                      units_out ? units_out + (size_t)b0 * T : nullptr, (char*)workspace + i * part_ws, si);
+    if (r && !rc) rc = r;
+    if (i > 0) {
+      DISSC_HIP_CHECK(hipEventRecord(m->ev_join[i - 1], si));
+      DISSC_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join[i - 1], 0));
+    }
+  }
+  return rc;
 }
 
 static int hubert_forward_part(dissc_hubert_t m, const float* wav, const int32_t* n_samples, int B, int Nmax,

@@ -152,9 +152,9 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   wino_sv (1)          conv_wino.hip, C >= 128: the 12 waves of a workgroup share the input transform (one barrier per
  *                        8 channels) instead of every wave forming its own tile; bit-identical, faster (0 = private tiles)
  *   attn_fused (1)       HuBERT attention as one fused kernel (0: batched GEMM -> softmax -> batched GEMM)
- *   hubert_split (1)     dissc_hubert_forward runs a batch of >= 16 utterances as two halves on two streams, which fill the
- *                        partly filled last workgroup rounds of each other's launches (0 never, 1 unless the whole batch
- *                        fills whole rounds by itself, 2 always); the units do not depend on it
+ *   hubert_split (1)     dissc_hubert_forward runs a batch of >= 16 utterances as 2-4 parts on streams of their own, which
+ *                        fill the partly filled last workgroup rounds of each other's launches (0 never, 1 unless the
+ *                        whole batch fills whole rounds by itself, N >= 2 always N parts); the units do not depend on it
  *   mfast (0)            M-fastest block order for convs with many M tiles
  * Unknown keys return DISSC_EINVAL. */
 int dissc_set_option(const char* key, int value);

@@ -110,7 +110,7 @@ def test_hubert_batch32_ragged_2_to_10s_against_oracle(env):
 
 
 def test_split_batch_forward_is_bit_identical(env):
-    """dissc_hubert_forward runs batches of >= 16 utterances as two halves on two streams (option "hubert_split": they fill
+    """dissc_hubert_forward runs batches of >= 16 utterances as 2-4 parts on streams of their own (option "hubert_split": they fill
     each other's partly filled workgroup rounds): same units and the same dense features, bit for bit, as the whole batch
     on one stream -- ragged lengths, NaN in the padding, an odd batch size."""
     from dissc_amd import _lib
@@ -122,7 +122,7 @@ def test_split_batch_forward_is_bit_identical(env):
         wav[i, :n] = torch.from_numpy(synth.synth_waveform(n, seed=900 + i))
     outs = []
     try:
-        for mode in (0, 2, 1):
+        for mode in (0, 2, 4, 1):
             assert _lib.lib.dissc_set_option(b"hubert_split", mode) == 0
             o = env["enc"](wav, n_samples=torch.tensor(ns))
             outs.append((o["units"].cpu(), o["dense"].cpu(), o["frames"].cpu()))
