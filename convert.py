@@ -133,7 +133,7 @@ def main(argv=None):
             st = pickle.load(f)
         pairs = []
         for fn in files:
-            e = st.get(formats.speaker_of(fn), None)
+            e = st.get(formats.parse_speaker(os.path.join(a.base_dir, fn), h.get("multispkr", None) or "_"), None)
             pairs.append((e["mean"], e["std"]) if e is not None else (st["f0_mean"], st["f0_std"]))
         f0_stats = (np.array([p[0] for p in pairs], np.float64), np.array([p[1] for p in pairs], np.float64))
 

@@ -104,10 +104,33 @@ def main(argv=None):
     order = sorted(lengths, key=lambda f: (-lengths[f], f))
     # Batches run longest first, but the manifest keeps the reference's line order (os.listdir order, one line per
     # file: data/encode.py:24-41 there) -- positional consumers (`infer.py -n N`, data_split) must see the same
-    # subset.  Finished batches are appended to `<out_file>.partial` as they complete (a failure keeps what was
-    # already encoded, like the reference's per-file append); the ordered lines are appended to out_file at the end.
+    # subset.  Finished batches are appended to `<out_file>.partial` as they complete; only each file's byte range in
+    # it is kept in memory, and the ordered lines are streamed from it into out_file at the end (appended, as the
+    # reference's per-line 'a+' does).  A run that died leaves the .partial behind: the next run over the same
+    # directory resumes from it (files whose line is already there are not encoded again).
     partial = str(args.out_file) + '.partial'
-    lines = {}
+    where = {}  # file -> (offset, length) of its line in .partial
+    if os.path.exists(partial):
+        good = 0
+        with open(partial, 'rb') as fi:
+            while True:
+                off, raw = fi.tell(), fi.readline()
+                if not raw:
+                    break
+                try:
+                    name = json.loads(raw)["audio"] if raw.endswith(b"\n") else None
+                except ValueError:
+                    name = None
+                if name is None:  # a torn last line: cut it off
+                    break
+                if name in lengths:
+                    where[name] = (off, len(raw))
+                good = off + len(raw)
+        with open(partial, 'r+b') as fo:
+            fo.truncate(good)
+        if where:
+            print(f"resuming from {partial}: {len(where)} of {len(lengths)} files already encoded")
+    order = [f for f in order if f not in where]
     i = 0
     while i < len(order):
         n0 = lengths[order[i]]
@@ -124,17 +147,20 @@ def main(argv=None):
         out = encoder.model(torch.from_numpy(wav), n_samples=torch.from_numpy(ns), want_dense=False)
         units = out["units"].cpu()
         f0s = track_f0(wav, ns, [int(t) for t in out["frames"]], args) if args.f0 == 'yaapt' else None
-        with open(partial, 'a+') as fo:
+        with open(partial, 'ab') as fo:
             for k, f in enumerate(batch):
                 T = int(out["frames"][k])
                 u = units[k, :T].tolist()
                 f0 = f0s[k] if f0s is not None else [0.0] * T
-                lines[f] = json.dumps({"units": u, "f0": f0, "durations": [1] * T, "audio": f}) + "\n"
-                fo.write(lines[f])
-    with open(args.out_file, 'a+') as fo:
-        for f in files:
-            if f in lines:
-                fo.write(lines[f])
+                raw = (json.dumps({"units": u, "f0": f0, "durations": [1] * T, "audio": f}) + "\n").encode()
+                where[f] = (fo.tell(), len(raw))
+                fo.write(raw)
+    if where:
+        with open(args.out_file, 'ab') as fo, open(partial, 'rb') as fi:
+            for f in files:
+                if f in where:
+                    fi.seek(where[f][0])
+                    fo.write(fi.read(where[f][1]))
     if os.path.exists(partial):
         os.remove(partial)
 

@@ -604,7 +604,9 @@ bool wino_wanted(int C, int KS) {
 }
 
 bool wino_supported(int Cout, int Cin, int KS, int dil) {
-  return Cout == Cin && (Cout == 64 || (Cout % 128 == 0 && 8 % (Cout / 128) == 0)) && (KS == 3 || KS == 7 || KS == 11) && (dil == 1 || dil == 3 || dil == 5);
+  // C in {64, 128, 256, 512}: every launch variant (large tiles and the small-grid RH = 2 / TW = 1 one, whose row-tile
+  // count C / 64 must divide the 8 XCDs) exists for these; C = 1024 would only fail at forward time on short batches
+  return Cout == Cin && (Cout == 64 || Cout == 128 || Cout == 256 || Cout == 512) && (KS == 3 || KS == 7 || KS == 11) && (dil == 1 || dil == 3 || dil == 5);
 }
 
 // w: [C][C][KS] -> transform-domain weights U[p][co][ci][j] = sum_i G[p][i] w[co][ci][j + NS i] as a grouped conv tensor

@@ -789,11 +789,12 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
   // 256) every round is full and splitting only costs (28.0 -> 28.9 ms).  The lengths live on the device, so the rows decide.
   bool split = g_hubert_split != 0 && B >= HUBERT_SPLIT_MIN_B;
   if (split && g_hubert_split == 1) {
-    static int n_cu = 0;
+    static int n_cu_of[64] = {0};  // per device (a process may hold models on several GPUs)
+    int dev = 0;
+    DISSC_HIP_CHECK(hipGetDevice(&dev));
+    int& n_cu = n_cu_of[dev & 63];
     if (!n_cu) {
-      int dev = 0;
       hipDeviceProp_t prop;
-      DISSC_HIP_CHECK(hipGetDevice(&dev));
       DISSC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
       n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
@@ -821,19 +822,33 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
   const size_t ldT = rup(T > 0 ? T : 1, 4);
   const size_t part_ws = rup(carve(m, Bp, Nmax, nullptr).bytes, 256);
   DISSC_HIP_CHECK(hipEventRecord(m->ev_fork, st));
+  // From here on side streams may hold work: an error must not return before `st` waits for every side stream that was
+  // forked (the caller may free or reuse the workspace as soon as `st` is done).  The side streams and events belong to
+  // the model: ONE forward of a model at a time (a model is single-stream, include/dissc_hip.h).
   int rc = DISSC_OK;
+  auto note = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && !rc) {
+      set_error("dissc_hubert_forward: %s: %s", what, hipGetErrorString(e));
+      rc = DISSC_EHIP;
+    }
+    return e == hipSuccess;
+  };
   for (int i = 0; i < nparts; ++i) {
     const int b0 = i * Bp, bn = (b0 + Bp <= B ? Bp : B - b0);
     if (bn <= 0) break;
     hipStream_t si = i == 0 ? st : m->side[i - 1];
-    if (i > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(si, m->ev_fork, 0));
-    const int r = hubert_forward_part(m, wav + (size_t)b0 * Nmax, n_samples ? n_samples + b0 : nullptr, bn, Nmax,
-                                      dense_out ? dense_out + (size_t)b0 * m->D * ldT : nullptr,
-                                      units_out ? units_out + (size_t)b0 * T : nullptr, (char*)workspace + i * part_ws, si);
-    if (r && !rc) rc = r;
-    if (i > 0) {
-      DISSC_HIP_CHECK(hipEventRecord(m->ev_join[i - 1], si));
-      DISSC_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join[i - 1], 0));
+    if (i > 0 && !note(hipStreamWaitEvent(si, m->ev_fork, 0), "fork")) continue;  // nothing launched on this stream
+    if (!rc) {
+      const int r = hubert_forward_part(m, wav + (size_t)b0 * Nmax, n_samples ? n_samples + b0 : nullptr, bn, Nmax,
+                                        dense_out ? dense_out + (size_t)b0 * m->D * ldT : nullptr,
+                                        units_out ? units_out + (size_t)b0 * T : nullptr, (char*)workspace + i * part_ws, si);
+      if (r && !rc) rc = r;
+    }
+    if (i > 0) {  // join even after an error: kernels already on `si` must finish before `st` moves on
+      if (note(hipEventRecord(m->ev_join[i - 1], si), "join record"))
+        note(hipStreamWaitEvent(st, m->ev_join[i - 1], 0), "join wait");
+      else
+        hipStreamSynchronize(si);
     }
   }
   return rc;

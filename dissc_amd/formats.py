@@ -48,3 +48,34 @@ def speaker_of(audio_name):
     """speaker = filename prefix before the first '_' (reference dataset/pitch_dataset.py:28,
     sr/dataset.py:139 method '_')."""
     return audio_name.split("/")[-1].split("_")[0]
+
+
+def parse_speaker(path, method):
+    """Speaker name of an audio path under the vocoder config's ``multispkr`` rule (reference
+    sr/dataset.py:132-147): 'parent_name' = the directory holding the file, 'parent_parent_name' = the one
+    above it, '_' = filename prefix before the first underscore, 'single' = the constant 'A', or a callable
+    taking the ``pathlib.Path``.  Anything else raises NotImplementedError like the reference."""
+    from pathlib import Path
+    p = Path(path) if isinstance(path, str) else path
+    if method == "parent_name":
+        return p.parent.name
+    if method == "parent_parent_name":
+        return p.parent.parent.name
+    if method == "_":
+        return p.name.split("_")[0]
+    if method == "single":
+        return "A"
+    if callable(method):
+        return method(p)
+    raise NotImplementedError(f"multispkr = {method!r}: expected 'parent_name', 'parent_parent_name', '_', 'single' "
+                              "or a callable (reference sr/dataset.py:132-147)")
+
+
+def speaker_id(name, spkr_to_id, what="source"):
+    """Index of a speaker in ``id_to_spkr``; an absent name raises KeyError as the reference's
+    ``self.spkr_to_id[spkr_name]`` does (sr/dataset.py:319-322) instead of silently conditioning on speaker 0."""
+    try:
+        return int(spkr_to_id[name])
+    except KeyError:
+        raise KeyError(f"{what} speaker {name!r} is not in id_to_spkr ({len(spkr_to_id)} speakers); "
+                       "pass --unseen_speaker for speakers outside the training set") from None

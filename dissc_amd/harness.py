@@ -229,18 +229,22 @@ def _to_host(t):
         return out
     cap = stage.numel() // 2
     halves = (stage[:cap], stage[cap:2 * cap])
-    events = (torch.cuda.Event(), torch.cuda.Event())
     chunks = [(o, min(cap, n - o)) for o in range(0, n, cap)]
-    for i, (o, k) in enumerate(chunks[:1]):
+    # copies and events both go to t's device's current stream: on a non-current device a bare Event.record() would
+    # land on another device's stream and order nothing
+    with torch.cuda.device(t.device):
+        st = torch.cuda.current_stream(t.device)
+        events = (torch.cuda.Event(), torch.cuda.Event())
+        o, k = chunks[0]
         halves[0][:k].copy_(t[o:o + k], non_blocking=True)
-        events[0].record()
-    for i, (o, k) in enumerate(chunks):
-        if i + 1 < len(chunks):
-            o2, k2 = chunks[i + 1]
-            halves[(i + 1) & 1][:k2].copy_(t[o2:o2 + k2], non_blocking=True)
-            events[(i + 1) & 1].record()
-        events[i & 1].synchronize()
-        out[o:o + k] = halves[i & 1][:k].numpy()
+        events[0].record(st)
+        for i, (o, k) in enumerate(chunks):
+            if i + 1 < len(chunks):
+                o2, k2 = chunks[i + 1]
+                halves[(i + 1) & 1][:k2].copy_(t[o2:o2 + k2], non_blocking=True)
+                events[(i + 1) & 1].record(st)
+            events[i & 1].synchronize()
+            out[o:o + k] = halves[i & 1][:k].numpy()
     return out
 
 

@@ -241,7 +241,10 @@ int dissc_hubert_frames(int n_samples);
 size_t dissc_hubert_workspace_bytes(dissc_hubert_t m, int B, int Nmax);
 /* wav f32 [B,Nmax] (16 kHz, un-normalised like hubert-base), n_samples i32 [B] (NULL = Nmax)
  * -> dense_out f32 [B,768,ldT] channels-first, ldT = frames(Nmax) rounded up to 4 (may be NULL)
- *    units_out i64 [B,frames(Nmax)] (may be NULL).  Each utterance is exact w.r.t. a B=1 run. */
+ *    units_out i64 [B,frames(Nmax)] (may be NULL).  Each utterance is exact w.r.t. a B=1 run.
+ * A model handle is SINGLE-STREAM: the part streams and fork/join events of the split forward belong to the handle, so
+ * two forwards of one handle must not be in flight at once (create one handle per concurrent stream).  On error, `stream`
+ * has already been made to wait for every part stream that received work: the workspace may be reused once it drains. */
 int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_samples, int B, int Nmax,
                          float* dense_out, int64_t* units_out, void* workspace,
                          size_t workspace_bytes, void* stream);

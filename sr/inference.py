@@ -131,7 +131,9 @@ def build_jobs(a, h, samples, id_to_spkr, f0_stats_cfg, target_f0_stats):
                 raise FileNotFoundError(f"--eval_mode needs the ground-truth audio {audio_path}")
             code_len = min(len(gt) // hop, len(code))
             code, f0 = code[:code_len], f0[:code_len]
-        src_name = formats.speaker_of(str(audio_path))
+        # speaker rule of the vocoder config (reference sr/dataset.py:132-147); configs without `multispkr` have no
+        # speaker embedding, the name then only selects F0 statistics (the '_' rule, like every shipped config)
+        src_name = formats.parse_speaker(audio_path, h.get('multispkr', None) or '_')
         if h.get('f0_normalize', False) and f0_stats_cfg is not None:
             st = f0_stats_cfg.get(src_name, None)
             mean, std = (st['mean'], st['std']) if st is not None else (f0_stats_cfg['f0_mean'], f0_stats_cfg['f0_std'])
@@ -139,9 +141,13 @@ def build_jobs(a, h, samples, id_to_spkr, f0_stats_cfg, target_f0_stats):
             if h.get('f0_median', False) and ii.any():
                 f0[~ii] = (np.median(f0[ii]) - mean) / std
             f0[ii] = (f0[ii] - mean) / std
-        src_id = 0 if a.unseen_speaker else spkr_to_id.get(src_name, 0)
+        emits_src = a.sample_df is None and not a.unseen_speaker
+        if a.unseen_speaker or not h.get('multispkr', None):
+            src_id = 0  # reference sr/dataset.py:292-293 (unseen) / no speaker embedding at all
+        else:  # the reference's data set looks the source speaker up for every item, converted or not
+            src_id = formats.speaker_id(src_name, spkr_to_id)  # KeyError like sr/dataset.py:319-322
         items.append((stem, audio_path, len(code)))
-        if a.sample_df is None and not a.unseen_speaker:
+        if emits_src:
             jobs.append(dict(code=code, f0=f0, spkr=src_id, out=f"{stem}_gen.wav"))
         if h.get('multispkr', None) and a.vc:
             local = spkrs if a.target_speakers is not None else \

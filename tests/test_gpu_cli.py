@@ -206,6 +206,17 @@ def test_encode_cli_roundtrip(gpu, golden_dir, tmp_path):
         top2 = torch.topk(dist, 2, largest=False).values
         safe = ((top2[:, 1] - top2[:, 0]) > 0.02).numpy()
         np.testing.assert_array_equal(np.array(d["units"])[safe], units.numpy()[safe])
+    # a run that died leaves <out_file>.partial: the next run resumes from it (the finished file is not encoded again --
+    # its line comes back verbatim, a torn last line is dropped) and the manifest keeps the listdir order
+    first = lines[0]
+    marked = dict(first, durations=[7] * 99)
+    with open(f"{td}/out/enc2.txt.partial", "w") as f:
+        f.write(json.dumps(marked) + "\n" + '{"units": [1, 2')
+    cli.main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/out/enc2.txt", "--checkpoint_dir", f"{td}/ckpt"])
+    again = [json.loads(x) for x in open(f"{td}/out/enc2.txt").read().strip().split("\n")]
+    assert [d["audio"] for d in again] == [d["audio"] for d in lines]
+    assert again[0] == marked and again[1] == lines[1]
+    assert not os.path.exists(f"{td}/out/enc2.txt.partial")
 
 
 def test_in_memory_converter_equals_file_pipeline(gpu, golden_dir, tmp_path):

@@ -92,3 +92,43 @@ def test_hubert_loader_accepts_fairseq_and_hf_layouts():
     assert tuple(a["encoder.pos_conv.0.weight"].shape) == (768, 48, 128)
     for k in a:
         assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+
+
+def test_parse_speaker_modes_and_unknown_source_speaker():
+    """reference sr/dataset.py:132-147 (the five `multispkr` rules) and :319-322 (an unknown speaker is a KeyError)."""
+    import argparse
+    from pathlib import Path
+
+    import pytest
+    from dissc_amd import AttrDict, formats
+    p = "/data/corpus/spkA/sess3/p226_001_mic2.wav"
+    assert formats.parse_speaker(p, "parent_name") == "sess3"
+    assert formats.parse_speaker(Path(p), "parent_parent_name") == "spkA"
+    assert formats.parse_speaker(p, "_") == "p226"
+    assert formats.parse_speaker(p, "single") == "A"
+    assert formats.parse_speaker(p, lambda q: q.stem.upper()) == "P226_001_MIC2"
+    with pytest.raises(NotImplementedError):
+        formats.parse_speaker(p, "basename")
+    with pytest.raises(KeyError, match="p999"):
+        formats.speaker_id("p999", {"p226": 0})
+
+    sr = _load("sr_host_spk", "sr/inference.py")
+    samples = [{"audio": "x/p226_001.wav", "units": [1, 2, 3], "f0": [0.0, 1.0, 2.0]}]
+
+    def args(**kw):
+        d = dict(sample_df=None, target_speakers=["p231"], data_path="/data/spkB", debug=False, n=-1, parts=False,
+                 eval_mode=True, pad=None, unseen_speaker=False, vc=True)
+        d.update(kw)
+        return argparse.Namespace(**d)
+
+    ids = ["p226", "p231", "spkB", "A"]
+    for rule, want in (("_", 0), ("parent_name", 2), ("single", 3)):
+        jobs, _ = sr.build_jobs(args(), AttrDict({"multispkr": rule}), samples, ids, None, None)
+        assert [j["spkr"] for j in jobs] == [want, 1] and jobs[1]["out"] == "p226_001_1_gen.wav"
+    # an unknown source speaker: KeyError like the reference's data set, speaker 0 only with --unseen_speaker
+    with pytest.raises(KeyError, match="p226"):
+        sr.build_jobs(args(), AttrDict({"multispkr": "_"}), samples, ["p231", "p232"], None, None)
+    jobs, _ = sr.build_jobs(args(unseen_speaker=True), AttrDict({"multispkr": "_"}), samples, ["p231", "p232"], None, None)
+    assert [(j["spkr"], j["out"]) for j in jobs] == [(0, "p226_001_0_gen.wav")]
+    with pytest.raises(NotImplementedError):
+        sr.build_jobs(args(), AttrDict({"multispkr": "nope"}), samples, ids, None, None)
