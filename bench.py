@@ -53,7 +53,26 @@ def host_cpu_info():
     return phys or len(avail), len(avail), model
 
 
-def cpu_baseline(synth, sd, code, f0, spkr, budget_s=14.0, max_utts=400):
+PARITY_TOL_RMS = 1e-4   # north_star / BASELINE.md 4.5: RMS(gpu - cpu) <= 1e-4 ...
+PARITY_TOL_REL = 1e-3   # ... and <= 1e-3 of the reference waveform's RMS
+SCHEMA = 4              # bench line layout version (round number of the last change of workloads / fields)
+
+
+def parity_vs(ref_waves, y_host):
+    """RMS / relative / max error of the GPU batch `y_host` [B,1,L] against the oracle waveforms the CPU baseline leg
+    produced for the first len(ref_waves) utterances of the same batch (same run, same inputs)."""
+    n = len(ref_waves)
+    ref = torch.stack([r.reshape(-1) for r in ref_waves]).double()
+    err = y_host[:n].reshape(n, -1).double() - ref
+    rms = float(err.pow(2).mean().sqrt())
+    ref_rms = float(ref.pow(2).mean().sqrt())
+    return {"rms": rms, "rel": rms / max(ref_rms, 1e-30), "max": float(err.abs().max()), "ref_rms": ref_rms, "utts": n,
+            "worst_utt_rms": float(err.pow(2).mean(1).sqrt().max()), "tol_rms": PARITY_TOL_RMS, "tol_rel": PARITY_TOL_REL,
+            "against": "oracle/generator_ref.py (CPU restatement pinned to the reference, tests/test_oracle_golden.py), B=1 per "
+                       "utterance, the waveforms the cpu_baseline leg produced while being timed"}
+
+
+def cpu_baseline(synth, sd, code, f0, spkr, budget_s=14.0, max_utts=400, keep=8):
     """The CPU oracle (kind='port': plain-PyTorch restatement pinned to the reference,
     tests/test_oracle_golden.py) timed the way the reference runs: B=1 per utterance on the host
     cores.  Bounded sample of the same workload: thread count picked by a probe on a full 10 s
@@ -75,18 +94,20 @@ def cpu_baseline(synth, sd, code, f0, spkr, budget_s=14.0, max_utts=400):
     torch.set_num_threads(threads)
     for b in range(3):
         one(b % code.shape[0])
-    times, t0 = [], time.perf_counter()
+    times, t0, waves = [], time.perf_counter(), []
     while len(times) < max_utts and (len(times) < 5 or time.perf_counter() - t0 < budget_s):
         t = time.perf_counter()
-        one(len(times) % code.shape[0])
+        w = one(len(times) % code.shape[0])
         times.append(time.perf_counter() - t)
+        if len(waves) < min(keep, code.shape[0]):  # utterances 0 .. keep-1 of the batch, for the in-run parity figure
+            waves.append(w)
     sec = code.shape[1] * 320 / 16000.0
     med = float(np.median(times))
     return {"value": round(sec / med, 2), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
             "physical_cores": phys, "logical_cpus": logical, "cpu_model": model,
             "sample": f"{len(times)} x {sec:g} s utterances, B=1 each (reference style), torch CPU fp32, {threads} threads "
                       f"(best of a probe on a full utterance), 3 warm-ups, median of {len(times)} "
-                      f"(mean rate {sec * len(times) / sum(times):.2f}), {sum(times):.1f} s of CPU work"}
+                      f"(mean rate {sec * len(times) / sum(times):.2f}), {sum(times):.1f} s of CPU work"}, waves
 
 
 class _FakeGenerator:
@@ -328,7 +349,7 @@ def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_se
     return {"arithmetic": "bf16 hi/lo operand split, 3 bf16 MFMAs per product, fp32 accumulate "
                           "(CodeGenerator(h, precision='split_bf16') / dissc_set_option('precision', 1); default is exact fp32)",
             "ms_per_step": round(dt * 1e3, 3), "value": round(audio_sec_per_step / dt, 1),
-            "unit": "audio-sec/sec",
+            "unit": "audio-sec/sec", "_y_head": y[:8].cpu(),
             # 3 bf16 MFMA products per algorithmic multiply-add, against the dense bf16 peak
             "roofline": {"bound": "mfma", "achieved": round(3 * flops_step / dt / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s (bf16)", "frac": round(3 * flops_step / dt / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)},
@@ -495,6 +516,7 @@ def main():
 
     audio_sec_per_step = world * B * T * hop / 16000.0
     value = audio_sec_per_step * a.steps / dt
+    y_head = y[:8].cpu() if rank == 0 else None  # the timed loop's last fp32 batch, for the in-run parity figure
 
     # strong-scaling figure (every rank takes part; rank 0 reports): a fixed ragged job list at every N
     strong = None
@@ -513,6 +535,7 @@ def main():
         ach = flops_exec / kern_s / 1e12      # the roofline fraction is taken on EXECUTED work, so it stays <= 1
         ach_alg = flops_step / kern_s / 1e12
         out = {
+            "schema": SCHEMA,
             "metric": "audio-sec/sec (RTF) HiFi-GAN resynth, 10s x32 batch",
             "value": round(value, 1), "unit": "audio-sec/sec", "n_gpus": n_gpus,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -564,13 +587,27 @@ def main():
                 out["pipeline"] = pipeline_leg(synth, dev, g)
             except Exception as e:  # noqa: BLE001
                 out["pipeline"] = {"error": f"{type(e).__name__}: {e}"}
+        y_split = out["split_bf16"].pop("_y_head", None) if isinstance(out.get("split_bf16"), dict) else None
+        parity_failed = None
         if not a.no_cpu_baseline and n_gpus == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(synth, sd, torch.from_numpy(code), torch.from_numpy(f0),
-                                                   torch.from_numpy(spkr))
+                out["cpu_baseline"], ref_waves = cpu_baseline(synth, sd, torch.from_numpy(code), torch.from_numpy(f0),
+                                                              torch.from_numpy(spkr))
+                # parity in the same run: the timed GPU batch against the oracle's waveforms
+                out["parity"] = parity_vs(ref_waves, y_head)
+                if y_split is not None:
+                    out["split_bf16"]["parity"] = parity_vs(ref_waves, y_split)
+                pr = out["parity"]
+                if not (pr["rms"] <= PARITY_TOL_RMS and pr["rel"] <= PARITY_TOL_REL):
+                    parity_failed = f"fp32 path: rms {pr['rms']:.3e} (tol {PARITY_TOL_RMS}), rel {pr['rel']:.3e} (tol {PARITY_TOL_REL})"
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
+        if parity_failed:
+            print("bench.py: PARITY FAILED -- " + parity_failed, file=sys.stderr, flush=True)
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(3)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -115,6 +115,61 @@ def kmeans_margin(x, centers):
     return top2[:, 1] - top2[:, 0]
 
 
+FEAT_EPS_L2_REL = 2e-4  # asserted bound on ||x_gpu[t] - x_ref[t]||_2 / ||x_ref[t]||_2 (the GPU tests assert it per frame)
+
+
+def unit_flip_allowed(x_ref, centers, eps_l2=None, eps_rel=FEAT_EPS_L2_REL):
+    """Which unit changes a feature error can explain -- DERIVED, not a hand-set margin.
+
+    With s_k(x) = ||c_k||^2 - 2 <x, c_k> (the expression of kmeans_assign) and a feature error delta,
+    (s_j - s_i)(x + delta) = (s_j - s_i)(x) + 2 <delta, c_i - c_j>, so a frame whose reference unit is i can come out as j
+    only if   s_j(x) - s_i(x) <= 2 ||c_i - c_j||_2 ||delta||_2 + r_ij,
+    where r_ij bounds the rounding of the two fp32 evaluations of s (reference and device, each a length-D dot product:
+    |fl(s_k) - s_k| <= gamma_D (||c_k||^2 + 2 sum_d |x_d c_kd|), gamma_D = D u / (1 - D u), u = 2^-24).
+    ``eps_l2`` [T]: the per-frame ||delta||_2 (measured against the device's features when they are at hand); None =
+    the asserted bound ``eps_rel`` * ||x_ref[t]||_2.
+    -> (allowed bool [T,K]: allowed[t, j] = "unit j is explicable at frame t" (always True at the reference unit),
+        n_ambiguous int: frames with more than one allowed unit)."""
+    x = torch.as_tensor(x_ref).double()
+    c = torch.as_tensor(centers).double()
+    T, D = x.shape
+    s = (c * c).sum(1)[None, :] - 2.0 * (x @ c.t())                      # [T,K]
+    i = s.argmin(1)
+    gap = s - s.gather(1, i[:, None])                                    # s_j - s_i >= 0
+    if eps_l2 is None:
+        eps_l2 = eps_rel * x.norm(dim=1)
+    eps_l2 = torch.as_tensor(eps_l2).double().reshape(T)
+    cdist = torch.cdist(c, c)                                            # [K,K]
+    u = 2.0 ** -24
+    gamma = D * u / (1 - D * u)
+    mag = (c * c).sum(1)[None, :] + 2.0 * (x.abs() @ c.abs().t())        # [T,K]
+    r = 2.0 * gamma * (mag + mag.gather(1, i[:, None]))                  # both evaluations, both terms
+    allowed = gap <= 2.0 * cdist[i] * eps_l2[:, None] + r
+    return allowed.numpy(), int((allowed.sum(1) > 1).sum())
+
+
+def check_units(units, units_ref, x_ref, centers, x_dev=None, tag="units"):
+    """Assert: every frame where ``units`` differs from the reference's is explained by the feature error (measured when
+    ``x_dev`` is given, else the asserted FEAT_EPS_L2_REL bound) -- and the unit chosen instead is one of the explicable
+    ones.  Returns (n_mismatch, n_ambiguous)."""
+    import numpy as np
+    x_ref = torch.as_tensor(x_ref)
+    eps = None
+    if x_dev is not None:
+        eps = (torch.as_tensor(x_dev).double() - x_ref.double()).norm(dim=1)
+        rel = eps / x_ref.double().norm(dim=1).clamp_min(1e-30)
+        assert float(rel.max()) <= FEAT_EPS_L2_REL, f"{tag}: per-frame feature error {float(rel.max()):.3e} > {FEAT_EPS_L2_REL}"
+    allowed, n_amb = unit_flip_allowed(x_ref, centers, eps)
+    units, units_ref = np.asarray(units).reshape(-1), np.asarray(units_ref).reshape(-1)
+    assert units.shape == units_ref.shape == (allowed.shape[0],)
+    ok = allowed[np.arange(len(units)), units]
+    mism = units != units_ref
+    print(f"{tag}: {int(mism.sum())} mismatching frames, {n_amb} ambiguous frames of {len(units)}"
+          + (f", feature error <= {float(rel.max()):.2e} (l2, relative, per frame)" if x_dev is not None else ""))
+    assert ok.all(), f"{tag}: frames {np.nonzero(~ok)[0][:10]} got units {units[~ok][:10]}, reference {units_ref[~ok][:10]}"
+    return int(mism.sum()), n_amb
+
+
 @torch.no_grad()
 def encode(sd, centers, wav, n_layers=6):
     """One utterance like the reference (B=1, data/encode.py:32): wav [1,N] -> (units [T], dense [T,768])"""

@@ -202,10 +202,8 @@ def test_encode_cli_roundtrip(gpu, golden_dir, tmp_path):
         assert sr == 16000 and len(x) == 32000
         units, dense = hr.encode(sd, centers, torch.from_numpy(x)[None])
         assert len(d["units"]) == 99 == len(d["f0"]) == len(d["durations"])
-        dist = ((dense[:, None, :] - centers[None]) ** 2).sum(-1)
-        top2 = torch.topk(dist, 2, largest=False).values
-        safe = ((top2[:, 1] - top2[:, 0]) > 0.02).numpy()
-        np.testing.assert_array_equal(np.array(d["units"])[safe], units.numpy()[safe])
+        # the CLI does not return features: the asserted feature-error bound stands in for the measured one
+        hr.check_units(np.array(d["units"]), units.numpy(), dense, centers, tag=d["audio"])
     # a run that died leaves <out_file>.partial: the next run resumes from it (the finished file is not encoded again --
     # its line comes back verbatim, a torn last line is dropped) and the manifest keeps the listdir order
     first = lines[0]

@@ -171,12 +171,9 @@ def test_hubert_oracle_matches_hf_and_sklearn(hgold, n):
     want = hgold[f"n{n}/dense"]
     assert dense.shape == want.shape
     assert np.abs(dense.numpy() - want).max() <= 2e-4 * max(1.0, np.abs(want).max())
-    # unit indices: equal wherever the top-2 centroid margin is above rounding noise
-    d = ((torch.from_numpy(want)[:, None, :] - centers[None]) ** 2).sum(-1)
-    top2 = torch.topk(d, 2, largest=False).values
-    safe = ((top2[:, 1] - top2[:, 0]) > 0.02).numpy()  # distances are O(1e3); fp32 noise ~1e-3
-    np.testing.assert_array_equal(units.numpy()[safe], hgold[f"n{n}/units"][safe])
-    assert safe.mean() > 0.9
+    # unit indices: equal except where the measured feature difference explains the other unit (derived bound)
+    mism, amb = hr.check_units(units.numpy(), hgold[f"n{n}/units"], want, centers, x_dev=dense.numpy(), tag=f"n={n}")
+    assert amb <= 0.1 * len(want) + 1
     if n <= 4000:
         cnn = hr.conv_feature_extractor(sd, wav)
         assert np.abs(cnn.numpy() - hgold[f"n{n}/cnn"]).max() <= 1e-4

@@ -1,0 +1,260 @@
+"""Parity against the un-vendored third parties THEMSELVES (fairseq HuBERT, amfm_decompy YAAPT, resampy / librosa),
+for every pin file ``tools/pin_third_party.py`` has written into ``$DISSC_PIN_DIR`` (default tests/golden).  Those
+libraries cannot be imported in the build container, so the files are absent there and these tests SKIP -- rows a2-a5 /
+N2 / N3 stay "parity unpinned" until someone with the libraries runs the one command and commits its output.  The last
+test drives the script with stub libraries, so that the route itself (detection, file layout, these tests reading the
+files) is exercised on every CPU run."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PIN_DIR = os.environ.get("DISSC_PIN_DIR", os.path.join(ROOT, "tests", "golden"))
+FS = 16000
+
+
+def _pin(name):
+    p = os.path.join(PIN_DIR, name)
+    if not os.path.exists(p):
+        pytest.skip(f"{name} not pinned yet (run tools/pin_third_party.py where the library imports)")
+    return np.load(p)
+
+
+def _keys(g, prefix):
+    return sorted(k[len(prefix):] for k in g.files if k.startswith(prefix))
+
+
+def _f0_agrees(f0, want, tag):
+    """voicing decisions on >= 98 % of the frames, voiced values within 0.5 % (p95) and 3 % (max)"""
+    f0, want = np.asarray(f0, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert f0.shape == want.shape, (tag, f0.shape, want.shape)
+    assert ((f0 > 0) == (want > 0)).mean() >= 0.98, (tag, ((f0 > 0) == (want > 0)).mean())
+    both = (f0 > 0) & (want > 0)
+    if both.any():
+        rel = np.abs(f0[both] - want[both]) / want[both]
+        assert np.percentile(rel, 95) <= 5e-3 and rel.max() <= 3e-2, (tag, np.percentile(rel, 95), rel.max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU: the oracle restatements against the libraries' outputs
+# ---------------------------------------------------------------------------------------------------------------
+def test_oracle_resampler_and_trim_match_resampy_librosa():
+    from oracle import preprocess_ref as pr
+    g = _pin("resample_resampy.npz")
+    for sr in _keys(g, "in/"):
+        got = pr.resample(g[f"in/{sr}"], int(sr), FS)
+        want = g[f"out/{sr}"]
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), (sr, np.abs(got - want).max())
+    if "trim/in" in g.files:
+        y, (s, e) = pr.trim(g["trim/in"], top_db=20)
+        assert [s, e] == list(g["trim/index"])
+        np.testing.assert_array_equal(y, g["trim/out"])
+
+
+def test_oracle_yaapt_matches_amfm_decompy():
+    from oracle import yaapt_ref as yr
+    g = _pin("yaapt_amfm.npz")
+    for name in _keys(g, "in/"):
+        _f0_agrees(yr.get_yaapt_f0(g[f"in/{name}"]), g[f"f0/{name}"], name)
+
+
+def test_oracle_hubert_matches_fairseq():
+    from oracle import hubert_ref as hr
+    import synthdata as synth
+    g = _pin("hubert_fairseq.npz")
+    sd, centers = synth.synth_hubert_state_dict(6), synth.synth_kmeans_centers()
+    for key in _keys(g, "n"):
+        if not key.endswith("/dense"):
+            continue
+        n = int(key.split("/")[0])
+        units, dense = hr.encode(sd, centers, torch.from_numpy(synth.synth_waveform(n, seed=n))[None])
+        want = g[f"n{n}/dense"]
+        assert dense.shape == want.shape
+        assert np.abs(dense.numpy() - want).max() <= 2e-4 * max(1.0, np.abs(want).max())
+        hr.check_units(units.numpy(), g[f"n{n}/units"], want, centers, x_dev=dense.numpy(), tag=f"fairseq n={n}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU: the HIP path against the same files
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_resampler_matches_resampy():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from dissc_amd import audio
+    g = _pin("resample_resampy.npz")
+    for sr in _keys(g, "in/"):
+        got = audio.resample(g[f"in/{sr}"], int(sr), FS)
+        assert np.abs(got - g[f"out/{sr}"]).max() <= 1e-9 * max(1.0, np.abs(g[f"out/{sr}"]).max())
+
+
+@pytest.mark.gpu
+def test_hip_yaapt_matches_amfm_decompy():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from dissc_amd.f0 import YaaptTracker
+    g = _pin("yaapt_amfm.npz")
+    names = _keys(g, "in/")
+    tracks = YaaptTracker(device="cuda:0")([g[f"in/{n}"] for n in names])
+    for n, t in zip(names, tracks):
+        _f0_agrees(t, g[f"f0/{n}"], n)
+
+
+@pytest.mark.gpu
+def test_hip_hubert_matches_fairseq():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from dissc_amd.hubert import HubertEncoder
+    from oracle import hubert_ref as hr
+    import synthdata as synth
+    g = _pin("hubert_fairseq.npz")
+    centers = synth.synth_kmeans_centers()
+    enc = HubertEncoder(synth.synth_hubert_state_dict(6), centers, n_layers=6).to("cuda:0")
+    for key in _keys(g, "n"):
+        if not key.endswith("/dense"):
+            continue
+        n = int(key.split("/")[0])
+        out = enc(torch.from_numpy(synth.synth_waveform(n, seed=n))[None])
+        dense, want = out["dense"][0].cpu().numpy(), g[f"n{n}/dense"]
+        assert np.abs(dense - want).max() <= 5e-4 * max(1.0, np.abs(want).max())
+        hr.check_units(out["units"][0].cpu().numpy(), g[f"n{n}/units"], want, centers, x_dev=dense, tag=f"fairseq n={n}")
+
+
+@pytest.mark.gpu
+def test_hip_encoder_matches_textless_with_the_real_checkpoints():
+    """bit-exact unit indices (north_star) against the reference's literal encoder call, wherever the real
+    hubert-base-ls960 / km100 files are at hand ($DISSC_CHECKPOINT_DIR)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    g = _pin("hubert_textless_real.npz")
+    ckpt = os.environ.get("DISSC_CHECKPOINT_DIR")
+    if not ckpt or not os.path.isdir(ckpt):
+        pytest.skip("DISSC_CHECKPOINT_DIR with the real checkpoints is not set")
+    from scipy.io import wavfile
+    from dissc_amd.hubert import SpeechEncoder
+    from oracle import hubert_ref as hr
+    enc = SpeechEncoder.by_name(checkpoint_dir=ckpt).to("cuda:0")
+    centers = enc.model.centers.cpu() if hasattr(enc.model, "centers") else None
+    for name in ("s1_1", "s1_2"):
+        sr, x = wavfile.read(os.path.join(ROOT, "tests", "golden", name + ".wav"))
+        out = enc(torch.from_numpy(x.astype(np.float32) / 32768.0)[None])
+        units = out["units"].cpu().numpy().reshape(-1)
+        want = g[f"{name}/units"].reshape(-1)
+        if centers is not None:
+            hr.check_units(units, want, g[f"{name}/dense"], centers, x_dev=out["dense"].cpu().numpy().reshape(len(want), -1),
+                           tag=f"textless {name}")
+        else:
+            np.testing.assert_array_equal(units, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the route itself, with stub libraries (they answer with the oracle, so the pins must then agree with it)
+# ---------------------------------------------------------------------------------------------------------------
+STUBS = {
+    "resampy/__init__.py": """
+        from oracle import preprocess_ref as _pr
+        __version__ = "0.0-stub"
+        def resample(x, sr_orig, sr_new, **kw):
+            return _pr.resample(x, sr_orig, sr_new)
+    """,
+    "librosa/__init__.py": """
+        from . import effects
+        __version__ = "0.0-stub"
+    """,
+    "librosa/effects.py": """
+        from oracle import preprocess_ref as _pr
+        def trim(y, top_db=60, **kw):
+            out, (s, e) = _pr.trim(y, top_db=top_db)
+            return out, (s, e)
+    """,
+    "amfm_decompy/__init__.py": """
+        __version__ = "0.0-stub"
+    """,
+    "amfm_decompy/basic_tools.py": """
+        class SignalObj:
+            def __init__(self, data, fs):
+                self.data, self.fs = data, fs
+    """,
+    "amfm_decompy/pYAAPT.py": """
+        from oracle import yaapt_ref as _yr
+        class _Pitch:
+            pass
+        def yaapt(signal, **kw):
+            assert kw == {'frame_length': 20.0, 'frame_space': 5.0, 'nccf_thresh1': 0.25, 'tda_frame_length': 25.0}, kw
+            p = _Pitch()
+            p.samp_values = _yr.yaapt(signal.data, signal.fs)
+            return p
+    """,
+    "fairseq/__init__.py": """
+        __version__ = "0.0-stub"
+    """,
+    "fairseq/models/__init__.py": "",
+    "fairseq/tasks/__init__.py": "",
+    "fairseq/tasks/hubert_pretraining.py": """
+        class HubertPretrainingConfig:
+            pass
+    """,
+    "fairseq/models/hubert.py": """
+        import torch
+        from oracle import hubert_ref as _hr
+        class HubertConfig:
+            def __init__(self, encoder_layers=12):
+                self.encoder_layers = encoder_layers
+        class HubertModel(torch.nn.Module):
+            def __init__(self, cfg, task_cfg, dictionaries):
+                super().__init__()
+                assert len(dictionaries[0]) > 0
+                self.cfg, self.sd = cfg, None
+            def load_state_dict(self, sd, strict=True):
+                self.sd = sd
+                return ["mask_emb", "final_proj.weight"], []
+            def extract_features(self, source, padding_mask=None, mask=False, ret_conv=False, output_layer=None):
+                assert not mask and output_layer == self.cfg.encoder_layers
+                x = _hr.encoder(self.sd, _hr.conv_feature_extractor(self.sd, source), output_layer)
+                return x, None
+    """,
+}
+
+
+def test_pin_script_route_with_stub_libraries(tmp_path):
+    if os.environ.get("DISSC_PIN_NESTED") == "1":
+        pytest.skip("running under tools/pin_third_party.py itself")
+    script = os.path.join(ROOT, "tools", "pin_third_party.py")
+    # (1) here, without the libraries: everything is skipped cleanly
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("DISSC_PIN_DIR", None)
+    r = subprocess.run([sys.executable, script, "--out", str(tmp_path / "none")], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    have = [m for m in ("resampy", "amfm_decompy", "fairseq") if _importable(m)]
+    if not have:
+        assert "pinned: []" in r.stdout and not os.listdir(tmp_path / "none")
+    # (2) with stubs on the path: three files, and the parity tests above pass against them
+    stubs = tmp_path / "stubs"
+    for rel, body in STUBS.items():
+        p = stubs / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_text(textwrap.dedent(body))
+    out = tmp_path / "pins"
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(stubs), ROOT]))
+    r = subprocess.run([sys.executable, script, "--out", str(out)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert sorted(os.listdir(out)) == ["hubert_fairseq.npz", "resample_resampy.npz", "yaapt_amfm.npz"]
+    assert "3 passed, 1 skipped" in r.stdout, r.stdout[-2000:]
+    g = np.load(out / "yaapt_amfm.npz")
+    assert {"s1_1", "s1_2", "flat120"} <= set(_keys(g, "f0/")) and len(g["f0/s1_1"]) == 400
+    g = np.load(out / "resample_resampy.npz")
+    assert len(g["out/48000"]) == 4000 and list(g["trim/index"]) == [int(v) for v in g["trim/index"]]
+    g = np.load(out / "hubert_fairseq.npz")
+    assert g["n32000/dense"].shape == (99, 768) and g["n32000/units"].shape == (99,)
+
+
+def _importable(name):
+    import importlib.util
+    return importlib.util.find_spec(name) is not None
