@@ -64,8 +64,13 @@ def build_parser():
     ap.add_argument("--target_speakers", nargs="+", required=True)
     ap.add_argument("--no_pred_len", action="store_true", help="keep the source rhythm (infer.py without --pred_len)")
     ap.add_argument("--round_seconds", default=16384.0, type=float,
-                    help="input audio x targets per rank and round: each round is gathered, written and freed "
-                         "(one round = one all-gather; the default holds 1 GiB of waveforms per rank)")
+                    help="input audio x targets per rank and round: each round is gathered, written and freed.  TWO "
+                         "collectives per round: a 16-byte all_reduce(MAX) of the exchange-buffer geometry (predicted "
+                         "durations size the outputs, so ranks cannot derive it from the file list) and ONE "
+                         "all_gather_into_tensor of the packed waveforms; the default holds 1 GiB of waveforms per rank.  "
+                         "Rounds are delivered (device-to-host copy, file writes) by a worker thread while the next one "
+                         "computes; env DISSC_WRITERS=rank0|all picks who writes at N > 1 (default all: every rank "
+                         "writes the conversions it produced)")
     return ap
 
 
@@ -142,15 +147,18 @@ def main(argv=None):
     if rank == 0:
         os.makedirs(a.output_dir, exist_ok=True)
 
-    def write(waves):  # rank 0, once per round: files are on disk before the next round starts
+    def write(waves):  # once per round, on the harness's delivery thread while the next round is computed
         for (i, t), w in sorted(waves.items()):
             wavfile.write(os.path.join(a.output_dir, f"{os.path.splitext(files[i])[0]}_{t}_gen.wav"),
                           h.sampling_rate, w)
 
+    # DISSC_WRITERS=all (default for N > 1): every rank writes the conversions it produced (it drains its own slice of
+    # the gathered buffer); rank0: rank 0 receives and writes every file
+    own = world > 1 and os.environ.get("DISSC_WRITERS", "all") != "rank0"
     n = conv.run_sharded(n_samples, load, targets, rank, world, dist, f0_stats=f0_stats, sink=write,
-                         round_floats=int(a.round_seconds * 16000))
-    if rank == 0:
-        print(f"{n} waveforms written to {a.output_dir}")
+                         round_floats=int(a.round_seconds * 16000), own_rows=own)
+    if own or rank == 0:
+        print(f"rank {rank}: {n} waveforms written to {a.output_dir}" if own else f"{n} waveforms written to {a.output_dir}")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

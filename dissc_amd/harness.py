@@ -248,29 +248,33 @@ def _to_host(t):
     return out
 
 
-_PIN_ROUND = {"buf": None}
+_PIN_ROUND = {}
 _PIN_ROUND_MAX_FLOATS = (2 << 30) // 4  # 2 GiB
 
 
-def _pinned_round(n_floats):
-    """One page-locked buffer for a whole round's waveforms (grown on demand, kept: page-locking 226 MB costs 45 ms), or
-    None when the round is larger than 2 GiB."""
+def _pinned_round(n_floats, slot=0):
+    """A page-locked buffer for a whole round's waveforms (grown on demand, kept: page-locking 226 MB costs 45 ms), or
+    None when the round is larger than 2 GiB.  Two slots: while a sink still reads round k out of one, round k + 1
+    lands in the other (Exchange)."""
     n = int(n_floats)
     if n > _PIN_ROUND_MAX_FLOATS:
         return None
-    if _PIN_ROUND["buf"] is None or _PIN_ROUND["buf"].numel() < n:
-        _PIN_ROUND["buf"] = None
-        _PIN_ROUND["buf"] = torch.empty(max(n, 1), dtype=torch.float32, pin_memory=True)
-    return _PIN_ROUND["buf"]
+    if _PIN_ROUND.get(slot) is None or _PIN_ROUND[slot].numel() < n:
+        _PIN_ROUND[slot] = None
+        _PIN_ROUND[slot] = torch.empty(max(n, 1), dtype=torch.float32, pin_memory=True)
+    return _PIN_ROUND[slot]
 
 
-def unpack_waves(gathered, n_cap, copy=False, stats=None, transient=False):
+def unpack_waves(gathered, n_cap, copy=False, stats=None, transient=False, ranks=None, slot=0):
     """gathered: f32 [world * (4 + 4*n_cap + data_cap)] or [world, ...] (any device) -> {job_id: 1-D float32
     numpy array}.  From a device buffer only what the tables say is in use comes over: the world headers +
     tables first (a few KB), then each rank's used data region through the page-locked staging buffer.
     A host buffer is viewed in place unless ``copy``.  ``transient``: the caller consumes the arrays before the next
     call (a ``sink`` that writes the files of a round) -- they are then views of ONE cached page-locked buffer the
-    device copies straight into, which saves the host memcpy out of the staging buffer (22 ms per 226 MB)."""
+    device copies straight into, which saves the host memcpy out of the staging buffer (22 ms per 226 MB); ``slot``
+    picks which of the two cached buffers.  ``ranks``: only the regions packed by these source ranks are read
+    (None = all) -- the others are neither copied nor unpacked.  Device work goes to the CURRENT stream of the buffer's
+    device (the Exchange worker calls this under its own copy stream)."""
     tbl = HDR + ENT * n_cap
     g = gathered.reshape(-1)
     per = None
@@ -287,9 +291,17 @@ def unpack_waves(gathered, n_cap, copy=False, stats=None, transient=False):
     heads = (heads.cpu() if heads.is_cuda else heads).contiguous().numpy().view(np.int32).reshape(world, 1 + n_cap, 4)
     moved = 0
     useds = [int(heads[r, 0, 2:4].copy().view(np.int64)[0]) for r in range(world)]
+    rows = [int(heads[r, 0, 0]) for r in range(world)]
+    for r in range(world):
+        if rows[r] < 0 or rows[r] > n_cap or useds[r] < 0 or useds[r] > per - tbl:
+            raise ValueError(f"rank {r}: corrupt exchange header (rows {rows[r]}, data floats {useds[r]})")
+    if ranks is not None:
+        keep = set(int(r) for r in ranks)
+        useds = [u if r in keep else 0 for r, u in enumerate(useds)]
+        rows = [n if r in keep else 0 for r, n in enumerate(rows)]
     big = None
     if transient and g2.is_cuda and all(0 <= u <= per - tbl for u in useds):
-        big = _pinned_round(sum(useds))
+        big = _pinned_round(sum(useds), slot)
         if big is not None:  # every rank's region straight into its slice of the round buffer, one synchronisation
             o = 0
             for r in range(world):
@@ -299,10 +311,8 @@ def unpack_waves(gathered, n_cap, copy=False, stats=None, transient=False):
             torch.cuda.current_stream(g2.device).synchronize()
     big_off = 0
     for r in range(world):
-        n_rows = int(heads[r, 0, 0])
+        n_rows = rows[r]
         used = useds[r]
-        if n_rows < 0 or n_rows > n_cap or used < 0 or used > per - tbl:
-            raise ValueError(f"rank {r}: corrupt exchange header (rows {n_rows}, data floats {used})")
         if big is not None:
             data_big = big[big_off:big_off + used].numpy()
             big_off += used
@@ -329,15 +339,14 @@ def unpack_waves(gathered, n_cap, copy=False, stats=None, transient=False):
     return out
 
 
-def gather_store(store, n_cap, data_cap, rank, world_size, dist=None, unpack_ranks=(0,), stats=None, transient=False):
-    """The single collective of a round.  Returns {job_id: samples} on the ranks in ``unpack_ranks``
-    (None = every rank), {} elsewhere -- only the consumers pay the device-to-host copy.  The collective
-    runs whenever a process group is given (``dist`` not None), also at world_size 1."""
+def gather_store(store, n_cap, data_cap, rank, world_size, dist=None, unpack_ranks=(0,), stats=None, transient=False,
+                 src_ranks=None):
+    """The single collective of a round, synchronously.  Returns {job_id: samples} on the ranks in ``unpack_ranks``
+    (None = every rank), {} elsewhere -- only the consumers pay the device-to-host copy (``src_ranks``: and only for
+    the regions those ranks packed).  The collective runs whenever a process group is given (``dist`` not None),
+    also at world_size 1."""
     buf = store.pack(n_cap, data_cap)
-    if stats is not None:
-        stats["payload_floats"] = stats.get("payload_floats", 0) + sum(int(b[1].sum()) for b in store.batches)
-        stats["sent_floats"] = stats.get("sent_floats", 0) + buf.numel()
-        stats["collectives"] = stats.get("collectives", 0) + (1 if dist is not None else 0)
+    _exchange_stats(stats, store, buf, dist)
     if dist is not None:
         out = torch.empty(world_size * buf.numel(), dtype=torch.float32, device=buf.device)
         dist.all_gather_into_tensor(out, buf)
@@ -346,7 +355,172 @@ def gather_store(store, n_cap, data_cap, rank, world_size, dist=None, unpack_ran
         buf = buf.view(1, -1)
     if unpack_ranks is not None and rank not in unpack_ranks:
         return {}
-    return unpack_waves(buf, n_cap, stats=stats, transient=transient)
+    return unpack_waves(buf, n_cap, stats=stats, transient=transient, ranks=src_ranks)
+
+
+class Exchange:
+    """The rounds of one run as a pipeline: pack -> all-gather -> device-to-host -> unpack -> ``sink``.
+
+    ``submit(store, n_cap, data_cap)`` packs a round on the caller's stream and starts its all-gather ASYNCHRONOUSLY;
+    with a ``sink`` on a GPU the rest of the round -- waiting for the gather, the copy of the wanted regions into one of
+    two page-locked round buffers on a copy stream of its own, the unpack and the sink (rank 0 writing files) -- runs on
+    a worker thread, so the caller goes straight on to batch and launch the next round: at N ranks the serial tail of a
+    run is the delivery of its LAST round only, not of all of it (reference sr/inference.py:288-292,351-357 -- there
+    every pool worker writes its own files; here one collective per round brings them together).  At most two rounds
+    are in flight (two page-locked slots); a third ``submit`` waits for the oldest to be delivered.  Without a sink
+    (results returned as a dict) or on the CPU the rounds are delivered synchronously, as before.
+
+    Who delivers what: ``unpack_ranks`` (default rank 0; None = every rank) receive EVERY waveform of the round;
+    ``own_rows=True`` instead makes every rank deliver exactly the rows it packed itself (it reads only its own slice
+    of the gathered buffer), which spreads the device-to-host copies and the file writes over the ranks.
+    ``decode`` maps the {job id: samples} of a round to what the sink / the result dict should see.
+    Collectives are only ever ISSUED from the caller's thread, in the same order on every rank; the worker only waits."""
+
+    def __init__(self, rank, world_size, device, dist=None, unpack_ranks=(0,), own_rows=False, sink=None, stats=None,
+                 decode=None, overlap=None):
+        self.rank, self.world, self.device, self.dist = int(rank), int(world_size), torch.device(device), dist
+        self.own_rows = bool(own_rows)
+        self.delivers = self.own_rows or unpack_ranks is None or self.rank in unpack_ranks
+        self.src_ranks = [self.rank] if self.own_rows else None
+        self.sink, self.decode, self.stats = sink, decode, stats
+        cuda = self.device.type == "cuda"
+        if overlap is None:
+            overlap = cuda and sink is not None and os.environ.get("DISSC_EXCHANGE_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap) and sink is not None
+        self.result, self.delivered, self.k = {}, 0, 0
+        self.error = None
+        self._pending = []   # (work, buf, out) of rounds this rank does not deliver: kept until the collective is done
+        self._thread = self._q = self._slots = self._side = None
+        self.t = {"pack_s": 0.0, "submit_wait_s": 0.0, "gather_wait_s": 0.0, "unpack_s": 0.0, "sink_s": 0.0}
+        if self.overlap and self.delivers:
+            import queue
+            import threading
+            self._q = queue.Queue()
+            self._slots = threading.Semaphore(2)
+            if cuda:
+                with torch.cuda.device(self.device):
+                    self._side = torch.cuda.Stream(self.device)
+            self._thread = threading.Thread(target=self._run, name="dissc-exchange", daemon=True)
+            self._thread.start()
+
+    # -- worker ------------------------------------------------------------------------------------------------
+    def _deliver(self, k, work, ev, buf, n_cap):
+        import time
+        t0 = time.perf_counter()
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device), torch.cuda.stream(self._side):
+                if work is not None:
+                    work.wait()               # RCCL: the copy stream waits for the collective; gloo: the host does
+                elif ev is not None:
+                    self._side.wait_event(ev)
+                self._side.synchronize()      # split "waiting for the round" from "moving it"
+                t1 = time.perf_counter()
+                got = unpack_waves(buf, n_cap, stats=self.stats, transient=True, ranks=self.src_ranks, slot=k & 1)
+        else:
+            if work is not None:
+                work.wait()
+            t1 = time.perf_counter()
+            got = unpack_waves(buf, n_cap, stats=self.stats, transient=True, ranks=self.src_ranks)
+        t2 = time.perf_counter()
+        if self.decode is not None:
+            got = self.decode(got)
+        if got:
+            self.sink(got)
+        self.delivered += len(got)
+        t3 = time.perf_counter()
+        self.t["gather_wait_s"] += t1 - t0
+        self.t["unpack_s"] += t2 - t1
+        self.t["sink_s"] += t3 - t2
+
+    def _run(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            try:
+                if self.error is None:
+                    self._deliver(*item[:5])
+            except BaseException as e:  # noqa: BLE001  (handed to the caller's thread by submit / finish)
+                self.error = e
+            finally:
+                del item
+                self._slots.release()
+
+    # -- caller ------------------------------------------------------------------------------------------------
+    def _raise(self):
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+    def submit(self, store, n_cap, data_cap):
+        import time
+        if not (self.overlap and (self.dist is not None or self.delivers)):
+            # synchronous round (no sink, CPU, or overlap switched off): pack, gather, unpack, deliver
+            got = gather_store(store, n_cap, data_cap, self.rank, self.world, self.dist,
+                               (self.rank,) if self.delivers else (), self.stats, transient=self.sink is not None,
+                               src_ranks=self.src_ranks)
+            if self.decode is not None:
+                got = self.decode(got)
+            if self.sink is not None:
+                if got:
+                    self.sink(got)
+                self.delivered += len(got)
+            else:
+                self.result.update(got)
+            self.k += 1
+            return
+        self._raise()
+        t0 = time.perf_counter()
+        if self.delivers:
+            self._slots.acquire()  # at most two rounds in flight: the page-locked slot k & 1 must have been consumed
+            self._raise()
+        t1 = time.perf_counter()
+        buf = store.pack(n_cap, data_cap)
+        _exchange_stats(self.stats, store, buf, self.dist)
+        work = ev = out = None
+        if self.dist is not None:
+            out = torch.empty(self.world * buf.numel(), dtype=torch.float32, device=buf.device)
+            work = self.dist.all_gather_into_tensor(out, buf, async_op=True)
+            view = out.view(self.world, -1)
+        else:
+            view = buf.view(1, -1)
+            if self.device.type == "cuda":
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+        self.t["submit_wait_s"] += t1 - t0
+        self.t["pack_s"] += time.perf_counter() - t1
+        if self.delivers:
+            self._q.put((self.k, work, ev, view, n_cap, buf, out))  # buf / out ride along: alive until delivered
+        else:
+            self._pending.append((work, buf, out))
+            while len(self._pending) > 2:
+                self._pending.pop(0)[0].wait()
+        self.k += 1
+
+    def finish(self):
+        """Wait for every round to be delivered (and for every collective this rank took part in).  Returns the number
+        of waveforms delivered to the sink, or the result dict when there is no sink."""
+        if self._thread is not None:
+            self._q.put(None)
+            self._thread.join()
+            self._thread = None
+        for w, _, _ in self._pending:
+            if w is not None:
+                w.wait()
+        self._pending = []
+        self._raise()
+        if self.stats is not None:
+            for k, v in self.t.items():
+                self.stats[k] = self.stats.get(k, 0.0) + v
+            self.stats["overlap"] = bool(self.overlap)
+        return self.delivered if self.sink is not None else self.result
+
+
+def _exchange_stats(stats, store, buf, dist):
+    if stats is not None:
+        stats["payload_floats"] = stats.get("payload_floats", 0) + sum(int(b[1].sum()) for b in store.batches)
+        stats["sent_floats"] = stats.get("sent_floats", 0) + buf.numel()
+        stats["collectives"] = stats.get("collectives", 0) + (1 if dist is not None else 0)
 
 
 def gather_waves(local_waves, local_ids, lengths, parts, hop, rank, world_size, device, dist=None,
@@ -373,12 +547,73 @@ def agree_geometry(n_local, data_local, world_size, device, dist=None):
     return int(t[0]), int(t[1])
 
 
+def _parse_cpulist(txt):
+    """'0-15,128-143' -> [[0..15], [128..143]] (one list per contiguous range)"""
+    out = []
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.append(list(range(int(a), int(b or a) + 1)))
+    return out
+
+
+def numa_cpus_for(local_rank, gpu_nodes, node_ranges, allowed=None):
+    """CPUs for the process that drives GPU ``local_rank``: those of its GPU's NUMA node, split evenly among the local
+    ranks whose GPUs sit on the same node (each contiguous CPU range of the node is cut into equal parts, so SMT
+    siblings -- the second range of a node on EPYC -- stay with their cores).  ``gpu_nodes[i]``: NUMA node of local GPU
+    i (-1 unknown); ``node_ranges[n]``: the node's CPU ranges.  None when nothing can / should be pinned."""
+    node = gpu_nodes[local_rank] if 0 <= local_rank < len(gpu_nodes) else -1
+    if node < 0 or node not in node_ranges:
+        return None
+    peers = [i for i, n in enumerate(gpu_nodes) if n == node]
+    k, n = peers.index(local_rank), len(peers)
+    mine = []
+    for rng in node_ranges[node]:
+        if allowed is not None:
+            rng = [c for c in rng if c in allowed]
+        lo, hi = k * len(rng) // n, (k + 1) * len(rng) // n
+        mine += rng[lo:hi]
+    return sorted(mine) or None
+
+
+def pin_to_gpu_numa(local_rank, n_local):
+    """Pin this process (its Python thread, the Exchange worker, torch's CPU threads) to the CPUs of its GPU's NUMA
+    node: page-locked staging buffers are then allocated, filled and written to disk next to the PCIe root the GPU
+    hangs off.  ``DISSC_NUMA_PIN=0`` switches it off; any failure to read the topology leaves the affinity alone.
+    Returns the CPU list applied, or None."""
+    if os.environ.get("DISSC_NUMA_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        nodes = []
+        for i in range(max(n_local, local_rank + 1)):
+            if i >= torch.cuda.device_count():
+                nodes.append(-1)
+                continue
+            p = torch.cuda.get_device_properties(i)
+            bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+                nodes.append(int(f.read().strip()))
+        ranges = {}
+        for n in set(nodes):
+            if n >= 0:
+                with open(f"/sys/devices/system/node/node{n}/cpulist") as f:
+                    ranges[n] = _parse_cpulist(f.read())
+        cpus = numa_cpus_for(local_rank, nodes, ranges, set(os.sched_getaffinity(0)))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return cpus
+    except Exception:  # noqa: BLE001  (topology files absent in a container, properties without PCI ids, ...)
+        return None
+
+
 def init_distributed(default_port, backend_env="DISSC_DIST_BACKEND"):
     """Process-group set-up shared by the CLIs (sr/inference.py, convert.py): one process per GPU from the
     torchrun environment.  Returns (rank, local_rank, world_size, dist-or-None).
 
     * WORLD_SIZE > 1: RCCL (backend "nccl") with one GPU per rank; ``DISSC_DIST_BACKEND=gloo`` is the rehearsal
       mode for a box with fewer GPUs than ranks (ranks share devices round-robin, tensors staged through the host).
+      Each rank's host threads are pinned to its GPU's NUMA node (``pin_to_gpu_numa``; DISSC_NUMA_PIN=0 = off).
     * WORLD_SIZE == 1: no process group -- unless ``DISSC_FORCE_DIST=1``, which initialises the same backend with
       one rank so that the collectives of the path run on the one GPU that is there."""
     rank = int(os.environ.get("RANK", 0))
@@ -396,20 +631,42 @@ def init_distributed(default_port, backend_env="DISSC_DIST_BACKEND"):
         raise RuntimeError(f"rank {rank}: local rank {local_rank} but {torch.cuda.device_count()} GPUs visible "
                            f"(one GPU per rank; {backend_env}=gloo shares devices for rehearsals)")
     torch.cuda.set_device(local_rank)
+    if world > 1 and backend == "nccl":
+        pin_to_gpu_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world, dist
 
 
+OVERLAP_ROUND_FRAMES = 8000  # smallest round worth cutting for overlap: batches under ~4 000 frames lose > 10 %
+OVERLAP_MAX_ROUNDS = 4
+
+
+def overlap_budget(lengths, parts, budget):
+    """Round budget (length units per rank and round) when rounds are delivered while the next one computes: a run that
+    would fit ONE round is still cut into up to OVERLAP_MAX_ROUNDS rounds of >= OVERLAP_ROUND_FRAMES frames per rank, so
+    that only the last round's exchange + device-to-host copy + sink is exposed.  Derived from the global job list:
+    every rank gets the same answer."""
+    share = max((sum(int(lengths[i]) for i in p) for p in parts), default=0)
+    n = min(OVERLAP_MAX_ROUNDS, share // OVERLAP_ROUND_FRAMES)
+    if n < 2:
+        return budget
+    cut = -(-share // n)
+    return cut if budget is None else min(budget, cut)
+
+
 def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist=None, max_batch=128,
                     max_frames=MAX_FRAMES, postprocess=None, unpack_ranks=(0,), sink=None,
-                    round_floats=ROUND_FLOATS, stats=None):
+                    round_floats=ROUND_FLOATS, stats=None, own_rows=False, overlap=None):
     """jobs: list of dicts {code: int array [T], f0: float array [T], spkr: int}.
-    Every rank runs its LPT share in length-bucketed batches, one all-gather per round (one round unless a
-    rank's share exceeds ``round_floats`` output samples).  Returns {job_id: float32 samples} (on
-    ``unpack_ranks``; None = all) -- or, with ``sink``, calls ``sink({job_id: samples})`` once per round on
-    those ranks and returns the number of waveforms delivered (nothing is retained between rounds: the arrays a sink
-    receives are views of a reused page-locked buffer, valid until it returns).
+    Every rank runs its LPT share in length-bucketed batches, one all-gather per round.  Returns {job_id: float32
+    samples} (on ``unpack_ranks``; None = all) -- or, with ``sink``, calls ``sink({job_id: samples})`` once per round
+    on those ranks and returns the number of waveforms delivered (nothing is retained between rounds: the arrays a
+    sink receives are views of a reused page-locked buffer, valid until it returns).  ``own_rows=True``: every rank
+    delivers the rows it decoded itself instead (Exchange).
+    Rounds: one unless a rank's share exceeds ``round_floats`` output samples -- or, with a sink on a GPU
+    (``overlap``, default on), up to 4 rounds of >= 8 000 frames per rank, delivered by a worker thread WHILE the
+    next round computes (Exchange; with a sink the callback therefore runs on that thread).
     ``postprocess(wav[B,1,L], n_samples[B])`` runs on the GPU in place.  ``stats`` (a dict) is filled with
     per-rank timing and traffic figures."""
     import time
@@ -420,9 +677,15 @@ def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist
     parts = lpt_shard(lengths, world_size)
     hop = int(np.prod(generator.h["upsample_rates"]))  # same on every rank, even one with no jobs
     dev = torch.device(device)
-    result, delivered = {}, 0
-    t_compute = 0.0
-    rounds = plan_rounds(lengths, parts, None if round_floats is None else max(1, round_floats // hop))
+    cuda = dev.type == "cuda"
+    ex = Exchange(rank, world_size, dev, dist, unpack_ranks, own_rows, sink, stats, overlap=overlap)
+    budget = None if round_floats is None else max(1, round_floats // hop)
+    if ex.overlap:
+        budget = overlap_budget(lengths, parts, budget)
+    rounds = plan_rounds(lengths, parts, budget)
+    t_host = 0.0
+    events = []
+    t_run = time.perf_counter()
     for shares in rounds:
         t0 = time.perf_counter()
         store = WaveStore(dev)
@@ -434,11 +697,10 @@ def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist
         shapes = [(len(bt), max((lengths[i] for i in bt), default=0)) for bt in batches]
         tot = sum(B * T for B, T in shapes)
         nrow = sum(B for B, _ in shapes)
-        pin = dev.type == "cuda"
-        h_code = torch.zeros(max(tot, 1), dtype=torch.int64, pin_memory=pin)
-        h_f0 = torch.zeros(max(tot, 1), dtype=torch.float32, pin_memory=pin)
-        h_spkr = torch.zeros(max(nrow, 1), dtype=torch.int64, pin_memory=pin)
-        h_lens = torch.zeros(max(nrow, 1), dtype=torch.int32, pin_memory=pin)
+        h_code = torch.zeros(max(tot, 1), dtype=torch.int64, pin_memory=cuda)
+        h_f0 = torch.zeros(max(tot, 1), dtype=torch.float32, pin_memory=cuda)
+        h_spkr = torch.zeros(max(nrow, 1), dtype=torch.int64, pin_memory=cuda)
+        h_lens = torch.zeros(max(nrow, 1), dtype=torch.int32, pin_memory=cuda)
         n_code, n_f0, n_spkr, n_lens = h_code.numpy(), h_f0.numpy(), h_spkr.numpy(), h_lens.numpy()
         o = r = 0
         for bt, (B, T) in zip(batches, shapes):
@@ -452,6 +714,9 @@ def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist
             r += B
         if hasattr(generator, "validate_host_ids"):
             generator.validate_host_ids(h_code[:tot], h_spkr[:nrow])
+        if cuda and stats is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(dev))
         d_code, d_f0 = h_code.to(dev, non_blocking=True), h_f0.to(dev, non_blocking=True)
         d_spkr, d_lens = h_spkr.to(dev, non_blocking=True), h_lens.to(dev, non_blocking=True)
         o = r = 0
@@ -471,20 +736,24 @@ def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist
             store.add(y, n_lens[r:r + B].astype(np.int64) * hop, bt)
             o += B * T
             r += B
-        if stats is not None and dev.type == "cuda":
-            torch.cuda.synchronize(dev)
-        t_compute += time.perf_counter() - t0
+        if cuda and stats is not None:
+            ev1.record(torch.cuda.current_stream(dev))
+            events.append((ev0, ev1))
+        t_host += time.perf_counter() - t0
         n_cap, data_cap = pack_geometry(lengths, shares, hop)
-        got = gather_store(store, n_cap, data_cap, rank, world_size, dist, unpack_ranks, stats, transient=sink is not None)
+        ex.submit(store, n_cap, data_cap)
         store.clear()
-        if sink is not None:
-            if got:
-                sink(got)
-            delivered += len(got)
-        else:
-            result.update(got)
     if stats is not None:
-        stats["compute_s"] = t_compute
+        # this rank's own work, delivery of other ranks' rounds excluded: the GPU spans of its rounds (H2D -> last
+        # kernel, HIP events) on a GPU -- launches run ahead of the device, so the host time alone says little -- or
+        # the host time of the loop on the CPU
+        if cuda:
+            torch.cuda.synchronize(dev)
+            stats["compute_s"] = sum(a.elapsed_time(b) for a, b in events) * 1e-3
+        else:
+            stats["compute_s"] = t_host
+        stats["host_batching_s"] = t_host
+        stats["compute_done_s"] = time.perf_counter() - t_run  # run start -> this rank's last kernel finished
         stats["imbalance"] = imbalance(lengths, parts)
         stats["rounds"] = len(rounds)
-    return delivered if sink is not None else result
+    return ex.finish()

@@ -181,33 +181,34 @@ class Converter:
         return out
 
     def run_sharded(self, n_samples, load, target_ids, rank=0, world_size=1, dist=None, unpack_ranks=(0,),
-                    f0_stats=None, sink=None, round_floats=harness.ROUND_FLOATS, stats=None):
+                    f0_stats=None, sink=None, round_floats=harness.ROUND_FLOATS, stats=None, own_rows=False,
+                    overlap=None):
         """n_samples: sample count of EVERY utterance (all ranks pass the same list: it defines the
         partition); load(i) -> waveform of utterance i (called for this rank's share only, one encode batch at a
-        time).  One all-gather per round; a run is one round unless a rank's share exceeds ``round_floats`` input
-        samples x targets (the output length is data-dependent with a rhythm model; the input length is the proxy
-        all ranks can agree on without talking).  Returns {(utt_index, target_id): samples} on ``unpack_ranks``
-        (None = all), {} elsewhere -- or, with ``sink``, calls ``sink({(utt, target): samples})`` per round there
-        and returns the number of waveforms delivered (the arrays a sink receives are views of a reused page-locked
-        buffer: valid until it returns)."""
+        time).  Per round: a 16-byte MAX all-reduce (the buffer geometry -- predicted durations size the outputs, so
+        the ranks cannot derive it from the job list) and ONE all-gather of the waveforms; a run is one round unless a
+        rank's share exceeds ``round_floats`` input samples x targets (the output length is data-dependent with a
+        rhythm model; the input length is the proxy all ranks can agree on without talking) -- or, with a ``sink`` on a
+        GPU, up to 4 rounds delivered by a worker thread while the next one computes (harness.Exchange).
+        Returns {(utt_index, target_id): samples} on ``unpack_ranks`` (None = all), {} elsewhere -- or, with
+        ``sink``, calls ``sink({(utt, target): samples})`` per round there and returns the number of waveforms
+        delivered (the arrays a sink receives are views of a reused page-locked buffer: valid until it returns).
+        ``own_rows=True``: every rank delivers the conversions it produced itself."""
         target_ids = list(target_ids)
         nt = max(len(target_ids), 1)
         parts = harness.lpt_shard(n_samples, world_size)
         budget = None if round_floats is None else max(1, round_floats // nt)
-        result, delivered = {}, 0
+        ex = harness.Exchange(rank, world_size, self.generator.device, dist, unpack_ranks, own_rows, sink, stats,
+                              decode=lambda got: self._decode(got, target_ids), overlap=overlap)
+        if ex.overlap:  # input frames (320 samples) as the length unit of the overlap rule
+            b = harness.overlap_budget([n // 320 for n in n_samples], parts, None)
+            if b is not None:
+                budget = b * 320 if budget is None else min(budget, b * 320)
         for shares in harness.plan_rounds(n_samples, parts, budget):
             store = harness.WaveStore(self.generator.device)
             self._run_local(shares[rank], n_samples, load, target_ids, store, f0_stats)
             n_cap = max(len(p) for p in shares) * len(target_ids)
             _, data_cap = harness.agree_geometry(store.n, store.data_floats, world_size, self.generator.device, dist)
-            got = harness.gather_store(store, n_cap, data_cap, rank, world_size, dist, unpack_ranks, stats,
-                                       transient=sink is not None)
+            ex.submit(store, n_cap, data_cap)
             store.clear()
-            got = self._decode(got, target_ids)
-            if sink is not None:
-                if got:
-                    sink(got)
-                delivered += len(got)
-            else:
-                result.update(got)
-        return delivered if sink is not None else result
+        return ex.finish()

@@ -250,19 +250,25 @@ def main(argv=None):
     os.makedirs(a.output_dir, exist_ok=True)
     jobs, items = build_jobs(a, h, samples, id_to_spkr, f0_stats_cfg, target_f0_stats)
 
-    def write(waves):  # rank 0, once per round (a run is one round unless a rank decodes > 1 GiB of audio)
+    def write(waves):  # once per round, on the harness's delivery thread while the next round is computed
         for j, w in sorted(waves.items()):
             wavfile.write(os.path.join(a.output_dir, jobs[j]['out']), h.sampling_rate, w)
 
-    harness.run_resynthesis(generator, jobs, rank, world, device, dist, postprocess=wav_postprocess_, sink=write)
+    # Who writes (DISSC_WRITERS): "all" (default for N > 1, like the reference's pool workers, which each write their
+    # own outputs: sr/inference.py:205-207,249-251 there) -- after the all-gather every rank drains the rows it decoded
+    # itself, so device-to-host copies and file writes spread over the ranks; "rank0" -- rank 0 receives and writes
+    # every file.  The files are byte-identical either way.
+    own = world > 1 and os.environ.get('DISSC_WRITERS', 'all') != 'rank0'
+    harness.run_resynthesis(generator, jobs, rank, world, device, dist, postprocess=wav_postprocess_, sink=write,
+                            own_rows=own)
+    if a.sample_df is None:  # ground-truth copies: no GPU work, the items are dealt round-robin to the writers
+        for stem, audio_path, code_len in (items[rank::world] if own else items if rank == 0 else []):
+            gt = load_gt(str(audio_path), code_len, a.pad, h.sampling_rate,
+                         None if a.eval_mode else int(h.code_hop_size))
+            if gt is not None:
+                wavfile.write(os.path.join(a.output_dir, stem + '_gt.wav'), h.sampling_rate,
+                              peak_normalize(gt))
     if rank == 0:
-        if a.sample_df is None:
-            for stem, audio_path, code_len in items:
-                gt = load_gt(str(audio_path), code_len, a.pad, h.sampling_rate,
-                             None if a.eval_mode else int(h.code_hop_size))
-                if gt is not None:
-                    wavfile.write(os.path.join(a.output_dir, stem + '_gt.wav'), h.sampling_rate,
-                                  peak_normalize(gt))
         print(f'{len(jobs)} waveforms written to {a.output_dir}')
     if dist is not None:
         dist.barrier()

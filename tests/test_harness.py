@@ -132,6 +132,20 @@ def _worker(rank, world, port, q):
                                 unpack_ranks=None, sink=seen.update, round_floats=400, stats=stats)
     assert n == 25 and stats["rounds"] >= 2 and stats["collectives"] == stats["rounds"]
     assert sorted(seen) == sorted(out) and all(np.array_equal(seen[k], out[k]) for k in out)
+    # the same rounds delivered by the Exchange worker thread while the next round is computed (the GPU default with a
+    # sink; asked for explicitly on the CPU), rank 0 only and "every rank delivers the rows it decoded"
+    for own in (False, True):
+        seen2, st2 = {}, {}
+        n2 = harness.run_resynthesis(_FakeGenerator(), _jobs(), rank, world, "cpu", dist, max_batch=4, max_frames=100,
+                                     sink=lambda w: seen2.update({k: v.copy() for k, v in w.items()}), round_floats=400,
+                                     stats=st2, own_rows=own, overlap=True)
+        assert st2["overlap"] is True and st2["rounds"] >= 2 and st2["collectives"] == st2["rounds"]
+        assert n2 == len(seen2) and all(np.array_equal(seen2[k], out[k]) for k in seen2)
+        if own:
+            mine = sorted(harness.lpt_shard([len(j["code"]) for j in _jobs()], world)[rank])
+            assert sorted(seen2) == mine
+        else:
+            assert sorted(seen2) == (sorted(out) if rank == 0 else [])
     q.put((rank, {k: v.tolist() for k, v in out.items()}))
     dist.barrier()
     dist.destroy_process_group()
@@ -145,6 +159,18 @@ def test_two_rank_gloo_matches_single_process():
     assert harness.run_resynthesis(_FakeGenerator(), _jobs(), 0, 1, "cpu", None, max_batch=4, max_frames=100,
                                    sink=rounds.update, round_floats=200) == 25
     assert all(np.array_equal(rounds[k], single[k]) for k in single)
+    # overlapped delivery without a process group; a sink that fails on the worker thread fails the run
+    seen, st = {}, {}
+    assert harness.run_resynthesis(_FakeGenerator(), _jobs(), 0, 1, "cpu", None, max_batch=4, max_frames=100,
+                                   sink=lambda w: seen.update({k: v.copy() for k, v in w.items()}), round_floats=200,
+                                   stats=st, overlap=True) == 25
+    assert st["overlap"] and st["rounds"] >= 3 and all(np.array_equal(seen[k], single[k]) for k in single)
+
+    def bad_sink(w):
+        raise OSError("disk full")
+    with pytest.raises(OSError, match="disk full"):
+        harness.run_resynthesis(_FakeGenerator(), _jobs(), 0, 1, "cpu", None, max_batch=4, max_frames=100,
+                                sink=bad_sink, round_floats=200, overlap=True)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -162,3 +188,35 @@ def test_two_rank_gloo_matches_single_process():
         assert sorted(got[r]) == list(range(25))
         for j in range(25):
             np.testing.assert_array_equal(np.array(got[r][j], dtype=np.float32), single[j])
+
+
+def test_overlap_budget_rule():
+    """a run that fits one round is still cut into <= 4 rounds of >= 8 000 frames per rank when rounds overlap"""
+    lengths = [175] * 1024
+    for world, want in ((1, 4), (2, 4), (4, 4), (8, 2), (16, None)):
+        parts = harness.lpt_shard(lengths, world)
+        b = harness.overlap_budget(lengths, parts, None)
+        if want is None:
+            assert b is None
+            continue
+        rounds = harness.plan_rounds(lengths, parts, b)
+        assert len(rounds) == want, (world, len(rounds))
+        assert sorted(i for sh in rounds for p in sh for i in p) == list(range(1024))
+    assert harness.overlap_budget(lengths, harness.lpt_shard(lengths, 1), 1000) == 1000  # a tighter budget wins
+
+
+def test_numa_cpu_assignment():
+    """8 GPUs on 2 NUMA nodes of an SMT-2 host: 4 ranks per node, each gets a quarter of both ranges of its node"""
+    ranges = {0: [list(range(0, 64)), list(range(128, 192))], 1: [list(range(64, 128)), list(range(192, 256))]}
+    gpu_nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    seen = set()
+    for lr in range(8):
+        c = harness.numa_cpus_for(lr, gpu_nodes, ranges)
+        assert len(c) == 32 and not (seen & set(c))
+        seen |= set(c)
+        base = (lr % 4) * 16 + (64 if lr >= 4 else 0)
+        assert c == list(range(base, base + 16)) + list(range(base + 128, base + 144))  # cores + their SMT siblings
+    assert seen == set(range(256))
+    assert harness.numa_cpus_for(0, [-1], ranges) is None                       # unknown topology: leave it alone
+    assert harness.numa_cpus_for(1, [0, 0], {0: [[0, 1, 2, 3]]}, allowed={2, 3}) == [3]
+    assert harness._parse_cpulist("0-3,8,10-11\n") == [[0, 1, 2, 3], [8], [10, 11]]
