@@ -270,11 +270,35 @@ def strong_jobs(synth, n_utts=256, targets=(6, 57, 3, 101), seed=77):
     return jobs
 
 
+XGMI_RING_GBPS = 60.0  # conservative effective all-gather bandwidth per rank over xGMI (one ring direction of a
+#                        ~76.8 GB/s-per-direction link; RCCL normally drives several rings) -- only used by the model below
+
+
+def strong_model(n):
+    """The committed strong-scaling prediction for N ranks (profiles/rNN/strong_model.json, written by
+    tools/strong_rehearsal.py from one-GPU rehearsals: every rank's share computed ALONE on the GPU + rank 0's measured
+    delivery cost + a modelled all-gather), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "strong_model.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+            row = j["per_n"].get(str(n))
+            if row:
+                return dict(row, source=os.path.relpath(path, ROOT))
+        except Exception:  # noqa: BLE001
+            continue
+    return None
+
+
 def strong_leg(synth, g, dev, rank, world, dist, fake=False, reps=3):
     """Strong scaling: the fixed 1 024-job list LPT-sharded over the ranks by length, each rank batching its share
-    through the generator + GPU post-processing, ONE all-gather of the ragged exchange buffer, rank 0 unpacking every
-    waveform to the host.  Wall = barrier -> slowest rank done (rank 0's unpack included); per-rank compute times and
-    the load imbalance of the partition are reported next to it."""
+    through the generator + GPU post-processing in rounds, ONE all-gather of the ragged exchange buffer per round, rank
+    0 receiving every waveform on the host -- round k's gather / device-to-host copy / hand-over to the sink running on
+    the harness's delivery thread while round k + 1 computes.  Wall = barrier -> slowest rank done (rank 0's delivery
+    of the last round included).  Next to it: each rank's own GPU span, when its last kernel finished, rank 0's
+    delivery split, the exposed tail, and the committed prediction for this N (strong_model).
+    DISSC_STRONG_SOLO=1 (rehearsals: several gloo ranks on ONE GPU) adds a pass in which the ranks take turns, each
+    computing its share alone on the device."""
     from dissc_amd import harness
     post = None
     if not fake:
@@ -282,50 +306,106 @@ def strong_leg(synth, g, dev, rank, world, dist, fake=False, reps=3):
     jobs = strong_jobs(synth) if not fake else strong_jobs(synth, 16, (6, 57))
     lengths = [len(j["code"]) for j in jobs]
     audio_sec = sum(lengths) * 320 / 16000.0
-    best = None
-    for rep in range(reps + 1):  # first pass = warm-up (workspace, staging buffers)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        stats = {}
-        t0 = time.perf_counter()
-        got = {}
 
-        def sink(waves):  # what sr/inference.py's sink gets per round (it writes the files): host arrays, valid during the call
-            for j, w in waves.items():
-                got[j] = len(w)
-        harness.run_resynthesis(g, jobs, rank, world, dev, dist, postprocess=post, stats=stats, sink=sink)
-        torch.cuda.synchronize()
-        t_rank = time.perf_counter() - t0
+    def barrier():
         if dist is not None:
             dist.barrier()
-        wall = time.perf_counter() - t0
-        if rank == 0:
-            assert len(got) == len(jobs) and all(got[j] == 320 * lengths[j] for j in range(len(jobs)))
-        rec = torch.tensor([wall, stats["compute_s"], t_rank], dtype=torch.float64, device=dev)
-        if dist is not None:
-            allr = torch.empty(world, 3, dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(allr, rec[None])
-        else:
-            allr = rec[None]
-        allr = allr.cpu().numpy()
-        cur = (float(allr[:, 0].max()), allr, stats)
-        if rep > 0 and (best is None or cur[0] < best[0]):
-            best = cur
-    wall, allr, stats = best
+        torch.cuda.synchronize()
+
+    def run(own_rows):
+        best = None
+        for rep in range(reps + 1):  # first pass = warm-up (workspace, staging buffers)
+            barrier()
+            stats = {}
+            t0 = time.perf_counter()
+            got = {}
+
+            def sink(waves):  # what sr/inference.py's sink gets per round (it writes the files): host arrays, valid during the call
+                for j, w in waves.items():
+                    got[j] = len(w)
+            harness.run_resynthesis(g, jobs, rank, world, dev, dist, postprocess=post, stats=stats, sink=sink,
+                                    own_rows=own_rows)
+            torch.cuda.synchronize()
+            t_rank = time.perf_counter() - t0
+            if dist is not None:
+                dist.barrier()
+            wall = time.perf_counter() - t0
+            mine = set(harness.lpt_shard(lengths, world)[rank]) if own_rows else (set(range(len(jobs))) if rank == 0 else set())
+            assert set(got) == mine and all(got[j] == 320 * lengths[j] for j in got)
+            rec = torch.tensor([wall, stats["compute_s"], t_rank, stats["compute_done_s"], stats.get("gather_wait_s", 0.0),
+                                stats.get("unpack_s", 0.0), stats.get("sink_s", 0.0), stats.get("pack_s", 0.0),
+                                stats.get("submit_wait_s", 0.0), stats["host_batching_s"]], dtype=torch.float64, device=dev)
+            if dist is not None:
+                allr = torch.empty(world, rec.numel(), dtype=torch.float64, device=dev)
+                dist.all_gather_into_tensor(allr, rec[None])
+            else:
+                allr = rec[None]
+            allr = allr.cpu().numpy()
+            cur = (float(allr[:, 0].max()), allr, stats)
+            if rep > 0 and (best is None or cur[0] < best[0]):
+                best = cur
+        return best
+
+    wall, allr, stats = run(False)
     comp = allr[:, 1]
-    return {"workload": f"{len(jobs)} generator jobs ({len(jobs) // 4 if not fake else len(jobs) // 2} ragged utterances of 2-5 s x "
-                        f"{4 if not fake else 2} targets), the same list at every N, LPT-sharded by length; host batching + H2D + "
-                        "generator + GPU post-processing + ragged pack + all-gather + rank-0 D2H into page-locked memory + hand-over to a per-round sink all inside the wall",
-            "scaling": "strong", "jobs": len(jobs), "audio_sec": round(audio_sec, 1),
-            "wall_ms": round(wall * 1e3, 2), "value": round(audio_sec / wall, 1), "unit": "audio-sec/sec",
-            "per_rank_compute_ms": [round(float(c) * 1e3, 2) for c in comp],
-            "compute_imbalance": round(float(comp.max() / comp.mean()), 4),
-            "load_imbalance": round(float(stats["imbalance"]), 4),
-            "exchange": {"collectives": int(stats.get("collectives", 0)), "rounds": int(stats["rounds"]),
-                         "sent_bytes_per_rank": 4 * int(stats["sent_floats"]),
-                         "payload_bytes_this_rank": 4 * int(stats["payload_floats"])},
-            "best_of": reps}
+    ms = lambda v: round(float(v) * 1e3, 2)
+    out = {"workload": f"{len(jobs)} generator jobs ({len(jobs) // 4 if not fake else len(jobs) // 2} ragged utterances of 2-5 s x "
+                       f"{4 if not fake else 2} targets), the same list at every N, LPT-sharded by length; host batching + H2D + "
+                       "generator + GPU post-processing + ragged pack + all-gather + rank-0 D2H into page-locked memory + hand-over "
+                       "to a per-round sink all inside the wall; rounds delivered by a worker thread while the next one computes",
+           "scaling": "strong", "jobs": len(jobs), "audio_sec": round(audio_sec, 1),
+           "wall_ms": ms(wall), "value": round(audio_sec / wall, 1), "unit": "audio-sec/sec",
+           "per_rank_compute_ms": [ms(c) for c in comp],
+           "per_rank_compute_done_ms": [ms(c) for c in allr[:, 3]],
+           "exposed_tail_ms": ms(wall - allr[:, 3].max()),
+           "rank0_delivery": {"wait_for_round_ms": ms(allr[0, 4]), "d2h_unpack_ms": ms(allr[0, 5]), "sink_ms": ms(allr[0, 6]),
+                              "pack_ms": ms(allr[0, 7]), "blocked_on_delivery_ms": ms(allr[0, 8]),
+                              "host_batching_ms": ms(allr[0, 9]),
+                              "note": "delivery thread of rank 0, summed over the rounds; wait_for_round includes waiting for the "
+                                      "round's compute (overlapped), blocked_on_delivery = main thread waiting for a free slot"},
+           "compute_imbalance": round(float(comp.max() / comp.mean()), 4),
+           "load_imbalance": round(float(stats["imbalance"]), 4),
+           "exchange": {"collectives": int(stats.get("collectives", 0)), "rounds": int(stats["rounds"]),
+                        "overlap": bool(stats.get("overlap", False)),
+                        "sent_bytes_per_rank": 4 * int(stats["sent_floats"]),
+                        "payload_bytes_this_rank": 4 * int(stats["payload_floats"])},
+           "best_of": reps}
+    if world > 1:  # the CLIs' default at N > 1: every rank drains and "writes" the rows it decoded itself
+        w2, a2, _ = run(True)
+        out["own_rows"] = {"what": "same list, every rank delivers the rows it decoded (DISSC_WRITERS=all, the CLIs' default at N > 1)",
+                           "wall_ms": ms(w2), "value": round(audio_sec / w2, 1),
+                           "exposed_tail_ms": ms(w2 - a2[:, 3].max())}
+    if os.environ.get("DISSC_STRONG_SOLO") == "1" and not fake:
+        # rehearsal: each rank computes its share with the device to itself (the others wait at the barrier)
+        parts = harness.lpt_shard(lengths, world)
+        solo = torch.zeros(world, 2, dtype=torch.float64, device=dev)
+        for r in range(world):
+            barrier()
+            if r == rank:
+                sub = [jobs[i] for i in parts[rank]]
+                bud = harness.overlap_budget(lengths, parts, None)   # the round cut of the N-rank run
+                rf = None if bud is None else bud * 320
+                ts = []
+                for rep in range(3):
+                    torch.cuda.synchronize()
+                    st = {}
+                    t0 = time.perf_counter()
+                    harness.run_resynthesis(g, sub, 0, 1, dev, None, postprocess=post, stats=st, unpack_ranks=(),
+                                            round_floats=rf, overlap=False)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t0, st["compute_s"]))
+                solo[rank, 0], solo[rank, 1] = min(t[0] for t in ts), min(t[1] for t in ts)
+            barrier()
+        if dist is not None:
+            dist.all_reduce(solo)
+        solo = solo.cpu().numpy()
+        out["solo"] = {"what": "each rank's share (same rounds, same batches) computed with the GPU to itself: host batching + "
+                               "H2D + generator + post-processing + ragged pack, no exchange, no delivery",
+                       "wall_ms": [ms(v) for v in solo[:, 0]], "gpu_span_ms": [ms(v) for v in solo[:, 1]]}
+    pred = strong_model(world)
+    if pred is not None:
+        out["predicted"] = pred
+    return out
 
 
 def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_sec_per_step, flops_step):
@@ -406,6 +486,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the full-pipeline leg (N=1 only)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (fixed 1 024-job list)")
     ap.add_argument("--no-d2h", action="store_true", help="skip the D2H-inclusive figure (N=1 only)")
+    ap.add_argument("--strong-only", action="store_true",
+                    help="only the strong-scaling leg (tools/strong_rehearsal.py): prints {'strong': ...} and exits")
     a = ap.parse_args()
 
     # DISSC_BENCH_FAKE=1: CPU/gloo dry run of the distributed bookkeeping only (tests/test_bench_dist.py);
@@ -467,6 +549,16 @@ def main():
         g.eval()
         g.remove_weight_norm()
 
+    if not fake and world > 1 and backend == "nccl":
+        from dissc_amd import harness as _h
+        _h.pin_to_gpu_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))  # host threads next to the GPU
+    if a.strong_only:
+        strong = strong_leg(synth, g, dev, rank, world, dist, fake)
+        if rank == 0:
+            print(json.dumps({"strong": strong, "n_gpus": world, "backend": backend if dist is not None else None}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     B, T = a.batch, a.frames
     code, f0, spkr, _ = synth.synth_generator_inputs(B, T, seed=1234 + rank)
     d_code = torch.from_numpy(code).to(dev)

@@ -150,6 +150,12 @@ class CodeGenerator:
         c.has_spkr = 1 if self.multispkr else 0
         return c
 
+    def prepare(self):
+        """Build the native handle now (weight-norm fold, host packing of the direct and transform-domain weights,
+        upload) instead of lazily on the first call -- so that a caller can account for it (tools/cli_wall.py)."""
+        self._ensure()
+        return self
+
     def _ensure(self):
         if self._handle is not None:
             return

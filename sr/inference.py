@@ -171,7 +171,37 @@ def build_jobs(a, h, samples, id_to_spkr, f0_stats_cfg, target_f0_stats):
     return jobs, items
 
 
+class _Phases:
+    """DISSC_CLI_TIMING=1: wall-clock marks since PROCESS START (tools/cli_wall.py), printed as one JSON line at exit."""
+
+    def __init__(self):
+        self.on = os.environ.get('DISSC_CLI_TIMING') == '1'
+        self.marks = []
+        if self.on:
+            import time
+
+            import psutil
+            self.t0 = psutil.Process().create_time()
+            self.now = time.time
+            self.mark('imports')
+
+    def mark(self, name, sync=None):
+        if self.on:
+            if sync is not None and torch.cuda.is_available():
+                torch.cuda.synchronize(sync)
+            self.marks.append((name, self.now() - self.t0))
+
+    def dump(self, rank, extra):
+        if self.on:
+            prev, out = 0.0, {}
+            for name, t in self.marks:
+                out[name + '_s'] = round(t - prev, 4)
+                prev = t
+            print('CLI_TIMING ' + json.dumps(dict(out, total_s=round(prev, 4), rank=rank, **extra)), flush=True)
+
+
 def main(argv=None):
+    ph = _Phases()
     print('Initializing Inference Process..')
     parser = argparse.ArgumentParser()
     parser.add_argument('--code_file', default=None)
@@ -205,6 +235,7 @@ def main(argv=None):
     from dissc_amd import harness
     rank, local_rank, world, dist = harness.init_distributed(29512)
     device = torch.device('cuda', local_rank)
+    ph.mark('process_group')
 
     if os.path.isdir(a.checkpoint_file):
         config_file = os.path.join(a.checkpoint_file, 'config.json')
@@ -214,6 +245,8 @@ def main(argv=None):
         cp_g = a.checkpoint_file
     from dissc_amd import AttrDict, CodeGenerator, formats, harness
     from dissc_amd.generator import wav_postprocess_
+    torch.zeros(1, device=device)  # HIP context + library load, accounted on their own
+    ph.mark('hip_init', device)
     with open(config_file) as f:
         h = AttrDict(json.loads(f.read()))
     if not os.path.isfile(cp_g):
@@ -245,10 +278,14 @@ def main(argv=None):
     generator = CodeGenerator(h).to(device)
     generator.load_state_dict(state['generator'])
     generator.eval()
+    ph.mark('manifest_and_checkpoint_load', device)
     generator.remove_weight_norm()
+    generator.prepare()
+    ph.mark('fold_and_pack_weights', device)
 
     os.makedirs(a.output_dir, exist_ok=True)
     jobs, items = build_jobs(a, h, samples, id_to_spkr, f0_stats_cfg, target_f0_stats)
+    ph.mark('build_jobs')
 
     def write(waves):  # once per round, on the harness's delivery thread while the next round is computed
         for j, w in sorted(waves.items()):
@@ -259,8 +296,10 @@ def main(argv=None):
     # itself, so device-to-host copies and file writes spread over the ranks; "rank0" -- rank 0 receives and writes
     # every file.  The files are byte-identical either way.
     own = world > 1 and os.environ.get('DISSC_WRITERS', 'all') != 'rank0'
+    run_stats = {} if ph.on else None
     harness.run_resynthesis(generator, jobs, rank, world, device, dist, postprocess=wav_postprocess_, sink=write,
-                            own_rows=own)
+                            own_rows=own, stats=run_stats)
+    ph.mark('resynthesis_and_writes', device)
     if a.sample_df is None:  # ground-truth copies: no GPU work, the items are dealt round-robin to the writers
         for stem, audio_path, code_len in (items[rank::world] if own else items if rank == 0 else []):
             gt = load_gt(str(audio_path), code_len, a.pad, h.sampling_rate,
@@ -268,11 +307,15 @@ def main(argv=None):
             if gt is not None:
                 wavfile.write(os.path.join(a.output_dir, stem + '_gt.wav'), h.sampling_rate,
                               peak_normalize(gt))
+    ph.mark('gt_copies')
     if rank == 0:
         print(f'{len(jobs)} waveforms written to {a.output_dir}')
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    ph.mark('teardown')
+    ph.dump(rank, {'jobs': len(jobs), 'world': world,
+                   'run': {k: round(float(v), 4) for k, v in (run_stats or {}).items() if isinstance(v, (int, float))}})
 
 
 if __name__ == '__main__':
