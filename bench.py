@@ -97,10 +97,10 @@ def cpu_baseline(synth, sd, code, f0, spkr, budget_s=14.0, max_utts=400, keep=8)
     times, t0, waves = [], time.perf_counter(), []
     while len(times) < max_utts and (len(times) < 5 or time.perf_counter() - t0 < budget_s):
         t = time.perf_counter()
-        w = one(len(times) % code.shape[0])
+        wav = one(len(times) % code.shape[0])
         times.append(time.perf_counter() - t)
         if len(waves) < min(keep, code.shape[0]):  # utterances 0 .. keep-1 of the batch, for the in-run parity figure
-            waves.append(w)
+            waves.append(wav)
     sec = code.shape[1] * 320 / 16000.0
     med = float(np.median(times))
     return {"value": round(sec / med, 2), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
@@ -297,8 +297,8 @@ def strong_leg(synth, g, dev, rank, world, dist, fake=False, reps=3):
     the harness's delivery thread while round k + 1 computes.  Wall = barrier -> slowest rank done (rank 0's delivery
     of the last round included).  Next to it: each rank's own GPU span, when its last kernel finished, rank 0's
     delivery split, the exposed tail, and the committed prediction for this N (strong_model).
-    DISSC_STRONG_SOLO=1 (rehearsals: several gloo ranks on ONE GPU) adds a pass in which the ranks take turns, each
-    computing its share alone on the device."""
+    DISSC_STRONG_EMULATE="1,2,4,8" (one process, N = 1): additionally computes every rank's share of an N-rank run
+    alone, for tools/strong_rehearsal.py's prediction."""
     from dissc_amd import harness
     post = None
     if not fake:
@@ -375,16 +375,20 @@ def strong_leg(synth, g, dev, rank, world, dist, fake=False, reps=3):
         out["own_rows"] = {"what": "same list, every rank delivers the rows it decoded (DISSC_WRITERS=all, the CLIs' default at N > 1)",
                            "wall_ms": ms(w2), "value": round(audio_sec / w2, 1),
                            "exposed_tail_ms": ms(w2 - a2[:, 3].max())}
-    if os.environ.get("DISSC_STRONG_SOLO") == "1" and not fake:
-        # rehearsal: each rank computes its share with the device to itself (the others wait at the barrier)
-        parts = harness.lpt_shard(lengths, world)
-        solo = torch.zeros(world, 2, dtype=torch.float64, device=dev)
-        for r in range(world):
-            barrier()
-            if r == rank:
-                sub = [jobs[i] for i in parts[rank]]
-                bud = harness.overlap_budget(lengths, parts, None)   # the round cut of the N-rank run
-                rf = None if bud is None else bud * 320
+    emu = os.environ.get("DISSC_STRONG_EMULATE", "")
+    if emu and world == 1 and not fake:
+        # Every rank's share at N ranks (the LPT partition, the rounds and the batches of the N-rank run) computed in THIS
+        # process, one share after the other, the GPU to itself.  (Rehearsing with N processes on one GPU does not give
+        # these numbers: beyond two processes the hardware queues are oversubscribed and every share takes 2-4x as long
+        # whatever its size -- measured, profiles/r04/README.md.)
+        out["emulated"] = {}
+        for n in [int(v) for v in emu.split(",") if v.strip()]:
+            parts = harness.lpt_shard(lengths, n)
+            bud = harness.overlap_budget(lengths, parts, None)   # the round cut of the N-rank run
+            rf = None if bud is None else bud * 320
+            walls, spans, rounds = [], [], 0
+            for r in range(n):
+                sub = [jobs[i] for i in parts[r]]
                 ts = []
                 for rep in range(3):
                     torch.cuda.synchronize()
@@ -393,15 +397,18 @@ def strong_leg(synth, g, dev, rank, world, dist, fake=False, reps=3):
                     harness.run_resynthesis(g, sub, 0, 1, dev, None, postprocess=post, stats=st, unpack_ranks=(),
                                             round_floats=rf, overlap=False)
                     torch.cuda.synchronize()
-                    ts.append((time.perf_counter() - t0, st["compute_s"]))
-                solo[rank, 0], solo[rank, 1] = min(t[0] for t in ts), min(t[1] for t in ts)
-            barrier()
-        if dist is not None:
-            dist.all_reduce(solo)
-        solo = solo.cpu().numpy()
-        out["solo"] = {"what": "each rank's share (same rounds, same batches) computed with the GPU to itself: host batching + "
-                               "H2D + generator + post-processing + ragged pack, no exchange, no delivery",
-                       "wall_ms": [ms(v) for v in solo[:, 0]], "gpu_span_ms": [ms(v) for v in solo[:, 1]]}
+                    ts.append((time.perf_counter() - t0, st["compute_s"], st["rounds"]))
+                walls.append(min(t[0] for t in ts))
+                spans.append(min(t[1] for t in ts))
+                rounds = max(rounds, ts[0][2])
+            full = harness.plan_rounds(lengths, parts, bud)
+            n_cap_dc = [harness.pack_geometry(lengths, sh, 320) for sh in full]
+            out["emulated"][str(n)] = {
+                "share_wall_ms": [ms(v) for v in walls], "share_gpu_span_ms": [ms(v) for v in spans], "rounds": len(full),
+                "sent_bytes_per_rank": 4 * sum(harness.buffer_floats(a, b) for a, b in n_cap_dc),
+                "load_imbalance": round(float(harness.imbalance(lengths, parts)), 4)}
+        out["emulated"]["what"] = ("each rank's share at N ranks (same partition, rounds and batches) computed alone in one "
+                                   "process: host batching + H2D + generator + post-processing + ragged pack, no exchange")
     pred = strong_model(world)
     if pred is not None:
         out["predicted"] = pred

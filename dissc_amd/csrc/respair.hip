@@ -79,6 +79,47 @@ __device__ __forceinline__ void pair_store4(const PairArgs& a, size_t idx, f32x4
   }
 }
 
+
+// (b, first output column) of workgroup `lin` when only the tiles that EXIST are enumerated: utterance 0's
+// ceil(len_0 / WOUT) tiles, then utterance 1's, ...  The grid still holds gridDim.x tiles for each of the B utterances;
+// the workgroups beyond the last real tile all sit at the END of the dispatch order and return at once -- enumerating
+// (tile, utterance) pairs and returning from the tiles beyond an utterance's end leaves the empty workgroups between the
+// real ones (7-9 % on ragged batches for conv_wino_kernel, +0.65 ms per ragged forward for these stages).  Every wave
+// finds its pair by a prefix sum of the tile counts over its lanes (the scheme of conv_wino.hip).
+template <int WOUT>
+__device__ __forceinline__ bool pair_tile(const PairArgs& a, int B, int& b, int& len, int& o0) {
+  const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  if (a.lengths == nullptr) {
+    b = blockIdx.y;
+    len = a.len_default;
+    o0 = blockIdx.x * WOUT;
+    return o0 < len;
+  }
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int l = b0 + lane < B ? a.lengths[b0 + lane] * a.len_mul : 0;
+    const int nt = (l + WOUT - 1) / WOUT;
+    int incl = nt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (lin < base + total) {
+      const unsigned long long m = __ballot(base + incl > lin);
+      const int lb = __ffsll((long long)m) - 1;
+      b = __builtin_amdgcn_readfirstlane(b0 + lb);
+      len = __builtin_amdgcn_readfirstlane(__shfl(l, lb, 64));
+      o0 = __builtin_amdgcn_readfirstlane((lin - base - __shfl(incl - nt, lb, 64)) * WOUT);
+      return true;
+    }
+    base += total;
+  }
+  return false;
+}
+
 // ---- C = 16: v_mfma_f32_16x16x4_f32, both convs' weights in registers -------------------------
 template <int KS, int DIL, int NI>
 __global__ void __launch_bounds__(256) respair16_kernel(const PairArgs a) {
@@ -96,10 +137,8 @@ __global__ void __launch_bounds__(256) respair16_kernel(const PairArgs a) {
   __shared__ __attribute__((aligned(16))) float Xs[C * XW1];  // lrelu(x) window (later: epilogue patches)
   __shared__ __attribute__((aligned(16))) float Ts[C * XW2];  // lrelu(conv1 + b1), 0 outside the utterance
 
-  const int b = blockIdx.y;
-  const int len = a.lengths ? a.lengths[b] * a.len_mul : a.len_default;
-  const int o0 = blockIdx.x * WOUT;
-  if (o0 >= len) return;
+  int b, len, o0;
+  if (!pair_tile<WOUT>(a, gridDim.y, b, len, o0)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int tin0 = o0 - P2 - P1;
@@ -257,10 +296,8 @@ __global__ void __launch_bounds__(256) respair32_kernel(const PairArgs a) {
   __shared__ __attribute__((aligned(16))) float Psep[LM == 1 ? NW * 8 * CW : 4];
   float* const Ts = LM == 0 ? Tsep : Xs;
 
-  const int b = blockIdx.y;
-  const int len = a.lengths ? a.lengths[b] * a.len_mul : a.len_default;
-  const int o0 = blockIdx.x * WOUT;
-  if (o0 >= len) return;
+  int b, len, o0;
+  if (!pair_tile<WOUT>(a, gridDim.y, b, len, o0)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int tin0 = o0 - P2 - P1;

@@ -162,11 +162,21 @@ class WaveStore:
         head[1:1 + self.n, 2:4] = offs.astype(np.int64).view(np.int32).reshape(-1, 2)
         tbl = HDR + ENT * n_cap
         buf = torch.empty(buffer_floats(n_cap, data_cap), dtype=torch.float32, device=self.device)
-        buf[:tbl].copy_(torch.from_numpy(head.reshape(-1)).view(torch.float32))
         if self.device.type == "cuda":
             from ._lib import check, current_stream_ptr, lib
-            d_ns = torch.from_numpy(ns).to(self.device)
-            d_off = torch.from_numpy(offs.astype(np.int64)).to(self.device)
+            # header, sample counts and offsets go over from ONE page-locked block with non-blocking copies: a
+            # pageable copy_ is ordered behind everything on the stream and blocks the host until the round's
+            # kernels are done -- the caller could not start batching the next round meanwhile
+            n_h, n_r = head.size, max(self.n, 1)
+            stage = torch.empty(n_h + n_r + 2 * n_r, dtype=torch.int32, pin_memory=True)
+            sn = stage.numpy()
+            sn[:n_h] = head.reshape(-1)
+            sn[n_h:n_h + self.n] = ns
+            sn[n_h + n_r:n_h + n_r + 2 * self.n] = offs.astype(np.int64).view(np.int32)
+            d_stage = stage.to(self.device, non_blocking=True)
+            buf[:tbl].copy_(d_stage[:n_h].view(torch.float32))
+            d_ns = d_stage[n_h:n_h + n_r]
+            d_off = d_stage[n_h + n_r:].view(torch.int64)
             data = buf[tbl:]
             assert data.data_ptr() % 16 == 0
             with torch.cuda.device(self.device):
@@ -179,6 +189,7 @@ class WaveStore:
                                               data.data_ptr(), st), "dissc_pack_rows")
                     row += B
         else:  # gloo/CPU rehearsal of the same layout (tests)
+            buf[:tbl].copy_(torch.from_numpy(head.reshape(-1)).view(torch.float32))
             buf[tbl:].zero_()
             row = 0
             for w2, bns, _ in self.batches:
@@ -651,7 +662,9 @@ def overlap_budget(lengths, parts, budget):
     n = min(OVERLAP_MAX_ROUNDS, share // OVERLAP_ROUND_FRAMES)
     if n < 2:
         return budget
-    cut = -(-share // n)
+    # plan_rounds closes a round when the next job would exceed the budget, so a round holds more than
+    # budget - longest job: with share / n + longest job as the budget there are at most n rounds
+    cut = -(-share // n) + max((int(v) for v in lengths), default=0)
     return cut if budget is None else min(budget, cut)
 
 

@@ -59,3 +59,25 @@ def test_bench_refuses_world_size_mismatch():
            "--batch", "1", "--frames", "10"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode != 0 and "--gpus 2" in (r.stdout + r.stderr)
+
+
+def test_cpu_baseline_and_in_run_parity_figure():
+    """bench.py's cpu_baseline leg returns the oracle waveforms it produced while being timed, and parity_vs compares a
+    batch against them (parity in the same run)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+
+    import bench
+    import synthdata as synth
+    sd = synth.synth_generator_state_dict(seed=0)
+    code, f0, spkr, _ = synth.synth_generator_inputs(3, 12, seed=1234)
+    out, waves = bench.cpu_baseline(synth, sd, torch.from_numpy(code), torch.from_numpy(f0), torch.from_numpy(spkr),
+                                    budget_s=0.5, max_utts=5)
+    assert out["kind"] == "port" and out["value"] > 0 and len(waves) == 3
+    y = torch.stack([w.reshape(1, -1) for w in waves])
+    p = bench.parity_vs(waves, y)
+    assert p["rms"] == 0.0 and p["utts"] == 3 and p["tol_rms"] == 1e-4
+    y[1, 0, 5] += 0.5
+    p = bench.parity_vs(waves, y)
+    assert p["rms"] > 1e-4 and abs(p["max"] - 0.5) < 1e-6
