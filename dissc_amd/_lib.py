@@ -97,6 +97,8 @@ def _load():
     L.dissc_set_option.argtypes = [ctypes.c_char_p, i32]
     L.dissc_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     L.dissc_conv_bench.argtypes = [i32] * 9 + [ctypes.POINTER(ctypes.c_float)]
+    L.dissc_pair_bench.argtypes = [i32] * 8 + [ctypes.POINTER(ctypes.c_float)]
+    L.dissc_respair1d.argtypes = [vp] * 8 + [i32] * 6 + [ctypes.c_float, i32, ctypes.c_float, i32, vp]
     L.dissc_wav_postprocess.argtypes = [vp, vp, i32, i32, vp]
     L.dissc_pitch_stats.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     i64 = ctypes.c_longlong

@@ -209,6 +209,21 @@ int run_wino(const DevConv& dc, const float* x, float* out, const float* res, fl
              int len_default, int len_mul, int B, int ldx, int ldo, int Lmax, float slope, int epi, float mrf_div,
              hipStream_t stream);
 
+// one residual pair per launch with BOTH convs in the Toom-Cook transform domain, t kept in LDS (respair_wino.hip)
+struct DevPairW {
+  float* w1 = nullptr;  // register-order transform-domain weights of conv_d / conv_1
+  float* w2 = nullptr;
+  float* b1 = nullptr;
+  float* b2 = nullptr;
+  int C = 0, KS = 0, dil = 1;
+};
+extern int g_pair_wino;  // "pair_wino" option (read at dissc_gen_create)
+bool pairw_supported(int C, int KS, int dil);
+int make_pairw(const float* w1, const float* b1, const float* w2, const float* b2, int C, int KS, int dil, DevPairW& pw);
+void free_pairw(DevPairW& pw);
+int launch_respair_wino(const DevPairW& pw, const float* x, float* out, float* acc, const int32_t* lengths, int len_default,
+                        int len_mul, int B, int Lmax, int ld, float slope, int epi, float mrf_div, hipStream_t stream);
+
 // one residual pair y = x + conv_1(lrelu(conv_d(lrelu(x)))) per launch, exact fp32 (respair.hip)
 extern int g_pair_pad_lds;
 extern int g_conv_pad_lds;

@@ -71,6 +71,7 @@ struct dissc_gen {
   DevConv conv_pre;
   std::vector<std::vector<DevConv>> ups;  // per stage: one conv per phase group
   std::vector<DevConv> rb1, rb2;  // [stage*nk*3 + j*3 + m]
+  std::vector<DevPairW> pw;       // same index: the pair as ONE transform-domain launch (respair_wino.hip), w1 == nullptr if not
   std::vector<float*> fused_w, fused_b;  // [stage*nk + j]: 6 packed convs / biases of a split-bf16 fused ResBlock
   std::vector<char> fused_bf3;           // ... (resblock_bf3.hip; precision = 1 only)
   float* post_w = nullptr;
@@ -104,6 +105,7 @@ struct dissc_gen {
     for (auto& v : ups) for (auto& c : v) free_conv(c);
     for (auto& c : rb1) free_conv(c);
     for (auto& c : rb2) free_conv(c);
+    for (auto& c : pw) free_pairw(c);
     for (float* p : fused_w) if (p) (void)hipFree(p);
     for (float* p : fused_b) if (p) (void)hipFree(p);
     if (post_w) (void)hipFree(post_w);
@@ -210,6 +212,7 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
   const int nk = cfg->num_kernels;
   g->rb1.resize((size_t)cfg->num_upsamples * nk * 3);
   g->rb2.resize((size_t)cfg->num_upsamples * nk * 3);
+  g->pw.resize((size_t)cfg->num_upsamples * nk * 3);
   g->fused_w.assign((size_t)cfg->num_upsamples * nk, nullptr);
   g->fused_b.assign((size_t)cfg->num_upsamples * nk, nullptr);
   g->fused_bf3.assign((size_t)cfg->num_upsamples * nk, 0);
@@ -249,6 +252,8 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         const bool wino = prec == 0 && wino_wanted(ch, rk) && wino_supported(ch, ch, rk, d);
         if ((rc = wino ? make_wino(w, b, ch, rk, d, g->rb1[idx]) : make_conv(w, b, ch, ch, rk, d, g->rb1[idx])))
           return fail(rc);
+        const float* w1c = w;
+        const float* b1c = b;
         if (bf3) {
           w6[2 * m] = w;
           fb.insert(fb.end(), b, b + ch);
@@ -259,6 +264,10 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         if ((rc = get(name, {ch}, &b))) return fail(rc);
         const bool wino2 = wino;
         if ((rc = wino2 ? make_wino(w, b, ch, rk, 1, g->rb2[idx]) : make_conv(w, b, ch, ch, rk, 1, g->rb2[idx])))
+          return fail(rc);
+        // the whole pair as one transform-domain launch (respair_wino.hip): C = 32, k = 7 / 11 and C = 64, k = 3
+        if (prec == 0 && g_pair_wino && g_wino && pairw_supported(ch, rk, d) && (ch > 32 || ch <= g_pair_max_c) &&
+            (ch < 64 || wino) && (rc = make_pairw(w1c, b1c, w, b, ch, rk, d, g->pw[idx])))
           return fail(rc);
         if (bf3) {
           w6[2 * m + 1] = w;
@@ -352,7 +361,13 @@ double dissc_gen_flops_executed(dissc_gen_t g, int64_t frames) {
   for (int i = 0; i < g->cfg.num_upsamples; ++i) {
     for (auto& c : g->ups[i]) macs += c.macs_per_t * mul;
     mul = g->stage_mul[i];
-    for (int j = 0; j < nk * 3; ++j) macs += (ex(g->rb1[(size_t)i * nk * 3 + j]) + ex(g->rb2[(size_t)i * nk * 3 + j])) * mul;
+    for (int j = 0; j < nk * 3; ++j) {
+      const size_t idx = (size_t)i * nk * 3 + j;
+      if (g->pw[idx].w1)  // the pair runs as one transform-domain launch (respair_wino.hip)
+        macs += 2.0 * wino_executed_macs_per_t(g->pw[idx].C, g->pw[idx].KS) * mul;
+      else
+        macs += (ex(g->rb1[idx]) + ex(g->rb2[idx])) * mul;
+    }
   }
   macs += (double)g->post_C * g->post_KS * mul;
   return 2.0 * macs * (double)frames;
@@ -529,7 +544,9 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
         bool pairs = !g->rb1[i0].prec && g->rb1[i0].m32 == (ch >= 32 ? 1 : 0);
         for (int m = 0; m < 3 && pairs; ++m)
           pairs = respair_supported(ch, g->rb1[i0 + m].KS, g->rb1[i0 + m].dil);
-        if (pairs) {
+        // (a chain whose three pairs all have a fused transform-domain form takes this path too, whatever its width)
+        const bool allw = g->pw[i0].w1 && g->pw[i0 + 1].w1 && g->pw[i0 + 2].w1 && (ch > 32 || ch <= g_pair_max_c);
+        if (pairs || allw) {
           const float* src[3] = {X, XKc, TMPc};
           float* dst[3] = {XKc, TMPc, nullptr};
           for (int m = 0; m < 3; ++m) {
@@ -538,9 +555,12 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
               epi = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET) : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
               if (multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));
             }
-            if ((rc = launch_respair(g->rb1[i0 + m], g->rb2[i0 + m], src[m], dst[m], ACC, lengths, L, mul, B, L,
-                                     ld, 0.1f, epi, (float)nk, sj)))
-              return rc;
+            if (g->pw[i0 + m].w1)
+              rc = launch_respair_wino(g->pw[i0 + m], src[m], dst[m], ACC, lengths, L, mul, B, L, ld, 0.1f, epi, (float)nk, sj);
+            else
+              rc = launch_respair(g->rb1[i0 + m], g->rb2[i0 + m], src[m], dst[m], ACC, lengths, L, mul, B, L, ld, 0.1f, epi,
+                                  (float)nk, sj);
+            if (rc) return rc;
           }
           if (multi) DISSC_HIP_CHECK(hipEventRecord(g->ev_fin[j], sj));
           continue;
@@ -639,6 +659,129 @@ int dissc_conv1d(const float* x, const float* w_host, const float* bias_host, fl
   return conv_once(dc, x, y, lengths, B, ldx, ldo, Lmax, in_slope, (hipStream_t)stream);
 }
 
+// Diagnostics / tests: ONE residual pair y = x + conv_1(lrelu(conv_d(lrelu(x)))) (or its MRF modes) on device data with
+// host weights, through a chosen implementation: mode 0 = two direct conv launches, 1 = the fused direct pair
+// (respair.hip), 2 = two conv_wino launches, 3 = the fused transform-domain pair (respair_wino.hip).  Synchronous.
+static int pair_run(int mode, const DevConv& c1, const DevConv& c2, const DevPairW& pw, const float* x, float* tmp, float* y,
+                    float* acc, const int32_t* lengths, int B, int C, int ld, int Lmax, float slope, int epi, float mrf_div,
+                    hipStream_t st) {
+  int rc;
+  switch (mode) {
+    case 0:
+      if ((rc = run_conv(c1, x, tmp, nullptr, nullptr, lengths, Lmax, 1, B, C, ld, ld, Lmax, slope, EPI_STORE, 1.f, st))) return rc;
+      return run_conv(c2, tmp, y, x, acc, lengths, Lmax, 1, B, C, ld, ld, Lmax, slope, epi, mrf_div, st);
+    case 1:
+      return launch_respair(c1, c2, x, y, acc, lengths, Lmax, 1, B, Lmax, ld, slope, epi, mrf_div, st);
+    case 2:
+      if ((rc = run_wino(c1, x, tmp, nullptr, nullptr, lengths, Lmax, 1, B, ld, ld, Lmax, slope, EPI_STORE, 1.f, st))) return rc;
+      return run_wino(c2, tmp, y, x, acc, lengths, Lmax, 1, B, ld, ld, Lmax, slope, epi, mrf_div, st);
+    case 3:
+      return launch_respair_wino(pw, x, y, acc, lengths, Lmax, 1, B, Lmax, ld, slope, epi, mrf_div, st);
+    default:
+      set_error("pair mode %d", mode);
+      return DISSC_EINVAL;
+  }
+}
+
+static int pair_make(int mode, const float* w1, const float* b1, const float* w2, const float* b2, int C, int k, int d,
+                     DevConv& c1, DevConv& c2, DevPairW& pw) {
+  int rc;
+  if (mode == 2) {
+    if (!wino_supported(C, C, k, d) && !(C == 32 && (k == 3 || k == 7 || k == 11) && (d == 1 || d == 3 || d == 5))) {
+      set_error("pair mode 2: no conv_wino instance for C = %d, k = %d, d = %d", C, k, d);
+      return DISSC_EINVAL;
+    }
+    if ((rc = make_wino(w1, b1, C, k, d, c1))) return rc;
+    return make_wino(w2, b2, C, k, 1, c2);
+  }
+  if (mode == 3) return make_pairw(w1, b1, w2, b2, C, k, d, pw);
+  if ((rc = make_conv(w1, b1, C, C, k, d, c1))) return rc;
+  return make_conv(w2, b2, C, C, k, 1, c2);
+}
+
+int dissc_respair1d(const float* x, const float* w1_host, const float* b1_host, const float* w2_host, const float* b2_host,
+                    float* y, float* acc, const int32_t* lengths, int B, int C, int k, int dilation, int ld, int Lmax,
+                    float slope, int epi, float mrf_div, int mode, void* stream) {
+  if (!x || !w1_host || !w2_host || !y || k % 2 != 1 || dilation < 1 || B <= 0 || epi < EPI_RES || epi > EPI_MRF_DIV ||
+      (epi != EPI_RES && !acc)) {
+    set_error("dissc_respair1d: bad argument");
+    return DISSC_EINVAL;
+  }
+  DevConv c1, c2;
+  DevPairW pw;
+  float* tmp = nullptr;
+  int rc = pair_make(mode, w1_host, b1_host, w2_host, b2_host, C, k, dilation, c1, c2, pw);
+  if (!rc && (mode == 0 || mode == 2) && hipMalloc((void**)&tmp, (size_t)B * C * ld * sizeof(float)) != hipSuccess) {
+    set_error("dissc_respair1d: hipMalloc");
+    rc = DISSC_ENOMEM;
+  }
+  if (!rc) rc = pair_run(mode, c1, c2, pw, x, tmp, y, acc, lengths, B, C, ld, Lmax, slope, epi, mrf_div, (hipStream_t)stream);
+  const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  if (tmp) (void)hipFree(tmp);
+  free_conv(c1);
+  free_conv(c2);
+  free_pairw(pw);
+  if (rc) return rc;
+  DISSC_HIP_CHECK(e);
+  return DISSC_OK;
+}
+
+// Diagnostics: average ms of `iters` launches of one residual pair (modes as dissc_respair1d) on synthetic data.
+int dissc_pair_bench(int B, int C, int k, int dilation, int L, int epi, int iters, int mode, float* ms_out) {
+  if (!ms_out || B <= 0 || L <= 0 || iters <= 0 || epi < EPI_RES || epi > EPI_MRF_DIV) {
+    set_error("dissc_pair_bench: bad argument");
+    return DISSC_EINVAL;
+  }
+  std::vector<float> w1((size_t)C * C * k), w2((size_t)C * C * k), bias(C, 0.1f);
+  uint32_t s = 12345u;
+  auto rnd = [&]() {
+    s = s * 1664525u + 1013904223u;
+    return (s >> 8) / 16777216.0f - 0.5f;
+  };
+  for (auto& v : w1) v = rnd() * 0.05f;
+  for (auto& v : w2) v = rnd() * 0.05f;
+  DevConv c1, c2;
+  DevPairW pw;
+  int rc = pair_make(mode, w1.data(), bias.data(), w2.data(), bias.data(), C, k, dilation, c1, c2, pw);
+  const int ld = (L + 3) / 4 * 4;
+  const size_t n = (size_t)B * C * ld;
+  float *x = nullptr, *y = nullptr, *t = nullptr, *a = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipSuccess;
+  float ms = 0.f;
+  if (!rc) {
+    std::vector<float> hx(n);
+    for (auto& v : hx) v = rnd() * 2.f;
+    if (hipMalloc((void**)&x, n * 4) != hipSuccess || hipMalloc((void**)&y, n * 4) != hipSuccess ||
+        hipMalloc((void**)&t, n * 4) != hipSuccess || hipMalloc((void**)&a, n * 4) != hipSuccess ||
+        hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemset(a, 0, n * 4) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+      set_error("dissc_pair_bench: allocation failed");
+      rc = DISSC_ENOMEM;
+    }
+  }
+  auto once = [&]() { return pair_run(mode, c1, c2, pw, x, t, y, a, nullptr, B, C, ld, L, 0.1f, epi, 3.f, nullptr); };
+  for (int it = 0; it < 2 && !rc; ++it) rc = once();
+  if (!rc) {
+    (void)hipEventRecord(e0, nullptr);
+    for (int it = 0; it < iters && !rc; ++it) rc = once();
+    (void)hipEventRecord(e1, nullptr);
+    e = hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / iters;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  for (float* q : {x, y, t, a})
+    if (q) (void)hipFree(q);
+  free_conv(c1);
+  free_conv(c2);
+  free_pairw(pw);
+  if (rc) return rc;
+  DISSC_HIP_CHECK(e);
+  return DISSC_OK;
+}
+
 int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bias_host, float* y,
                            const int32_t* lengths, int B, int Cin, int Cout, int k, int stride,
                            int ldx, int ldo, int Lmax, float in_slope, void* stream) {
@@ -715,6 +858,7 @@ int dissc_set_option(const char* key, int value) {
     return DISSC_OK;
   }
   if (strcmp(key, "pair_max_c") == 0) { g_pair_max_c = value; return DISSC_OK; }
+  if (strcmp(key, "pair_wino") == 0) { g_pair_wino = value; return DISSC_OK; }
   if (strcmp(key, "pair_pad_lds") == 0) { g_pair_pad_lds = value; return DISSC_OK; }
   if (strcmp(key, "conv_pad_lds") == 0) { g_conv_pad_lds = value; return DISSC_OK; }
   if (strcmp(key, "pair_lds") == 0) { g_pair_lds_mode = value; return DISSC_OK; }

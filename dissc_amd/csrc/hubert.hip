@@ -848,7 +848,7 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
       if (note(hipEventRecord(m->ev_join[i - 1], si), "join record"))
         note(hipStreamWaitEvent(st, m->ev_join[i - 1], 0), "join wait");
       else
-        hipStreamSynchronize(si);
+        (void)hipStreamSynchronize(si);
     }
   }
   return rc;

@@ -168,15 +168,15 @@ class WaveStore:
             # pageable copy_ is ordered behind everything on the stream and blocks the host until the round's
             # kernels are done -- the caller could not start batching the next round meanwhile
             n_h, n_r = head.size, max(self.n, 1)
-            stage = torch.empty(n_h + n_r + 2 * n_r, dtype=torch.int32, pin_memory=True)
+            stage = torch.empty(2 * n_r + n_h + n_r, dtype=torch.int32, pin_memory=True)  # [offsets i64 | header | counts]
             sn = stage.numpy()
-            sn[:n_h] = head.reshape(-1)
-            sn[n_h:n_h + self.n] = ns
-            sn[n_h + n_r:n_h + n_r + 2 * self.n] = offs.astype(np.int64).view(np.int32)
+            sn[:2 * self.n] = offs.astype(np.int64).view(np.int32)
+            sn[2 * n_r:2 * n_r + n_h] = head.reshape(-1)
+            sn[2 * n_r + n_h:2 * n_r + n_h + self.n] = ns
             d_stage = stage.to(self.device, non_blocking=True)
-            buf[:tbl].copy_(d_stage[:n_h].view(torch.float32))
-            d_ns = d_stage[n_h:n_h + n_r]
-            d_off = d_stage[n_h + n_r:].view(torch.int64)
+            d_off = d_stage[:2 * n_r].view(torch.int64)   # at offset 0: 8-byte aligned
+            buf[:tbl].copy_(d_stage[2 * n_r:2 * n_r + n_h].view(torch.float32))
+            d_ns = d_stage[2 * n_r + n_h:]
             data = buf[tbl:]
             assert data.data_ptr() % 16 == 0
             with torch.cuda.device(self.device):

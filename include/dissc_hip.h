@@ -143,6 +143,9 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   cpb2 (0)             k <= value convs stage 32 channels per barrier
  *   pair_max_c (32)      widest fp32 stage whose residual pairs (conv_d -> conv_1 -> +x) run as ONE launch each
  *                        (respair.hip; 0 = every conv its own launch; results are bit-identical either way)
+ *   pair_wino (1)        read at dissc_gen_create: residual pairs with C = 32, k = 7 / 11 and C = 64, k = 3 run as ONE launch with
+ *                        both convs in the Toom-Cook transform domain and the intermediate in LDS (respair_wino.hip); 0 = the
+ *                        direct fused pair (C = 32) / two transform-domain launches (C = 64)
  *   bf3_pairs (-1)       split-bf16 fused ResBlocks as three launches of one residual pair each: -1 = for >= 64
  *                        channels only, 0 = never, 1 = always
  *   fused_variant (0)    split-bf16 fused ResBlocks: 0 = 512-column windows, 1 = 1024
@@ -168,6 +171,17 @@ int dissc_get_option(const char* key, int* value);
  * tile shape for this process (0 = keep). */
 int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int epi, int iters,
                      int flags, float* ms_out);
+
+/* Diagnostics / tests (not on the product path): ONE residual pair of a ResBlock1,
+ *   y = x + conv_1(lrelu(conv_d(lrelu(x))))          (reference sr/models.py:34-41; `epi` 1 = that, 2..4 = the MRF modes on `acc`)
+ * on device data x / y / acc f32 [B,C,ld] with host weights [C,C,k] + biases [C], through a chosen implementation:
+ * mode 0 = two direct conv launches, 1 = the fused direct pair (C = 16 / 32), 2 = two transform-domain launches
+ * (conv_wino), 3 = the fused transform-domain pair (respair_wino: C = 32 with k = 7 / 11, C = 64 with k = 3).
+ * y must not alias x.  dissc_respair1d synchronises the stream; dissc_pair_bench times `iters` launches on synthetic data. */
+int dissc_respair1d(const float* x, const float* w1_host, const float* b1_host, const float* w2_host, const float* b2_host,
+                    float* y, float* acc, const int32_t* lengths, int B, int C, int k, int dilation, int ld, int Lmax,
+                    float slope, int epi, float mrf_div, int mode, void* stream);
+int dissc_pair_bench(int B, int C, int k, int dilation, int L, int epi, int iters, int mode, float* ms_out);
 
 /* ------------------------------------------------------------------------- *
  * Length / pitch predictors and infer.py's integer sample logic.

@@ -367,19 +367,45 @@ def test_precision_option_leaves_predictors_and_units_exact():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_fused_residual_pairs_are_bit_identical_to_separate_launches(env):
-    """respair.hip (one launch per residual pair of the narrow stages) against the same generator with
-    every conv as its own launch ("pair_max_c" = 0): identical bits, for a ragged batch (window edges,
-    utterance ends inside a window, a 1-frame utterance) and at the BASELINE size."""
-    lib, g, synth = env["lib"], env["g"], env["synth"]
-    cur = ctypes.c_int(0)
-    assert lib.dissc_get_option(b"pair_max_c", ctypes.byref(cur)) == 0 and cur.value >= 16
+def _generator_with(lib, synth, **options):
+    """an instance built under the given creation-time options (restored afterwards)"""
+    import dissc_amd
+    saved = {}
+    try:
+        for k, v in options.items():
+            cur = ctypes.c_int(0)
+            saved[k] = cur.value if lib.dissc_get_option(k.encode(), ctypes.byref(cur)) != 0 else cur.value
+            assert lib.dissc_set_option(k.encode(), v) == 0
+        gd = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
+        gd.load_state_dict(synth.synth_generator_state_dict(seed=0))
+        gd.eval().remove_weight_norm()
+        c1, f1, s1, _ = synth.synth_generator_inputs(1, 3, seed=1)
+        gd(code=torch.from_numpy(c1), f0=torch.from_numpy(f1), spkr=torch.from_numpy(s1))  # the native handle is built here
+    finally:
+        for k in options:
+            lib.dissc_set_option(k.encode(), 1 if k in ("pair_wino", "wino") else saved[k])
+    return gd
+
+
+def _pair_cases(synth):
     cases = [synth.synth_generator_inputs(6, 41, seed=21, ragged=True), synth.synth_generator_inputs(32, 500, seed=1234)]
     code, f0, spkr, lengths = cases[0]
     lengths = lengths.copy()
     lengths[1], lengths[2] = 1, 41
     cases[0] = (code, f0, spkr, lengths)
-    for code, f0, spkr, lengths in cases:
+    return cases
+
+
+def test_fused_residual_pairs_are_bit_identical_to_separate_launches(env):
+    """respair.hip (one launch per residual pair of the narrow stages, direct form) against the same generator with
+    every conv as its own launch ("pair_max_c" = 0): identical bits, for a ragged batch (window edges,
+    utterance ends inside a window, a 1-frame utterance) and at the BASELINE size.  (Instance built with "pair_wino" = 0:
+    the default one runs the k = 7 / 11 pairs of the 32-channel stage in the transform domain, test below.)"""
+    lib, synth = env["lib"], env["synth"]
+    g = _generator_with(lib, synth, pair_wino=0)
+    cur = ctypes.c_int(0)
+    assert lib.dissc_get_option(b"pair_max_c", ctypes.byref(cur)) == 0 and cur.value >= 16
+    for code, f0, spkr, lengths in _pair_cases(synth):
         kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
                   lengths=torch.from_numpy(lengths))
         y_pair = g(**kw).cpu()
@@ -390,3 +416,23 @@ def test_fused_residual_pairs_are_bit_identical_to_separate_launches(env):
             lib.dissc_set_option(b"pair_max_c", cur.value)
         assert torch.isfinite(y_pair).all()
         assert torch.equal(y_pair, y_sep)
+
+
+def test_transform_domain_pairs_agree_with_the_unfused_generator(env):
+    """respair_wino.hip (default: the k = 7 / 11 pairs of the 32-channel stage and the k = 3 pairs of the 64-channel stage
+    as ONE transform-domain launch each) against an instance built with "pair_wino" = 0: same waveform to fp32 rounding,
+    ragged and at the BASELINE size; and fewer executed FLOPs are reported for it."""
+    lib, g, synth = env["lib"], env["g"], env["synth"]
+    gd = _generator_with(lib, synth, pair_wino=0)
+    assert g.flops_executed(1000) < gd.flops_executed(1000) and g.flops(1000) == gd.flops(1000)
+    for code, f0, spkr, lengths in _pair_cases(synth):
+        kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
+                  lengths=torch.from_numpy(lengths))
+        yw, yd = g(**kw).cpu(), gd(**kw).cpu()
+        assert torch.isfinite(yw).all() and not torch.equal(yw, yd)
+        e = (yw - yd).double()
+        rms = float(e.pow(2).mean().sqrt())
+        print(f"B={code.shape[0]} T={code.shape[1]}: fused transform-domain pairs vs pair_wino=0: rms {rms:.2e}, max {float(e.abs().max()):.2e}")
+        assert rms <= 5e-6 and float(e.abs().max()) <= 1e-4
+        one = g(code=kw["code"][:1], f0=kw["f0"][:1], spkr=kw["spkr"][:1], lengths=kw["lengths"][:1]).cpu()[0]
+        assert torch.equal(one, yw[0])  # an utterance's samples do not depend on the batch it runs in
