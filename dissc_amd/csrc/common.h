@@ -218,7 +218,9 @@ struct DevPairW {
   int C = 0, KS = 0, dil = 1;
 };
 extern int g_pair_wino;  // "pair_wino" option (read at dissc_gen_create)
+extern int g_pairw_chv;  // "pairw_chv" option
 bool pairw_supported(int C, int KS, int dil);
+bool pairw_wanted(int C, int KS, int dil);  // the generator's policy ("pair_wino" option)
 int make_pairw(const float* w1, const float* b1, const float* w2, const float* b2, int C, int KS, int dil, DevPairW& pw);
 void free_pairw(DevPairW& pw);
 int launch_respair_wino(const DevPairW& pw, const float* x, float* out, float* acc, const int32_t* lengths, int len_default,

@@ -266,8 +266,9 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         if ((rc = wino2 ? make_wino(w, b, ch, rk, 1, g->rb2[idx]) : make_conv(w, b, ch, ch, rk, 1, g->rb2[idx])))
           return fail(rc);
         // the whole pair as one transform-domain launch (respair_wino.hip): C = 32, k = 7 / 11 and C = 64, k = 3
-        if (prec == 0 && g_pair_wino && g_wino && pairw_supported(ch, rk, d) && (ch > 32 || ch <= g_pair_max_c) &&
-            (ch < 64 || wino) && (rc = make_pairw(w1c, b1c, w, b, ch, rk, d, g->pw[idx])))
+        // (C = 64: only a chain's FIRST pair -- the later ones update x_k in place, which a fused pair cannot)
+        if (prec == 0 && g_wino && pairw_wanted(ch, rk, d) && (ch > 32 ? (wino && m == 0) : ch <= g_pair_max_c) &&
+            (rc = make_pairw(w1c, b1c, w, b, ch, rk, d, g->pw[idx])))
           return fail(rc);
         if (bf3) {
           w6[2 * m + 1] = w;
@@ -544,9 +545,7 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
         bool pairs = !g->rb1[i0].prec && g->rb1[i0].m32 == (ch >= 32 ? 1 : 0);
         for (int m = 0; m < 3 && pairs; ++m)
           pairs = respair_supported(ch, g->rb1[i0 + m].KS, g->rb1[i0 + m].dil);
-        // (a chain whose three pairs all have a fused transform-domain form takes this path too, whatever its width)
-        const bool allw = g->pw[i0].w1 && g->pw[i0 + 1].w1 && g->pw[i0 + 2].w1 && (ch > 32 || ch <= g_pair_max_c);
-        if (pairs || allw) {
+        if (pairs) {
           const float* src[3] = {X, XKc, TMPc};
           float* dst[3] = {XKc, TMPc, nullptr};
           for (int m = 0; m < 3; ++m) {
@@ -569,6 +568,12 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
       for (int m = 0; m < 3; ++m) {
         const size_t idx = ((size_t)i * nk + j) * 3 + m;
         const float* xin = (m == 0) ? X : XKc;
+        if (m == 0 && g->pw[idx].w1) {
+          // the chain's first pair as ONE transform-domain launch (respair_wino.hip): X -> XK, t never leaves LDS
+          if ((rc = launch_respair_wino(g->pw[idx], xin, XKc, ACC, lengths, L, mul, B, L, ld, 0.1f, EPI_RES, (float)nk, sj)))
+            return rc;
+          continue;
+        }
         if (g->rb1[idx].wino && g->rb2[idx].wino) {
           // Toom-Cook F(4,3) form (conv_wino.hip): t = conv_d(lrelu(x)); x = x + conv_1(lrelu(t)) / MRF update
           if ((rc = run_wino(g->rb1[idx], xin, TMPc, nullptr, nullptr, lengths, L, mul, B, ld, ld, L, 0.1f, EPI_STORE,
@@ -859,6 +864,7 @@ int dissc_set_option(const char* key, int value) {
   }
   if (strcmp(key, "pair_max_c") == 0) { g_pair_max_c = value; return DISSC_OK; }
   if (strcmp(key, "pair_wino") == 0) { g_pair_wino = value; return DISSC_OK; }
+  if (strcmp(key, "pairw_chv") == 0) { g_pairw_chv = value == 2 ? 2 : 1; return DISSC_OK; }
   if (strcmp(key, "pair_pad_lds") == 0) { g_pair_pad_lds = value; return DISSC_OK; }
   if (strcmp(key, "conv_pad_lds") == 0) { g_conv_pad_lds = value; return DISSC_OK; }
   if (strcmp(key, "pair_lds") == 0) { g_pair_lds_mode = value; return DISSC_OK; }

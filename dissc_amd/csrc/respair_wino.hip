@@ -33,8 +33,8 @@
 
 namespace dissc {
 
-int g_pair_wino = 1;  // "pair_wino" option (read at dissc_gen_create): 1 = the shapes pairw_supported() names run as fused
-                      // transform-domain pairs, 0 = as before (respair32 direct / two conv_wino launches)
+int g_pair_wino = 1;  // "pair_wino" option (read at dissc_gen_create): 1 = the shapes pairw_wanted() names run as fused
+                      // transform-domain pairs, 2 = every shape with an instance, 0 = none (respair32 direct / two conv_wino launches)
 
 struct PairWArgs {
   const float* x;     // [B][C][ld] pair input x_k
@@ -51,6 +51,7 @@ struct PairWArgs {
   float slope, mrf_div;
   int epi;
   int gx, B;
+  int dbg;  // diagnostics ("wino_dbg" option): knock-outs, bit 0 transforms, 1 MFMAs, 2 the A^T passes of the exchanges
 };
 
 constexpr int pw_rup4(int n) { return (n + 3) / 4 * 4; }
@@ -80,7 +81,9 @@ constexpr int pw_row_len(int D, int NTU, int XRW) {
 }
 
 // geometry of one (C, KS, DIL) instance, shared by the kernel and the host
-template <int C, int KS, int DIL>
+// CHV: column halves per workgroup -- 2: 12 waves, one workgroup per CU; 1: 6 waves and half the tile, TWO workgroups per
+// CU whose phases overlap (the staging / exchange / transform phases of one cover MFMA phases of the other)
+template <int C, int KS, int DIL, int CHV>
 struct PairWGeo {
   static constexpr int NS = (KS + 2) / 3;
   static constexpr int MI = C / 32;
@@ -89,55 +92,60 @@ struct PairWGeo {
   static constexpr int P2 = (KS - 1) / 2, P1 = P2 * DIL;
   static constexpr int D1 = DIL * NS, W1 = DIL * (2 * NS - 1), D2 = NS, W2 = 2 * NS - 1;
   static constexpr int NTU1 = NCW / D1, NCOL1 = NTU1 * D1, NTU2 = NCW / D2, NCOL2 = NTU2 * D2;
-  static constexpr int T1 = 4 * D1 * NTU1 * 2;           // t values conv_d produces (both column halves)
-  static constexpr int O2 = 4 * D2 * NTU2 * 2;           // outputs conv_1 produces
+  static constexpr int T1 = 4 * D1 * NTU1 * CHV;         // t values conv_d produces
+  static constexpr int O2 = 4 * D2 * NTU2 * CHV;         // outputs conv_1 produces
   static constexpr int OTR = (T1 - 2 * P2) < O2 ? (T1 - 2 * P2) : O2;
   static constexpr int OT = OTR & ~3;                    // outputs a workgroup stores
   static constexpr int RAW1 = T1 + DIL * (3 * NS - 1);   // x samples conv_d's transforms touch
   static constexpr int XRW1 = pw_rup4(RAW1 + 3 + 3);     // staged positions per channel (alignment shift <= 3)
   static constexpr int NV1 = XRW1 / 4;
-  static constexpr int RL1 = pw_row_len(D1, 2 * NTU1, XRW1), CHF1 = D1 * RL1;
+  static constexpr int RL1 = pw_row_len(D1, CHV * NTU1, XRW1), CHF1 = D1 * RL1;
   static constexpr int XT2 = O2 + D2 * (3 * NS - 1);     // t positions conv_1's transforms touch (beyond T1: zeros)
-  static constexpr int RL2 = pw_row_len(D2, 2 * NTU2, pw_rup4(XT2 + 3)), CHF2 = D2 * RL2;
+  static constexpr int RL2 = pw_row_len(D2, CHV * NTU2, pw_rup4(XT2 + 3)), CHF2 = D2 * RL2;
   static constexpr int XV = (NTU1 * W1 > NTU2 * W2 ? NTU1 * W1 : NTU2 * W2) <= 48 ? 48 : 112;  // V row stride (% 32 == 16)
-  static constexpr int CPR = 16;                          // channels of the x window per round
+  static constexpr int CPR = CHV == 2 ? 16 : 8;           // channels of the x window per round
+  static constexpr int RP = CHV == 2 ? 1 : 2;             // row parts of a Y exchange pass (LDS budget)
+  static constexpr int NWV = 6 * CHV, NTH = 64 * NWV;
   static constexpr int YS = NCW + 4;
   static constexpr int T_FLOATS = C * CHF2;
   static constexpr int XW_FLOATS = CPR * CHF1;
-  static constexpr int V_FLOATS = 12 * 8 * XV;
-  static constexpr int Y_FLOATS = 6 * C * YS;             // one column half
+  static constexpr int V_FLOATS = NWV * 8 * XV;
+  static constexpr int Y_FLOATS = 6 * (C / RP) * YS;      // one exchange pass: a column half, C / RP rows
   static constexpr int S_FLOATS = (XW_FLOATS + V_FLOATS) > Y_FLOATS ? (XW_FLOATS + V_FLOATS) : Y_FLOATS;
   static constexpr int LDS_FLOATS = T_FLOATS + S_FLOATS;
   static constexpr int NW4 = MI * NS * (C / 8);           // float4 weight registers per lane and conv
   static_assert(C == 32 || C == 64, "C");
   static_assert(NTU1 >= 1 && NTU2 >= 1 && NTU1 * W1 <= XV && NTU2 * W2 <= XV, "tile geometry");
   static_assert(OT > 0 && OT + 2 * P2 <= T1 && OT <= O2, "output tile");
-  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
+  static_assert(LDS_FLOATS * 4 <= (CHV == 2 ? 160 : 80) * 1024, "LDS");
   static_assert(NW4 <= 16, "a point's weights must fit 64 registers");
 };
 
-template <int C, int KS, int DIL>
-__global__ void __launch_bounds__(768, 3) respair_wino_kernel(const PairWArgs a) {
-  using G = PairWGeo<C, KS, DIL>;
-  constexpr int NTH = 768;
+template <int C, int KS, int DIL, int CHV>
+__global__ void __launch_bounds__(384 * CHV, 3) respair_wino_kernel(const PairWArgs a) {
+  using G = PairWGeo<C, KS, DIL, CHV>;
+  constexpr int NTH = G::NTH, RP = G::RP;
   constexpr int NS = G::NS, MI = G::MI, NI = G::NI, NCW = G::NCW, XV = G::XV, YS = G::YS, CPR = G::CPR;
   constexpr int CL = 64 / NCW;                 // lanes per column in the transform (1 or 2: the halves take alternate channels)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const Treg = lds;                     // [C][D2][RL2]: t in conv_1's polyphase layout
   float* const scr = lds + G::T_FLOATS;        // x window + V tiles | Y exchange
   float* const xwin = scr;                     // [CPR][D1][RL1]
-  float* const vbuf = scr + G::XW_FLOATS;      // [12 waves][8][XV]
+  float* const vbuf = scr + G::XW_FLOATS;      // [waves][8][XV]
 
-  // ---- which tile: only the tiles that exist are enumerated (conv_wino.hip); the empty workgroups sit at the end
-  const int lin = blockIdx.x;
+  // ---- which tile: only the tiles that exist are enumerated (conv_wino.hip: utterance 0's ceil(len_0 / OT) tiles, then
+  // utterance 1's, ...), found by a prefix sum of the tile counts over the lanes; the empty workgroups sit at the end.
+  // (A persistent form -- workgroups looping over tiles, the next tile's weights and window fetched behind the last
+  // phase -- measured 10-15 % SLOWER: the loop keeps enough per-lane state alive to spill 50-80 registers.)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  int b = -1, len = a.len_default, o0 = 0;
-  if (a.lengths == nullptr) {
-    b = lin / a.gx;
-    o0 = (lin - b * a.gx) * G::OT;
-    if (b >= a.B || o0 >= len) return;
-  } else {
+  auto find_tile = [&](int lin, int& tb_, int& tlen, int& to0) __attribute__((always_inline)) -> bool {
+    if (a.lengths == nullptr) {
+      tb_ = lin / a.gx;
+      tlen = a.len_default;
+      to0 = (lin - tb_ * a.gx) * G::OT;
+      return tb_ < a.B && to0 < tlen;
+    }
     int base = 0;
     for (int b0 = 0; b0 < a.B; b0 += 64) {
       const int l = b0 + lane < a.B ? a.lengths[b0 + lane] * a.len_mul : 0;
@@ -152,20 +160,21 @@ __global__ void __launch_bounds__(768, 3) respair_wino_kernel(const PairWArgs a)
       if (lin < base + total) {
         const unsigned long long m = __ballot(base + incl > lin);
         const int lb = __ffsll((long long)m) - 1;
-        b = b0 + lb;
-        len = __builtin_amdgcn_readfirstlane(__shfl(l, lb, 64));
-        o0 = (lin - base - __builtin_amdgcn_readfirstlane(__shfl(incl - nt, lb, 64))) * G::OT;
-        break;
+        tb_ = __builtin_amdgcn_readfirstlane(b0 + lb);
+        tlen = __builtin_amdgcn_readfirstlane(__shfl(l, lb, 64));
+        to0 = __builtin_amdgcn_readfirstlane((lin - base - __shfl(incl - nt, lb, 64)) * G::OT);
+        return true;
       }
       base += total;
     }
-    if (b < 0) return;
-    b = __builtin_amdgcn_readfirstlane(b);
-    o0 = __builtin_amdgcn_readfirstlane(o0);
-  }
+    return false;
+  };
+  const int lin = blockIdx.x;
+  int b, len, o0;
+  if (!find_tile(lin, b, len, o0)) return;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = wave % 6;       // this wave's evaluation point
-  const int chh = wave / 6;     // ... and its column half
+  const int chh = CHV == 2 ? wave / 6 : 0;     // ... and its column half
   const int l31 = lane & 31, h = lane >> 5;
   const float slope = a.slope;
   const float* xb = a.x + (size_t)b * a.bstride;
@@ -173,33 +182,34 @@ __global__ void __launch_bounds__(768, 3) respair_wino_kernel(const PairWArgs a)
   const int o1 = o2 - G::P1;            // conv_d's window origin
   const int tb = o1 & ~3, sh = o1 - tb;
 
-  // ---- this wave's weights, conv_d first: NW4 float4 per lane, [p][mi][j][ksub][lane]
+  // ---- this wave's weights: NW4 float4 per lane, [p][mi][j][ksub][lane]; conv_d's first, conv_1's take the registers over
   f32x4 wr[G::NW4];
-  {
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.w1) + (size_t)p * G::NW4 * 64 + lane;
+  auto load_w = [&](const float* w) __attribute__((always_inline)) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(w) + (size_t)p * G::NW4 * 64 + lane;
 #pragma unroll
     for (int i = 0; i < G::NW4; ++i) wr[i] = wp[i * 64];
-  }
+  };
+  load_w(a.w1);
 
   // ---- x window staging (conv_wino.hip): clamped 16-byte loads, activation + zero padding + polyphase scatter to LDS
   constexpr int NV = G::NV1, SV = (CPR * NV + NTH - 1) / NTH;
   const int r0 = tid / NV, v0 = tid - r0 * NV;
   constexpr int dr = NTH / NV, dv = NTH - dr * NV;
   f32x4 sv[SV];
-  auto stage_load = [&](int rd) {
+  auto stage_load = [&](int rd, const float* xb_, int tb_) __attribute__((always_inline)) {
     int r = r0, v = v0;
 #pragma unroll
     for (int i = 0; i < SV; ++i) {
       const int ci = rd * CPR + (r < CPR ? r : CPR - 1);
-      int t = tb + 4 * v;
+      int t = tb_ + 4 * v;
       t = t < 0 ? 0 : (t > a.ld - 4 ? a.ld - 4 : t);
-      sv[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)ci * a.ld + t);
+      sv[i] = *reinterpret_cast<const f32x4*>(xb_ + (size_t)ci * a.ld + t);
       v += dv;
       r += dr;
       if (v >= NV) { v -= NV; ++r; }
     }
   };
-  auto stage_store = [&]() {
+  auto stage_store = [&]() __attribute__((always_inline)) {
     int r = r0, v = v0;
 #pragma unroll
     for (int i = 0; i < SV; ++i) {
@@ -219,16 +229,13 @@ __global__ void __launch_bounds__(768, 3) respair_wino_kernel(const PairWArgs a)
       if (v >= NV) { v -= NV; ++r; }
     }
   };
-  stage_load(0);
+  stage_load(0, xb, tb);
   // region T: zero (conv_1's transforms read a few positions beyond what conv_d produces; every sample a stored
   // output's F(4,3) group touches must be finite -- and zero costs no accuracy)
   for (int i = tid; i < G::T_FLOATS / 4; i += NTH) reinterpret_cast<f32x4*>(Treg)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  stage_store();
-  if (C / CPR > 1) stage_load(1);
-  __syncthreads();
 
   f32x16 acc[MI][NI];
-  auto zero_acc = [&]() {
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -239,7 +246,7 @@ __global__ void __launch_bounds__(768, 3) respair_wino_kernel(const PairWArgs a)
   float* const vp = vbuf + wave * (8 * XV);
 
   // transform of 8 channels for this wave's point and columns: lane <-> column (tau, phi), entries w = phi and phi + D
-  auto transform8 = [&](const float* win8, auto dc, auto wc, auto rlc, auto ntuc) {
+  auto transform8 = [&](const float* win8, auto dc, auto wc, auto rlc, auto ntuc) __attribute__((always_inline)) {
     constexpr int D = decltype(dc)::value, W = decltype(wc)::value, RL = decltype(rlc)::value, NTU = decltype(ntuc)::value;
     constexpr int NCOL = NTU * D, CHF = D * RL;
     const int cl = lane % NCW, csel = lane / NCW;
@@ -250,7 +257,8 @@ __global__ void __launch_bounds__(768, 3) respair_wino_kernel(const PairWArgs a)
     const bool ok1 = tphi + D < W;
     const int e1 = ok1 ? e0 + D : e0;
     const float* rw = win8 + toff;
-    auto go = [&](auto pc) {
+    if (a.dbg & 1) return;
+    auto go = [&](auto pc) __attribute__((always_inline)) {
       constexpr int P = decltype(pc)::value;
 #pragma unroll
       for (int it = 0; it < 8 / (2 * CL); ++it) {
@@ -284,9 +292,10 @@ __global__ void __launch_bounds__(768, 3) respair_wino_kernel(const PairWArgs a)
   };
 
   // NS taps x 4 k-steps on this wave's V tile with the register weights of sub-chunk `ksub` (compile-time)
-  auto run_taps = [&](auto ksc, auto dc, auto wc, auto ntuc, auto dilc) {
+  auto run_taps = [&](auto ksc, auto dc, auto wc, auto ntuc, auto dilc) __attribute__((always_inline)) {
     constexpr int KSUB = decltype(ksc)::value, D = decltype(dc)::value, W = decltype(wc)::value, NTU = decltype(ntuc)::value;
     constexpr int TD = decltype(dilc)::value, NCOL = NTU * D;
+    if (a.dbg & 2) return;
     const float* bj[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -320,33 +329,42 @@ __global__ void __launch_bounds__(768, 3) respair_wino_kernel(const PairWArgs a)
   using IR2 = std::integral_constant<int, G::RL2>;
   using IN2 = std::integral_constant<int, G::NTU2>;
 
+  stage_store();
+  if (C / CPR > 1) stage_load(1, xb, tb);
+  __syncthreads();
   // ================================ phase A: conv_d ================================
   zero_acc();
-  auto round_a = [&](auto rdc) {
-    constexpr int RD = decltype(rdc)::value;
-    transform8(xwin, ID1{}, IW1{}, IR1{}, IN1{});
-    run_taps(std::integral_constant<int, 2 * RD>{}, ID1{}, IW1{}, IN1{}, std::integral_constant<int, DIL>{});
-    transform8(xwin + 8 * G::CHF1, ID1{}, IW1{}, IR1{}, IN1{});
-    run_taps(std::integral_constant<int, 2 * RD + 1>{}, ID1{}, IW1{}, IN1{}, std::integral_constant<int, DIL>{});
-    if constexpr (RD + 1 < C / CPR) {
-      __syncthreads();   // every wave is done with this round's window
-      stage_store();     // round RD + 1 (its loads were issued a round ago)
-      if constexpr (RD + 2 < C / CPR) stage_load(RD + 2);
-      __syncthreads();
+  auto round_a = [&](auto rdc) __attribute__((always_inline)) {
+    constexpr int RD = decltype(rdc)::value, SPR = CPR / 8;  // 8-channel sub-chunks per round
+    if constexpr (RD < C / CPR) {
+      transform8(xwin, ID1{}, IW1{}, IR1{}, IN1{});
+      run_taps(std::integral_constant<int, SPR * RD>{}, ID1{}, IW1{}, IN1{}, std::integral_constant<int, DIL>{});
+      if constexpr (SPR > 1) {
+        transform8(xwin + 8 * G::CHF1, ID1{}, IW1{}, IR1{}, IN1{});
+        run_taps(std::integral_constant<int, SPR * RD + 1>{}, ID1{}, IW1{}, IN1{}, std::integral_constant<int, DIL>{});
+      }
+      if constexpr (RD + 1 < C / CPR) {
+        __syncthreads();   // every wave is done with this round's window
+        stage_store();     // round RD + 1 (its loads were issued a round ago)
+        if constexpr (RD + 2 < C / CPR) stage_load(RD + 2, xb, tb);
+        __syncthreads();
+      }
     }
   };
   round_a(std::integral_constant<int, 0>{});
   round_a(std::integral_constant<int, 1>{});
-  if constexpr (C / CPR > 2) {
-    round_a(std::integral_constant<int, 2>{});
-    round_a(std::integral_constant<int, 3>{});
-  }
+  round_a(std::integral_constant<int, 2>{});
+  round_a(std::integral_constant<int, 3>{});
+  round_a(std::integral_constant<int, 4>{});
+  round_a(std::integral_constant<int, 5>{});
+  round_a(std::integral_constant<int, 6>{});
+  round_a(std::integral_constant<int, 7>{});
 
   // ---- A^T of one row's quad: 4 consecutive outputs u = 4 g + e of unit tau from the Y_p [6][C][YS] in LDS
-  auto at_quad = [&](const float* yb, int row, int tau, int g, auto dc) -> f32x4 {
+  auto at_quad = [&](const float* yb, int row, int tau, int g, auto dc) __attribute__((always_inline)) -> f32x4 {
     constexpr int D = decltype(dc)::value;
     const float* yr = yb + row * YS + tau * D;
-    constexpr int PS = C * YS;  // point stride
+    constexpr int PS = (C / RP) * YS;  // point stride
     f32x4 v;
     if constexpr (D == 1) {
       const float y0 = yr[0], y1 = yr[PS], y2 = yr[2 * PS], y3 = yr[3 * PS], y4 = yr[4 * PS], y5 = yr[5 * PS];
@@ -391,62 +409,71 @@ __global__ void __launch_bounds__(768, 3) respair_wino_kernel(const PairWArgs a)
     }
     return v;
   };
-  auto y_write = [&](float* yb) {  // this wave's accumulators -> Y_p[row][col]
+  auto y_write = [&](float* yb, auto rpc) __attribute__((always_inline)) {  // this wave's accumulators of row part RPI -> Y_p[row][col]
+    constexpr int RPI = decltype(rpc)::value, RPP = C / RP;  // rows per part
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          yb[(p * C + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * YS + ni * 32 + l31] = acc[mi][ni][r];
+        for (int r = 0; r < 16; ++r) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int rbase = mi * 32 + 8 * (r >> 2);          // compile-time after unrolling; (r & 3) + 4 h stays below 8
+          if (rbase / RPP == RPI)
+            yb[(p * RPP + (rbase % RPP) + (r & 3) + 4 * h) * YS + ni * 32 + l31] = acc[mi][ni][r];
+        }
   };
 
   // ================================ phase B: Y exchange -> t in LDS ================================
   __syncthreads();  // all MFMAs of conv_d are done: the scratch region becomes the exchange buffer
-  {
-    // conv_1's weights take over the weight registers (fetched behind the exchange)
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.w2) + (size_t)p * G::NW4 * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < G::NW4; ++i) wr[i] = wp[i * 64];
-  }
+  load_w(a.w2);  // conv_1's weights take over the weight registers (fetched behind the exchange)
   float* const yb = scr;
+  auto pass_b = [&](auto hc, auto rpc) __attribute__((always_inline)) {
+    constexpr int half = decltype(hc)::value, RPI = decltype(rpc)::value, RPP = C / RP;
+    if constexpr (half < CHV && RPI < RP) {
+      if (half > 0 || RPI > 0) __syncthreads();
+      if (chh == half) y_write(yb, rpc);
+      __syncthreads();
+      constexpr int NQ = RPP * G::NCOL1, NIT = (NQ + NTH - 1) / NTH;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (half > 0) __syncthreads();
-    if (chh == half) y_write(yb);
-    __syncthreads();
-    constexpr int NQ = C * G::NCOL1, NIT = (NQ + NTH - 1) / NTH;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = tid + it * NTH;
-      if (idx >= NQ) continue;
-      const int row = idx / G::NCOL1, qi = idx - row * G::NCOL1;
-      const int tau = qi / G::D1, g = qi - tau * G::D1;
-      f32x4 v = at_quad(yb, row, tau, g, ID1{});
-      const float bz = a.b1[row];
-      const int x2 = 4 * G::D1 * (half * G::NTU1 + tau) + 4 * g;  // position within t (multiple of 4)
-      float* trow = Treg + row * G::CHF2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int nt = o2 + x2 + e;
-        v[e] = (nt >= 0 && nt < len) ? lrelu(v[e] + bz, slope) : 0.f;
-      }
-      if constexpr (G::D2 == 1) {
-        *reinterpret_cast<f32x4*>(trow + x2 + 4) = v;
-      } else {
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NTH;
+        if (idx >= NQ) continue;
+        if (a.dbg & 4) continue;
+        const int lrow = idx / G::NCOL1, qi = idx - lrow * G::NCOL1;
+        const int row = RPI * RPP + lrow;
+        const int tau = qi / G::D1, g = qi - tau * G::D1;
+        f32x4 v = at_quad(yb, lrow, tau, g, ID1{});
+        const float bz = a.b1[row];
+        const int x2 = 4 * G::D1 * (half * G::NTU1 + tau) + 4 * g;  // position within t (multiple of 4)
+        float* trow = Treg + row * G::CHF2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int xs = x2 + e + 4 * G::D2;
-          trow[(xs % G::D2) * G::RL2 + xs / G::D2] = v[e];
+          const int nt = o2 + x2 + e;
+          v[e] = (nt >= 0 && nt < len) ? lrelu(v[e] + bz, slope) : 0.f;
+        }
+        if constexpr (G::D2 == 1) {
+          *reinterpret_cast<f32x4*>(trow + x2 + 4) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int xs = x2 + e + 4 * G::D2;
+            trow[(xs % G::D2) * G::RL2 + xs / G::D2] = v[e];
+          }
         }
       }
     }
-  }
+  };
+  pass_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  pass_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  pass_b(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  pass_b(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
   __syncthreads();  // t is complete; the exchange buffer is free (the V tiles live in it)
 
   // ================================ phase C: conv_1 on T ================================
   zero_acc();
-  auto sub_c = [&](auto kc) {
+  auto sub_c = [&](auto kc) __attribute__((always_inline)) {
     constexpr int KSUB = decltype(kc)::value;
     transform8(Treg + (KSUB * 8) * G::CHF2, ID2{}, IW2{}, IR2{}, IN2{});
     run_taps(kc, ID2{}, IW2{}, IN2{}, std::integral_constant<int, 1>{});
@@ -466,68 +493,76 @@ __global__ void __launch_bounds__(768, 3) respair_wino_kernel(const PairWArgs a)
   const int epi = a.epi;
   const size_t ob = (size_t)b * a.bstride;
   __syncthreads();
+  auto pass_d = [&](auto hc, auto rpc) __attribute__((always_inline)) {
+    constexpr int half = decltype(hc)::value, RPI = decltype(rpc)::value, RPP = C / RP;
+    if constexpr (half < CHV && RPI < RP) {
+      constexpr int NQ = RPP * G::NCOL2, NIT = (NQ + NTH - 1) / NTH;
+      // residual quads of the pass, fetched before the exchange (raw x: this workgroup staged it a moment ago)
+      f32x4 pres[NIT];
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    constexpr int NQ = C * G::NCOL2, NIT = (NQ + NTH - 1) / NTH;
-    // residual quads of the pass, fetched before the exchange (raw x: this workgroup staged it a moment ago)
-    f32x4 pres[NIT];
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NTH;
+        const int lrow = idx / G::NCOL2, qi = idx - lrow * G::NCOL2;
+        const int row = RPI * RPP + lrow;
+        const int tau = qi / G::D2, g = qi - tau * G::D2;
+        const int xo = 4 * G::D2 * (half * G::NTU2 + tau) + 4 * g;
+        const int n0 = o0 + xo;
+        if (idx < NQ && xo < G::OT && n0 + 4 <= len) pres[it] = *reinterpret_cast<const f32x4*>(a.x + ob + (size_t)row * a.ld + n0);
+      }
+      if (half > 0 || RPI > 0) __syncthreads();
+      if (chh == half) y_write(yb, rpc);
+      __syncthreads();
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = tid + it * NTH;
-      const int row = idx / G::NCOL2, qi = idx - row * G::NCOL2;
-      const int tau = qi / G::D2, g = qi - tau * G::D2;
-      const int xo = 4 * G::D2 * (half * G::NTU2 + tau) + 4 * g;
-      const int n0 = o0 + xo;
-      if (idx < NQ && xo < G::OT && n0 + 4 <= len) pres[it] = *reinterpret_cast<const f32x4*>(a.x + ob + (size_t)row * a.ld + n0);
-    }
-    if (half > 0) __syncthreads();
-    if (chh == half) y_write(yb);
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = tid + it * NTH;
-      if (idx >= NQ) continue;
-      const int row = idx / G::NCOL2, qi = idx - row * G::NCOL2;
-      const int tau = qi / G::D2, g = qi - tau * G::D2;
-      const int xo = 4 * G::D2 * (half * G::NTU2 + tau) + 4 * g;
-      const int n0 = o0 + xo;
-      if (xo >= G::OT || n0 >= len) continue;   // (OT is a multiple of 4: a quad is stored whole or not at all)
-      f32x4 v = at_quad(yb, row, tau, g, ID2{});
-      const float bz = a.b2[row];
-      v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
-      const size_t ix = ob + (size_t)row * a.ld + n0;
-      if (n0 + 4 <= len) {
-        const f32x4 rs = pres[it];
-        v[0] += rs[0]; v[1] += rs[1]; v[2] += rs[2]; v[3] += rs[3];
-        if (epi == EPI_RES) {
-          *reinterpret_cast<f32x4*>(a.out + ix) = v;
-        } else if (epi == EPI_MRF_SET) {
-          *reinterpret_cast<f32x4*>(a.acc + ix) = v;
-        } else {
-          const f32x4 ac = *reinterpret_cast<const f32x4*>(a.acc + ix);
-          v[0] = ac[0] + v[0]; v[1] = ac[1] + v[1]; v[2] = ac[2] + v[2]; v[3] = ac[3] + v[3];
-          if (epi == EPI_MRF_DIV) {
-            v[0] = __fdiv_rn(v[0], a.mrf_div); v[1] = __fdiv_rn(v[1], a.mrf_div);
-            v[2] = __fdiv_rn(v[2], a.mrf_div); v[3] = __fdiv_rn(v[3], a.mrf_div);
-          }
-          *reinterpret_cast<f32x4*>(a.acc + ix) = v;
-        }
-      } else {
-        for (int e = 0; e < len - n0; ++e) {
-          float x = v[e] + a.x[ix + e];
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NTH;
+        if (idx >= NQ) continue;
+        const int lrow = idx / G::NCOL2, qi = idx - lrow * G::NCOL2;
+        const int row = RPI * RPP + lrow;
+        const int tau = qi / G::D2, g = qi - tau * G::D2;
+        const int xo = 4 * G::D2 * (half * G::NTU2 + tau) + 4 * g;
+        const int n0 = o0 + xo;
+        if (xo >= G::OT || n0 >= len || (a.dbg & 4)) continue;   // (OT is a multiple of 4: a quad is stored whole or not at all)
+        f32x4 v = at_quad(yb, lrow, tau, g, ID2{});
+        const float bz = a.b2[row];
+        v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
+        const size_t ix = ob + (size_t)row * a.ld + n0;
+        if (n0 + 4 <= len) {
+          const f32x4 rs = pres[it];
+          v[0] += rs[0]; v[1] += rs[1]; v[2] += rs[2]; v[3] += rs[3];
           if (epi == EPI_RES) {
-            a.out[ix + e] = x;
+            *reinterpret_cast<f32x4*>(a.out + ix) = v;
           } else if (epi == EPI_MRF_SET) {
-            a.acc[ix + e] = x;
+            *reinterpret_cast<f32x4*>(a.acc + ix) = v;
           } else {
-            x = a.acc[ix + e] + x;
-            if (epi == EPI_MRF_DIV) x = __fdiv_rn(x, a.mrf_div);
-            a.acc[ix + e] = x;
+            const f32x4 ac = *reinterpret_cast<const f32x4*>(a.acc + ix);
+            v[0] = ac[0] + v[0]; v[1] = ac[1] + v[1]; v[2] = ac[2] + v[2]; v[3] = ac[3] + v[3];
+            if (epi == EPI_MRF_DIV) {
+              v[0] = __fdiv_rn(v[0], a.mrf_div); v[1] = __fdiv_rn(v[1], a.mrf_div);
+              v[2] = __fdiv_rn(v[2], a.mrf_div); v[3] = __fdiv_rn(v[3], a.mrf_div);
+            }
+            *reinterpret_cast<f32x4*>(a.acc + ix) = v;
+          }
+        } else {
+          for (int e = 0; e < len - n0; ++e) {
+            float x = v[e] + a.x[ix + e];
+            if (epi == EPI_RES) {
+              a.out[ix + e] = x;
+            } else if (epi == EPI_MRF_SET) {
+              a.acc[ix + e] = x;
+            } else {
+              x = a.acc[ix + e] + x;
+              if (epi == EPI_MRF_DIV) x = __fdiv_rn(x, a.mrf_div);
+              a.acc[ix + e] = x;
+            }
           }
         }
       }
     }
-  }
+  };
+  pass_d(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  pass_d(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  pass_d(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  pass_d(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -539,6 +574,18 @@ bool pairw_supported(int C, int KS, int dil) {
   if (C == 32) return KS == 7 || KS == 11;
   if (C == 64) return KS == 3;
   return false;
+}
+
+// ... and the ones the generator uses it for ("pair_wino" = 1): where it measured faster than what it replaces
+// (tools/pair_gate.py, B = 32 x 10 s, one MI355X: C = 32, k = 11: 895 / 988 us against 1 042 / 1 047 for the direct fused
+// pair at d = 1 / 3, break-even at d = 5 and slower with the MRF epilogue that pair always has; C = 64, k = 3, d = 1:
+// 624 against 658 for two conv_wino launches, break-even at d = 3 / 5; C = 32, k = 7: 884-963 against 732: never).
+// "pair_wino" = 2 takes every supported shape (tests).
+bool pairw_wanted(int C, int KS, int dil) {
+  if (!g_pair_wino || !pairw_supported(C, KS, dil)) return false;
+  if (g_pair_wino >= 2) return true;
+  if (C == 32) return KS == 11 && dil <= 3;
+  return C == 64 && KS == 3 && dil == 1;
 }
 
 // w: [C][C][KS] -> U[p][co][ci][j] = sum_i G[p][i] w[co][ci][j + NS i] in the order the kernel's lanes hold them:
@@ -588,18 +635,22 @@ void free_pairw(DevPairW& pw) {
   }
 }
 
-template <int C, int KS, int DIL>
+int g_pairw_chv = 2;  // "pairw_chv" option: column halves per workgroup of respair_wino_kernel (2: one 12-wave workgroup per CU;
+                      // 1: two 6-wave workgroups with half the tile each -- measured 5-30 % slower, kept for the tests)
+
+template <int C, int KS, int DIL, int CHV>
 static int launch_pairw_t(PairWArgs a, int B, int Lmax, hipStream_t stream) {
-  using G = PairWGeo<C, KS, DIL>;
+  using G = PairWGeo<C, KS, DIL, CHV>;
   static bool attr_done = false;
   if (!attr_done) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&respair_wino_kernel<C, KS, DIL>),
+    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&respair_wino_kernel<C, KS, DIL, CHV>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   a.gx = (Lmax + G::OT - 1) / G::OT;
   a.B = B;
-  hipLaunchKernelGGL((respair_wino_kernel<C, KS, DIL>), dim3(a.gx * B), dim3(768), (size_t)G::LDS_FLOATS * sizeof(float),
+  const int grid = a.gx * B;
+  hipLaunchKernelGGL((respair_wino_kernel<C, KS, DIL, CHV>), dim3(grid), dim3(G::NTH), (size_t)G::LDS_FLOATS * sizeof(float),
                      stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
@@ -616,9 +667,10 @@ int launch_respair_wino(const DevPairW& pw, const float* x, float* out, float* a
   PairWArgs a;
   a.x = x; a.out = out; a.acc = acc; a.w1 = pw.w1; a.w2 = pw.w2; a.b1 = pw.b1; a.b2 = pw.b2;
   a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul; a.ld = ld;
-  a.bstride = (long long)pw.C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.gx = 0; a.B = B;
-#define DISSC_PAIRW(C_, K_, D_) \
-  if (pw.C == C_ && pw.KS == K_ && pw.dil == D_) return launch_pairw_t<C_, K_, D_>(a, B, Lmax, stream);
+  a.bstride = (long long)pw.C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.gx = 0; a.B = B; a.dbg = g_wino_dbg;
+#define DISSC_PAIRW(C_, K_, D_)                                                                       \
+  if (pw.C == C_ && pw.KS == K_ && pw.dil == D_)                                                      \
+    return g_pairw_chv == 2 ? launch_pairw_t<C_, K_, D_, 2>(a, B, Lmax, stream) : launch_pairw_t<C_, K_, D_, 1>(a, B, Lmax, stream);
   DISSC_PAIRW(32, 7, 1) DISSC_PAIRW(32, 7, 3) DISSC_PAIRW(32, 7, 5)
   DISSC_PAIRW(32, 11, 1) DISSC_PAIRW(32, 11, 3) DISSC_PAIRW(32, 11, 5)
   DISSC_PAIRW(64, 3, 1) DISSC_PAIRW(64, 3, 3) DISSC_PAIRW(64, 3, 5)

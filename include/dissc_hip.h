@@ -143,9 +143,11 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   cpb2 (0)             k <= value convs stage 32 channels per barrier
  *   pair_max_c (32)      widest fp32 stage whose residual pairs (conv_d -> conv_1 -> +x) run as ONE launch each
  *                        (respair.hip; 0 = every conv its own launch; results are bit-identical either way)
- *   pair_wino (1)        read at dissc_gen_create: residual pairs with C = 32, k = 7 / 11 and C = 64, k = 3 run as ONE launch with
- *                        both convs in the Toom-Cook transform domain and the intermediate in LDS (respair_wino.hip); 0 = the
- *                        direct fused pair (C = 32) / two transform-domain launches (C = 64)
+ *   pair_wino (1)        read at dissc_gen_create: 1 = the residual pairs this measured faster for (C = 32, k = 11, d = 1 / 3;
+ *                        the first pair of the C = 64, k = 3 chain) run as ONE launch with both convs in the Toom-Cook
+ *                        transform domain and the intermediate in LDS (respair_wino.hip); 2 = every shape with an instance
+ *                        (C = 32: k = 7 / 11; C = 64: k = 3, first pair of a chain); 0 = none
+ *   pairw_chv (2)        respair_wino.hip: 2 = one 12-wave workgroup per CU, 1 = two 6-wave workgroups with half the tile
  *   bf3_pairs (-1)       split-bf16 fused ResBlocks as three launches of one residual pair each: -1 = for >= 64
  *                        channels only, 0 = never, 1 = always
  *   fused_variant (0)    split-bf16 fused ResBlocks: 0 = 512-column windows, 1 = 1024

@@ -419,13 +419,16 @@ def test_fused_residual_pairs_are_bit_identical_to_separate_launches(env):
 
 
 def test_transform_domain_pairs_agree_with_the_unfused_generator(env):
-    """respair_wino.hip (default: the k = 7 / 11 pairs of the 32-channel stage and the k = 3 pairs of the 64-channel stage
-    as ONE transform-domain launch each) against an instance built with "pair_wino" = 0: same waveform to fp32 rounding,
-    ragged and at the BASELINE size; and fewer executed FLOPs are reported for it."""
-    lib, g, synth = env["lib"], env["g"], env["synth"]
+    """respair_wino.hip (default: the k = 11, d = 1 / 3 pairs of the 32-channel stage and the first k = 3 pair of the
+    64-channel stage as ONE transform-domain launch each; "pair_wino" = 2: every shape with an instance) against an
+    instance built with "pair_wino" = 0: same waveform to fp32 rounding, ragged and at the BASELINE size; fewer executed
+    FLOPs are reported for them."""
+    lib, synth = env["lib"], env["synth"]
     gd = _generator_with(lib, synth, pair_wino=0)
-    assert g.flops_executed(1000) < gd.flops_executed(1000) and g.flops(1000) == gd.flops(1000)
-    for code, f0, spkr, lengths in _pair_cases(synth):
+    ga = _generator_with(lib, synth, pair_wino=2)   # every shape that has an instance
+    assert env["g"].flops_executed(1000) < gd.flops_executed(1000) and env["g"].flops(1000) == gd.flops(1000)
+    assert ga.flops_executed(1000) < env["g"].flops_executed(1000)
+    for g, (code, f0, spkr, lengths) in [(g_, c) for g_ in (env["g"], ga) for c in _pair_cases(synth)]:
         kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
                   lengths=torch.from_numpy(lengths))
         yw, yd = g(**kw).cpu(), gd(**kw).cpu()

@@ -16,10 +16,12 @@ for C, L, shapes in ((32, 80000, [(7, 1), (7, 3), (7, 5), (11, 1), (11, 3), (11,
     for k, d in shapes:
         for epi in (1, 3):
             row = []
-            for mode in ((1, 3) if C == 32 else (2, 3)):
+            for mode, chv in (((1, 1), (3, 2), (3, 1)) if C == 32 else ((2, 1), (3, 2), (3, 1))):
+                assert lib.dissc_set_option(b"pairw_chv", chv) == 0
                 check(lib.dissc_pair_bench(32, C, k, d, L, epi, iters, mode, ctypes.byref(ms)), f"pair_bench mode {mode}")
                 ns = (k + 2) // 3
                 gf_alg = 2 * 2.0 * C * C * k * L * 32 / 1e9
                 gf_exec = gf_alg if mode in (0, 1) else 2 * 2.0 * C * C * 6 * ns / 4 * L * 32 / 1e9
-                row.append(f"{NAMES[mode]}: {ms.value * 1e3:7.1f} us ({gf_exec / ms.value:6.1f} TF executed, {gf_alg / ms.value:6.1f} algorithmic)")
+                tag = NAMES[mode] + (f" chv={chv}" if mode == 3 else "")
+                row.append(f"{tag}: {ms.value * 1e3:7.1f} us ({gf_exec / ms.value:5.1f} TF exec)")
             print(f"C={C} k={k} d={d} epi={epi}:  " + "   ".join(row), flush=True)
