@@ -33,8 +33,11 @@
 
 namespace dissc {
 
-int g_pair_wino = 1;  // "pair_wino" option (read at dissc_gen_create): 1 = the shapes pairw_wanted() names run as fused
-                      // transform-domain pairs, 2 = every shape with an instance, 0 = none (respair32 direct / two conv_wino launches)
+int g_pair_wino = 0;  // "pair_wino" option (read at dissc_gen_create): 0 (default) = not used (respair32 direct / two conv_wino
+                      // launches); 1 = the shapes pairw_wanted() names run as fused transform-domain pairs, 2 = every shape
+                      // with an instance.  Off by default: the gate experiment failed (below) -- per launch the winning
+                      // shapes are 6-15 % faster, in the whole forward (three chains overlapping on their streams) that
+                      // is 35.36 against 35.42 ms, while the executed-FLOP utilisation falls from 0.619 to 0.602.
 
 struct PairWArgs {
   const float* x;     // [B][C][ld] pair input x_k
@@ -576,11 +579,14 @@ bool pairw_supported(int C, int KS, int dil) {
   return false;
 }
 
-// ... and the ones the generator uses it for ("pair_wino" = 1): where it measured faster than what it replaces
+// ... and the ones the generator uses it for with "pair_wino" = 1: where it measured faster than what it replaces
 // (tools/pair_gate.py, B = 32 x 10 s, one MI355X: C = 32, k = 11: 895 / 988 us against 1 042 / 1 047 for the direct fused
 // pair at d = 1 / 3, break-even at d = 5 and slower with the MRF epilogue that pair always has; C = 64, k = 3, d = 1:
 // 624 against 658 for two conv_wino launches, break-even at d = 3 / 5; C = 32, k = 7: 884-963 against 732: never).
-// "pair_wino" = 2 takes every supported shape (tests).
+// The verdict's gates (C = 32, k = 11, d = 1 pair <= 720 us where the direct pair takes 921; C = 64, k = 3 pair <= 520 us)
+// were NOT met: knock-outs (tools/pair_ko.py) put a k = 11 tile at MFMAs 476 + input transforms 100 + the two A^T
+// exchanges 125 + skeleton (staging, barriers, weight loads, launch) 197 us, nothing overlapping -- one workgroup fills
+// the CU and fp32 VALU work shares the MFMA datapath.  "pair_wino" = 2 takes every supported shape (tests).
 bool pairw_wanted(int C, int KS, int dil) {
   if (!g_pair_wino || !pairw_supported(C, KS, dil)) return false;
   if (g_pair_wino >= 2) return true;

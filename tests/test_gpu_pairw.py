@@ -89,12 +89,13 @@ def test_fused_transform_domain_pair_matches_float64_and_the_other_paths(lib, ch
     for i in (3, 6):
         one = _pair(lib, 3, x[i:i + 1].clone(), w1, b1, w2, b2, lengths[i:i + 1], k, d)
         assert torch.equal(one[0, :, :lengths[i]], y3[i, :, :lengths[i]])
-    # the two-launch transform-domain path (the product path of the 64-channel stage with "pair_wino" = 0) does the
-    # same arithmetic in the same order: identical bits
+    # the two-launch transform-domain path (the product path of the 64-channel stage) does the same arithmetic in the
+    # same order -- except that a tile's last F(4,3) groups see zeros where the two-launch path sees the neighbouring
+    # tile's t (contributions that cancel exactly only in exact arithmetic): equal to rounding, not bit for bit
     if C == 64:
         y2 = _pair(lib, 2, x, w1, b1, w2, b2, lengths, k, d)
         for i, n in enumerate(lengths):
-            assert torch.equal(y2[i, :, :n], y3[i, :, :n]), f"utterance {i} differs from the two-launch transform path"
+            assert (y2[i, :, :n] - y3[i, :, :n]).abs().max().item() <= 2e-6 if n else True
 
 
 @pytest.mark.parametrize("C,k,d", [(32, 11, 3), (64, 3, 1), (32, 7, 5)])
