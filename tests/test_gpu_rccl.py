@@ -135,3 +135,21 @@ def test_bench_two_ranks_sharing_this_gpu():
     assert 1.0 <= st["load_imbalance"] < 1.01 and st["value"] > 200
     # each rank sends its half of the waveforms (plus table and 16-byte row padding), not a dense matrix
     assert st["exchange"]["sent_bytes_per_rank"] <= 0.55 * 4 * 16000 * st["audio_sec"]
+
+
+def test_to_host_double_buffered_path_on_a_non_current_device():
+    """harness._to_host above 32 MB works through two page-locked halves with events: copies and events must go to the
+    TENSOR's device's stream also when another device is current.  Needs two GPUs; on the one-GPU box the
+    same path is checked on the current device."""
+    from dissc_amd import harness
+    n = (40 << 20) // 4 + 12345  # > 32 MB: the double-buffered branch
+    dev = torch.device("cuda", 1) if torch.cuda.device_count() > 1 else torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    want = torch.rand(n, generator=g)
+    t = want.to(dev)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.device(0):  # device 0 current, tensor possibly on device 1
+        # some work on the tensor's stream right before, so that an unordered read would see stale staging halves
+        t.mul_(2.0).mul_(0.5)
+        got = harness._to_host(t)
+    assert got.shape == (n,) and np.array_equal(got, want.numpy())
