@@ -508,13 +508,18 @@ class Exchange:
                 self._pending.pop(0)[0].wait()
         self.k += 1
 
-    def finish(self):
-        """Wait for every round to be delivered (and for every collective this rank took part in).  Returns the number
-        of waveforms delivered to the sink, or the result dict when there is no sink."""
+    def close(self):
+        """Stop the delivery thread (idempotent; rounds already queued are still delivered first).  Callers put this in
+        a ``finally`` so that a run that fails half-way does not leave a thread behind."""
         if self._thread is not None:
             self._q.put(None)
             self._thread.join()
             self._thread = None
+
+    def finish(self):
+        """Wait for every round to be delivered (and for every collective this rank took part in).  Returns the number
+        of waveforms delivered to the sink, or the result dict when there is no sink."""
+        self.close()
         for w, _, _ in self._pending:
             if w is not None:
                 w.wait()
@@ -696,9 +701,20 @@ def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist
     if ex.overlap:
         budget = overlap_budget(lengths, parts, budget)
     rounds = plan_rounds(lengths, parts, budget)
+    t_run = time.perf_counter()
+    try:
+        return _run_rounds(generator, jobs, rank, dev, cuda, ex, rounds, lengths, parts, hop, max_batch, max_frames,
+                           postprocess, stats, t_run)
+    finally:
+        ex.close()
+
+
+def _run_rounds(generator, jobs, rank, dev, cuda, ex, rounds, lengths, parts, hop, max_batch, max_frames, postprocess,
+                stats, t_run):
+    """the round loop of run_resynthesis (its own function so that the caller can close the Exchange in a finally)"""
+    import time
     t_host = 0.0
     events = []
-    t_run = time.perf_counter()
     for shares in rounds:
         t0 = time.perf_counter()
         store = WaveStore(dev)

@@ -204,11 +204,14 @@ class Converter:
             b = harness.overlap_budget([n // 320 for n in n_samples], parts, None)
             if b is not None:
                 budget = b * 320 if budget is None else min(budget, b * 320)
-        for shares in harness.plan_rounds(n_samples, parts, budget):
-            store = harness.WaveStore(self.generator.device)
-            self._run_local(shares[rank], n_samples, load, target_ids, store, f0_stats)
-            n_cap = max(len(p) for p in shares) * len(target_ids)
-            _, data_cap = harness.agree_geometry(store.n, store.data_floats, world_size, self.generator.device, dist)
-            ex.submit(store, n_cap, data_cap)
-            store.clear()
-        return ex.finish()
+        try:
+            for shares in harness.plan_rounds(n_samples, parts, budget):
+                store = harness.WaveStore(self.generator.device)
+                self._run_local(shares[rank], n_samples, load, target_ids, store, f0_stats)
+                n_cap = max(len(p) for p in shares) * len(target_ids)
+                _, data_cap = harness.agree_geometry(store.n, store.data_floats, world_size, self.generator.device, dist)
+                ex.submit(store, n_cap, data_cap)
+                store.clear()
+            return ex.finish()
+        finally:
+            ex.close()  # (idempotent: a run that fails half-way must not leave the delivery thread behind)
