@@ -10,8 +10,12 @@ exchanged with a single ``all_gather_into_tensor`` of a packed RAGGED fp32 buffe
 
 A run is ONE round -- one all-gather -- unless a rank's share exceeds ``round_floats`` (default 2^28
 floats = 1 GiB = 4.6 hours of 16 kHz audio per rank): then every rank cuts its share into the same number
-of rounds, and each round is packed, gathered, handed to ``sink`` (rank 0 writes the files) and FREED before
-the next one starts, so the resident footprint is bounded by the round and a failure loses one round at most.
+of rounds, and each round is packed, gathered, handed to ``sink`` and FREED before the next one starts, so the
+resident footprint is bounded by the round and a failure loses one round at most.  With a ``sink`` on a GPU a
+run is cut into up to 4 rounds anyway and ``Exchange`` delivers round k (wait for the gather, device-to-host
+copy on a copy stream, unpack, sink) on a worker thread while round k + 1 computes: the serial tail of a run at
+N ranks is the delivery of its last round only.  Who delivers: rank 0 everything, or (``own_rows``) every rank
+the rows it decoded itself.
 
 Everything here is host logic; it runs on CPU tensors with the gloo backend in the tests (there the
 rows are packed with torch copies) and on CUDA tensors over RCCL/xGMI in production.  A non-None ``dist``

@@ -10,8 +10,11 @@ Same command line, inputs and outputs as the reference's sr/inference.py
 Execution differs: instead of ``Pool(8)`` B=1 workers, launch one process per GPU
 (``python -m torch.distributed.run --nproc-per-node N sr/inference.py ...``; a plain
 ``python sr/inference.py`` is the 1-GPU case).  Jobs are LPT-sharded over ranks, batched through
-the HIP generator, post-processed on the GPU, and returned to rank 0 with a single RCCL
-all-gather; rank 0 writes the files.  The ground-truth mel the reference computes and throws
+the HIP generator, post-processed on the GPU and exchanged with ONE RCCL all-gather per round (a run
+is 1-4 rounds; a round is delivered -- device-to-host copy, file writes -- by a worker thread while the
+next one computes).  Like the reference's pool workers every rank writes the files of the jobs it
+decoded (DISSC_WRITERS=all, the default for N > 1; DISSC_WRITERS=rank0: rank 0 receives and writes
+everything).  The ground-truth mel the reference computes and throws
 away (sr/dataset.py:269-271) is not computed.
 """
 import argparse
