@@ -99,6 +99,7 @@ struct ConvArgs {
   float mrf_div;
   float out_slope;      // EPI_STORE_ACT: leaky-ReLU slope applied to the stored value
   int dma_in;           // 1: x has the EPI_STORE_ACT layout (activated, zero tails) -> LDS-DMA staging, slope must be 1
+  int ragged_enum;      // set by the launcher: ragged batch, (time tile, utterance) pairs re-dealt so that only existing tiles are enumerated
   int epi;
   int up;               // 1 = conv; s = ConvTranspose stride
   int up_np, up_p0;     // ConvTranspose phase group: row = co*up_np + pi, phase = up_p0 + pi
@@ -142,6 +143,7 @@ extern int g_precision;   // "precision" option: 0 = fp32 (default); 1 = split-b
 extern thread_local int g_conv_prec;   // precision make_conv packs for: g_precision inside dissc_gen_create, else 0
                           // (predictors and HuBERT feed integer decisions and always stay fp32)
 extern int g_use_mfma32;  // tuning: 0 forces the 16x16x4 kernel everywhere
+extern int g_ragged_enum; // "ragged_enum" option: conv_mfma32_kernel enumerates only the tiles that exist on ragged batches
 
 // Host-side weight packing.  w: [Cout][Cin][KS] (Conv1d layout).  Returns the packed
 // buffer (Mpad/16 * nchunk * KS * 64 float4) and Mpad (M rounded up to 16).

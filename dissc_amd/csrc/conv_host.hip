@@ -7,6 +7,7 @@
 namespace dissc {
 
 int g_use_mfma32 = 1;
+int g_ragged_enum = 1;  // "ragged_enum" option (conv_mfma32.hip)
 int g_pos48 = 1;
 int g_precision = 0;
 thread_local int g_conv_prec = 0;  // (per thread: handles may be built concurrently) what make_conv packs for; dissc_gen_create raises it to g_precision for its own layers
@@ -130,6 +131,7 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
   a.CIN = dc.CIN; a.M = dc.M; a.KS = dc.KS; a.dil = dc.dil; a.nchunk = dc.nchunk;
   a.pad_left = dc.pad_left >= 0 ? dc.pad_left : ((dc.KS - 1) * dc.dil) / 2;
   a.mfast = 0;
+  a.ragged_enum = 0;
   a.groups = dc.groups; a.nsub_group = dc.Mpad / (dc.m32 ? 32 : 16); a.act = dc.act; a.m32 = dc.m32; a.prec = dc.prec;
   a.cfg32 = -1;
   const int span = (dc.KS - 1) * dc.dil;

@@ -35,11 +35,47 @@ __global__ void __launch_bounds__(64 * WM * WN, DMA ? DISSC_LB32_DMA : DISSC_LB3
   constexpr int SV = (KCB * (XW_MAX / 4) + NT - 1) / NT;  // float4 staging slots per thread
   extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x [KCB][XW] | NW x [8][32*NI+4] (epilogue)
 
-  const int b = blockIdx.z;
+  int b = blockIdx.z;
+  int bx = a.mfast ? blockIdx.y : blockIdx.x;  // time tile
+  const int by = a.mfast ? blockIdx.x : blockIdx.y;  // (group, M tile)
+  if (a.ragged_enum) {
+    // Ragged batch: (time tile, utterance) pairs are re-dealt so that only the tiles that EXIST are enumerated --
+    // utterance 0's ceil(olen_0 / BN) tiles, then utterance 1's, ... -- and the workgroups left over all sit at the END of
+    // the dispatch order (z slowest) and return at once, instead of lying between the real ones (conv_wino.hip has the
+    // measurements).  Every wave finds its pair by a prefix sum of the tile counts over its lanes.  Not for
+    // EPI_STORE_ACT, whose tiles beyond an utterance's end still have zero tails to write.
+    const int ntile = a.mfast ? gridDim.y : gridDim.x;
+    const int lin = b * ntile + bx;
+    const int lane_ = threadIdx.x & 63;
+    const int nb = gridDim.z;
+    int base = 0;
+    b = -1;
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+      int l = 0;
+      if (b0 + lane_ < nb)
+        l = a.lengths_out ? a.lengths_out[b0 + lane_]
+                          : (a.olen_default >= 0 ? a.olen_default : (a.lengths ? a.lengths[b0 + lane_] * a.len_mul : a.len_default));
+      const int nt = (l + BN - 1) / BN;
+      int incl = nt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane_ >= o) incl += v;
+      }
+      const int total = __shfl(incl, 63, 64);
+      if (lin < base + total) {
+        const unsigned long long m = __ballot(base + incl > lin);
+        const int lb = __ffsll((long long)m) - 1;
+        b = __builtin_amdgcn_readfirstlane(b0 + lb);
+        bx = __builtin_amdgcn_readfirstlane(lin - base - __shfl(incl - nt, lb, 64));
+        break;
+      }
+      base += total;
+    }
+    if (b < 0) return;
+  }
   const int len = (a.lengths ? a.lengths[b] * a.len_mul : a.len_default);  // valid INPUT positions
   const int olen = a.lengths_out ? a.lengths_out[b] : (a.olen_default >= 0 ? a.olen_default : len);
-  const int bx = a.mfast ? blockIdx.y : blockIdx.x;  // time tile
-  const int by = a.mfast ? blockIdx.x : blockIdx.y;  // (group, M tile)
   const int t0 = bx * BN;
   if (t0 >= olen) {
     if (a.epi == EPI_STORE_ACT && by == 0) zero_tail_tile<NT, BN>(a, b, t0, olen);
@@ -360,6 +396,7 @@ static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   // XCD receives (id % 8) share a few M tiles and their weight slices stay L2-resident.
   a.mfast = (a.mt_per_group * a.groups >= 3 && g_mfast) ? 1 : 0;
   if (a.mfast) grid = dim3(grid.y, grid.x, grid.z);
+  a.ragged_enum = (g_ragged_enum && (a.lengths || a.lengths_out) && a.epi != EPI_STORE_ACT && B > 1) ? 1 : 0;
   size_t lds_f = (size_t)2 * KC * CPB * a.XW;
   if (lds_f < (size_t)NW * 8 * CW) lds_f = (size_t)NW * 8 * CW;
   const size_t lds = lds_f * sizeof(float) + (size_t)g_conv_pad_lds;  // (+ diagnostics: occupancy experiments)

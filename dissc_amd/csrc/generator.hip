@@ -842,6 +842,7 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "lin_tile") == 0) { g_lin_tile = value; return DISSC_OK; }
   if (strcmp(key, "cpb2") == 0) { g_cpb2 = value; return DISSC_OK; }
   if (strcmp(key, "mfast") == 0) { g_mfast = value; return DISSC_OK; }
+  if (strcmp(key, "ragged_enum") == 0) { g_ragged_enum = value; return DISSC_OK; }
   if (strcmp(key, "lin_dma") == 0) { g_lin_dma = value; return DISSC_OK; }
   if (strcmp(key, "pos48") == 0) { g_pos48 = value; return DISSC_OK; }
   if (strcmp(key, "pair_dma") == 0) { g_pair_dma = value; return DISSC_OK; }

@@ -143,6 +143,8 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   cpb2 (0)             k <= value convs stage 32 channels per barrier
  *   pair_max_c (32)      widest fp32 stage whose residual pairs (conv_d -> conv_1 -> +x) run as ONE launch each
  *                        (respair.hip; 0 = every conv its own launch; results are bit-identical either way)
+ *   ragged_enum (1)      conv_mfma32_kernel on a ragged batch enumerates only the (time tile, utterance) pairs that exist (the
+ *                        empty workgroups all sit at the end of the dispatch order); 0 = tile x utterance grid with early exits
  *   pair_wino (0)        read at dissc_gen_create: 0 = off (default: the whole-forward gain is 0.2 %); 1 = the residual pairs this measured faster for (C = 32, k = 11, d = 1 / 3;
  *                        the first pair of the C = 64, k = 3 chain) run as ONE launch with both convs in the Toom-Cook
  *                        transform domain and the intermediate in LDS (respair_wino.hip); 2 = every shape with an instance
