@@ -273,6 +273,16 @@ def test_sr_inference_256_utterances_two_ranks(models, golden_dir, tmp_path):
     assert len(files) == 512 and sorted(os.listdir(f"{td}/o2")) == files
     for fn in files:
         assert open(f"{td}/o1/{fn}", "rb").read() == open(f"{td}/o2/{fn}", "rb").read(), fn
+    # (o2: every rank wrote the files of the jobs it decoded, the N > 1 default.)  One writer instead -- rank 0 receives
+    # every waveform of every round -- must produce the same bytes
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "sr", "inference.py")] + args + ["--output_dir", f"{td}/o3"],
+                       env=dict(env, DISSC_WRITERS="rank0"), capture_output=True, text=True, timeout=900, cwd=td)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert sorted(os.listdir(f"{td}/o3")) == files
+    for fn in files:
+        assert open(f"{td}/o1/{fn}", "rb").read() == open(f"{td}/o3/{fn}", "rb").read(), fn
 
 
 def _run(cmd, env, cwd, timeout=1500):
