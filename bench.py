@@ -445,7 +445,7 @@ def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_se
 
 
 GEN_KERNEL_SOURCES = ("common.h", "conv_epilogue32.h", "conv_host.hip", "conv_mfma.hip", "conv_mfma32.hip", "conv_wino.hip",
-                      "gen_misc.hip", "generator.hip", "respair.hip", "respair_wino.hip", "wino_common.h")
+                      "conv_wino8.hip", "gen_misc.hip", "generator.hip", "respair.hip", "respair_wino.hip", "wino_common.h")
 
 
 def kernel_source_hash():

@@ -168,7 +168,7 @@ struct DevConv {
   int m32 = 0;              // packed for the 32x32x2 kernel
   int prec = 0;             // 1: packed as split-bf16 hi/lo fragments
   double macs_per_t = 0;  // MACs per input time step (algorithmic, zero taps excluded)
-  int wino = 0;           // packed for conv_wino_kernel (Toom-Cook F(4,3) transform-domain weights)
+  int wino = 0;           // 1: packed for conv_wino_kernel (Toom-Cook F(4,3) transform-domain weights), 2: for conv_wino8_kernel (F(6,3))
 };
 // Per-call extras of run_conv_ex (strided / valid convolutions with their own output lengths).
 struct ConvIO {
@@ -210,6 +210,19 @@ double wino_executed_macs_per_t(int C, int KS);
 int run_wino(const DevConv& dc, const float* x, float* out, const float* res, float* acc, const int32_t* lengths,
              int len_default, int len_mul, int B, int ldx, int ldo, int Lmax, float slope, int epi, float mrf_div,
              hipStream_t stream);
+
+// Toom-Cook F(6,3) form on 8-wave workgroups (conv_wino8.hip): the k = 7 / 11 ResBlock convs of the C >= 64 stages
+extern int g_wino8;      // "wino8" option (read at dissc_gen_create)
+extern int g_wino8_dbg;
+extern int g_wino8_c64_wide;
+extern int g_wino8_mask;
+bool wino8_supported(int Cout, int Cin, int KS, int dil);
+bool wino8_wanted(int C, int KS);
+int make_wino8(const float* w, const float* bias, int C, int KS, int dil, DevConv& dc);  // sets dc.wino = 2
+double wino8_executed_macs_per_t(int C, int KS);
+int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, float* acc, const int32_t* lengths,
+              int len_default, int len_mul, int B, int ldx, int ldo, int Lmax, float slope, int epi, float mrf_div,
+              hipStream_t stream);
 
 // one residual pair per launch with BOTH convs in the Toom-Cook transform domain, t kept in LDS (respair_wino.hip)
 struct DevPairW {

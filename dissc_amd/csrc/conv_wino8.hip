@@ -1,0 +1,601 @@
+// conv_wino8_kernel: the k = 7 / 11 ResBlock convs of the wide stages (C -> C channels, dilation 1 / 3 / 5; reference
+// sr/models.py:16-41) in the Toom-Cook F(6,3) transform domain: 6 outputs of a 3-tap filter from 8 products (evaluation
+// points 0, +-1, +-2, +-1/2, inf) instead of F(4,3)'s 4 from 6 (conv_wino.hip) -- 8 ceil(k / 3) / 6 MFMA products per
+// output, 11 % fewer -- still fp32 operands, fp32 products, fp32 accumulation on v_mfma_f32_32x32x2_f32.
+//
+// Why a second transform-domain kernel: EIGHT points map onto EIGHT waves, two per SIMD, and the tap loop of a
+// 2-waves-per-SIMD workgroup sustains 138-145 TFLOP/s where conv_wino's 12 waves (three per SIMD) reach 122-126 with
+// the same operand traffic (tools/ubench/mfma_mix8.hip: the global-load return path of the A fragments interacts with
+// the MFMA issue of three waves, NOTES.md round 3 #14) -- and two waves per SIMD may hold a 128 x 64 accumulator tile.
+//
+//   y[n] = sum_i w[i] xa[n - pad + i d],  xa = lrelu(x) inside the utterance, 0 outside.
+// The k taps are split into NS = ceil(k / 3) sub-filters of 3 taps with tap stride NS, D = d NS (conv_wino.hip); per point
+//       Y_p[co][tau][rho] = sum_j sum_ci U_pj[co][ci] V_p[ci][tau][rho + d j],       rho in [0, D), j in [0, NS)
+//       V_p[ci][tau][w]   = sum_q B^T[p][q] xa[ci][o + 6 D tau + w + D q],            w in [0, d (2 NS - 1)), q in [0, 8)
+//       y[co][t0 + 6 D tau + rho + D a] = sum_p A^T[a][p] Y_p[co][tau][rho] + bias,   a in [0, 6)
+// One workgroup = 8 waves = 8 points, every wave on the whole (32 MI rows) x (32 NI columns) tile of its point; the
+// activated input window of 16 channels is staged like conv_wino's (registers -> lrelu / zero padding -> LDS in the
+// polyphase layout [channel][x mod D][x div D], double-buffered, loads two rounds ahead); each wave forms V_p of 8
+// channels for its point (8 neighbouring samples = four aligned 8-byte reads) into a private tile; A fragments streamed
+// from L2 one tap ahead; epilogue: the 8 waves exchange Y_p through LDS 32 rows at a time, one thread applies A^T, bias
+// and the residual / MRF mode to 4 consecutive outputs.
+// Rounding: per layer 1.8x the F(4,3) form's error (numpy model of a C = 256 layer, k = 11: rms 1.5e-7 vs 8.3e-8 on O(0.3)
+// outputs, direct 9.3e-8); DESIGN.md section 4.
+#include <string.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "conv_epilogue32.h"
+
+namespace dissc {
+
+int g_wino8 = 0;      // "wino8" option (read at dissc_gen_create): 0 (default) = not used; 1 = the k = 7 / 11 ResBlock convs the
+                      // "wino8_mask" names use this kernel instead of conv_wino's F(4,3) form; 2 = the stand-alone dissc_conv1d
+                      // entry uses it too (tests).  Off by default: per launch it is 3-17 % faster than the F(4,3) form on 26 of
+                      // the 36 (C, k, d, epilogue) shapes of the generator (tools/wino8_gate.py) and 4-9 % slower on the d = 1 shapes
+                      // of the 128-channel stage (864 workgroups = 3.4 rounds of 256 CUs where the F(4,3) tiles make exactly 5.0),
+                      // but in the whole forward -- three chains overlapping on their streams -- the best mask (0x31: C >= 256 both
+                      // kernel sizes, C = 64 k = 7) is worth 35.25 against 35.51 ms (serial launches: 36.96 against 37.49), while the
+                      // executed-FLOP utilisation falls from 0.618 to 0.603 (11 % fewer products on those layers).
+int g_wino8_dbg = 0;  // diagnostics: knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue
+int g_wino8_c64_wide = 1;  // "wino8_c64_wide" option: C = 64 instances on 64 x 128 tiles (768 outputs) instead of 64 x 64
+
+struct Wino8Args {
+  const float* x;
+  const float* wpack;   // [8 points][C / 32][nchunk][2 halves][NS taps][64 lanes][4 k-steps] (make_wino8)
+  const float* bias;    // [C]
+  const float* res;
+  float* out;
+  float* acc;
+  const int32_t* lengths;
+  int len_default, len_mul;
+  int C, nchunk, pad;
+  int ldx, ldo;
+  long long x_bstride, o_bstride;
+  float slope, mrf_div;
+  int epi;
+  int dbg;
+  int gx, gy, B;  // time tiles, row tiles, utterances
+};
+
+// G rows of F(6,3) at the points 0, 1, -1, 2, -2, 1/2, -1/2, inf (host, double); B^T and A^T are written out below
+static const double kW8G[8][3] = {{-1.0, 0.0, 0.0},
+                                  {-2.0 / 9.0, -2.0 / 9.0, -2.0 / 9.0},
+                                  {-2.0 / 9.0, 2.0 / 9.0, -2.0 / 9.0},
+                                  {1.0 / 90.0, 1.0 / 45.0, 2.0 / 45.0},
+                                  {1.0 / 90.0, -1.0 / 45.0, 2.0 / 45.0},
+                                  {32.0 / 45.0, 16.0 / 45.0, 8.0 / 45.0},
+                                  {32.0 / 45.0, -16.0 / 45.0, 8.0 / 45.0},
+                                  {0.0, 0.0, 1.0}};
+
+// row P of B^T (all entries exactly representable) applied to eight neighbouring samples
+template <int P>
+__device__ __forceinline__ float w8_bt(float r0, float r1, float r2, float r3, float r4, float r5, float r6, float r7) {
+  if constexpr (P == 0) return fmaf(5.25f, r2 - r4, r6 - r0);
+  if constexpr (P == 1) return fmaf(-4.25f, r3 + r4, (r1 + r2) + (r5 + r6));
+  if constexpr (P == 2) return fmaf(4.25f, r3 - r4, (r2 - r1) + (r6 - r5));
+  if constexpr (P == 3) return fmaf(0.5f, r1, fmaf(0.25f, r2, fmaf(-2.5f, r3, fmaf(-1.25f, r4, fmaf(2.f, r5, r6)))));
+  if constexpr (P == 4) return fmaf(-0.5f, r1, fmaf(0.25f, r2, fmaf(2.5f, r3, fmaf(-1.25f, r4, fmaf(-2.f, r5, r6)))));
+  if constexpr (P == 5) return fmaf(2.f, r1, fmaf(4.f, r2, fmaf(-2.5f, r3, fmaf(-5.f, r4, fmaf(0.5f, r5, r6)))));
+  if constexpr (P == 6) return fmaf(-2.f, r1, fmaf(4.f, r2, fmaf(2.5f, r3, fmaf(-5.f, r4, fmaf(-0.5f, r5, r6)))));
+  if constexpr (P == 7) return fmaf(5.25f, r3 - r5, r7 - r1);
+  return 0.f;
+}
+
+constexpr int w8_rup(int n, int m) { return (n + m - 1) / m * m; }
+
+// polyphase row length >= need (even): lane = tau * D + phi of the transform reads 8 bytes at float offset phi * RL + 6 tau
+// (+ 2 q); a ds_read_b64 is serviced 32 lanes at a time over 64 banks of 4 bytes -- pick the RL (<= need + 62) whose worst
+// 32-lane group touches the fewest lanes per bank pair
+constexpr int w8_row_len(int D, int NTU, int need) {
+  int best = need, best_cost = 1 << 30;
+  for (int rl = need; rl <= need + 62; rl += 2) {
+    int cost = 0;
+    for (int g0 = 0; g0 < 64; g0 += 32) {
+      int cnt[32] = {0};
+      for (int l = g0; l < g0 + 32; ++l) {
+        const int c = l < NTU * D ? l : NTU * D - 1;
+        const int slot = (((c % D) * rl + 6 * (c / D)) / 2) % 32;
+        ++cnt[slot];
+      }
+      for (int i = 0; i < 32; ++i)
+        if (cnt[i] > cost) cost = cnt[i];
+    }
+    if (cost < best_cost) { best_cost = cost; best = rl; }
+    if (cost <= 1) break;
+  }
+  return best;
+}
+
+template <int NS, int DIL, int MI, int NI>
+struct Wino8Geo {
+  static constexpr int NTH = 512;
+  static constexpr int D = DIL * NS, W = DIL * (2 * NS - 1);
+  static constexpr int NCW = 32 * NI;
+  static constexpr int NTU0 = NCW / D;
+  static constexpr int NTU = (D % 2 == 1 && NTU0 % 2 == 1) ? NTU0 - 1 : NTU0;  // (an odd D takes an even unit count: OT % 4 == 0)
+  static constexpr int NCOL = NTU * D;
+  static constexpr int OT = 6 * D * NTU;               // outputs per workgroup tile
+  static constexpr int RAW = OT + D + W;                // input samples the transforms touch
+  static constexpr int XRW = w8_rup(RAW + 3 + 3, 4);    // staged positions per channel (alignment shift <= 3)
+  static constexpr int NV = XRW / 4;
+  static constexpr int OFF = 2;                         // polyphase index offset: window sample x at [(x + OFF D) % D][(x + OFF D) / D]
+  static constexpr int RL_MIN = w8_rup(((XRW - 1 + OFF * D) / D + 1) > (6 * NTU + OFF + 10) ? ((XRW - 1 + OFF * D) / D + 1) : (6 * NTU + OFF + 10), 2);
+  static constexpr int RL = w8_row_len(D, NTU, RL_MIN);  // bumped so that the 8-byte transform reads of a half wave spread over the banks
+  static constexpr int CHF = D * RL;
+  static constexpr int CPR = NI == 4 ? 8 : 16;         // channels of the window per round (LDS budget of the 128-column tile)
+  static constexpr int RPP = NI == 4 ? 16 : 32;        // rows per epilogue pass (likewise)
+  static constexpr int CG = NCW / 64 > 0 ? NCW / 64 : 1;  // 64-column groups a lane transforms
+  static constexpr int XV = NTU * W <= 112 ? 112 : 240; // V row stride (% 32 == 16: the two k halves of a fragment read hit different banks)
+  static constexpr int YS = NCW + 4;
+  static constexpr int WIN_FLOATS = 2 * CPR * CHF;
+  static constexpr int V_FLOATS = 8 * 8 * XV;
+  static constexpr int Y_FLOATS = 8 * RPP * YS;
+  static constexpr int OS = OT + 4;                     // row stride of the epilogue's output tile (16-byte aligned rows)
+  static constexpr int EPI_FLOATS = Y_FLOATS + RPP * OS;
+  static constexpr int LDS_FLOATS = (WIN_FLOATS + V_FLOATS) > EPI_FLOATS ? (WIN_FLOATS + V_FLOATS) : EPI_FLOATS;
+  static_assert(NTU >= 1 && NTU * W <= XV && OT % 4 == 0 && RL % 2 == 0, "tile geometry");
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
+};
+
+template <int NS, int DIL, int MI, int NI>
+__global__ void __launch_bounds__(512, 2) conv_wino8_kernel(const Wino8Args a) {
+  using G = Wino8Geo<NS, DIL, MI, NI>;
+  constexpr int NTH = G::NTH, D = G::D, W = G::W, NCW = G::NCW, NTU = G::NTU, NCOL = G::NCOL, OT = G::OT, NV = G::NV, RL = G::RL,
+                CHF = G::CHF, CPR = G::CPR, XV = G::XV, YS = G::YS, OFF = G::OFF, RPP = G::RPP, CG = G::CG;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const vbuf = lds + G::WIN_FLOATS;  // [8 waves][8][XV]
+
+  // 1-D grid, XCD-aware (conv_wino.hip): row tiles pinned to XCD groups, time tiles / utterances spread inside a group
+  const int per = 8 / a.gy;
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int mt = xcd / per;
+  const int lin = (xcd - mt * per) + per * kq;
+  if (lin >= a.gx * a.B) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  int b = -1, len = a.len_default, t0 = 0;
+  if (a.lengths == nullptr) {
+    b = lin / a.gx;
+    t0 = (lin - b * a.gx) * OT;
+    if (t0 >= len) return;
+  } else {  // only the tiles that exist are enumerated (conv_wino.hip)
+    int base = 0;
+    for (int b0 = 0; b0 < a.B; b0 += 64) {
+      const int l = b0 + lane < a.B ? a.lengths[b0 + lane] * a.len_mul : 0;
+      const int nt = (l + OT - 1) / OT;
+      int incl = nt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      const int total = __shfl(incl, 63, 64);
+      if (lin < base + total) {
+        const unsigned long long m = __ballot(base + incl > lin);
+        const int lb = __ffsll((long long)m) - 1;
+        b = b0 + lb;
+        len = __builtin_amdgcn_readfirstlane(__shfl(l, lb, 64));
+        t0 = (lin - base - __builtin_amdgcn_readfirstlane(__shfl(incl - nt, lb, 64))) * OT;
+        break;
+      }
+      base += total;
+    }
+    if (b < 0) return;
+    b = __builtin_amdgcn_readfirstlane(b);
+    t0 = __builtin_amdgcn_readfirstlane(t0);
+  }
+  const int p = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's evaluation point
+  const int l31 = lane & 31, h = lane >> 5;
+  const int o = t0 - a.pad;
+  const int tb = o & ~3;
+  const int sh = o - tb;
+  const float slope = a.slope;
+  const float* xb = a.x + (size_t)b * a.x_bstride;
+  const int nround = a.C / CPR;
+
+  // ---- window staging (conv_wino.hip): clamped 16-byte loads; activation, zero padding and the polyphase scatter on the way to LDS
+  const int r0 = tid / NV, v0 = tid - r0 * NV;
+  constexpr int dr = NTH / NV, dv = NTH - dr * NV;
+  constexpr int SV = (CPR * NV + NTH - 1) / NTH;
+  f32x4 sv[SV];
+  auto stage_load = [&](int rd) __attribute__((always_inline)) {
+    int r = r0, v = v0;
+#pragma unroll
+    for (int i = 0; i < SV; ++i) {
+      int ci = rd * CPR + (r < CPR ? r : CPR - 1);
+      ci = ci < a.C ? ci : a.C - 1;
+      int t = tb + 4 * v;
+      t = t < 0 ? 0 : (t > a.ldx - 4 ? a.ldx - 4 : t);
+      sv[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)ci * a.ldx + t);
+      v += dv;
+      r += dr;
+      if (v >= NV) { v -= NV; ++r; }
+    }
+  };
+  auto stage_store = [&](float* raw) __attribute__((always_inline)) {
+    int r = r0, v = v0;
+#pragma unroll
+    for (int i = 0; i < SV; ++i) {
+      if (r < CPR) {
+        const int t = tb + 4 * v;
+        const f32x4 val = sv[i];
+        float* rowp = raw + r * CHF;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = (t + e) >= 0 && (t + e) < len;
+          const int xs = 4 * v + e - sh + OFF * D;  // >= OFF D - 3 >= 0 (D >= 3)
+          rowp[(xs % D) * RL + xs / D] = ok ? lrelu(val[e], slope) : 0.f;
+        }
+      }
+      v += dv;
+      r += dr;
+      if (v >= NV) { v -= NV; ++r; }
+    }
+  };
+
+  // ---- transform: lane <-> column (tau, phi) (+ 64 per column group); entries w = phi and w = phi + D of unit tau: samples
+  // 6 tau + OFF (+ 1) + q
+  int toff[CG], e0[CG], e1[CG];
+  bool ok1[CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) {
+    const int c0 = lane + 64 * g;
+    const int tcol = c0 < NCOL ? c0 : NCOL - 1;
+    const int ttau = tcol / D, tphi = tcol % D;
+    toff[g] = tphi * RL + 6 * ttau + OFF;  // even: 8-byte aligned reads
+    e0[g] = ttau * W + tphi;
+    ok1[g] = tphi + D < W;
+    e1[g] = ok1[g] ? e0[g] + D : e0[g];
+  }
+  float* const vp = vbuf + p * (8 * XV);
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  auto transform8 = [&](const float* raw8) __attribute__((always_inline)) {
+    if (a.dbg & 1) return;
+    auto go = [&](auto pc) __attribute__((always_inline)) {
+      constexpr int P = decltype(pc)::value;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int g = 0; g < CG; ++g) {
+          const float* rw = raw8 + i * CHF + toff[g];
+          const f32x2 q0 = *reinterpret_cast<const f32x2*>(rw), q1 = *reinterpret_cast<const f32x2*>(rw + 2),
+                      q2 = *reinterpret_cast<const f32x2*>(rw + 4), q3 = *reinterpret_cast<const f32x2*>(rw + 6);
+          const float v0 = w8_bt<P>(q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]);
+          vp[i * XV + e0[g]] = v0;
+          if constexpr (NS > 1) {
+            const float r8 = rw[8];
+            const float v1 = w8_bt<P>(q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1], r8);
+            vp[i * XV + e1[g]] = ok1[g] ? v1 : v0;
+          }
+        }
+      }
+    };
+    switch (p) {  // uniform per wave
+      case 0: go(std::integral_constant<int, 0>{}); break;
+      case 1: go(std::integral_constant<int, 1>{}); break;
+      case 2: go(std::integral_constant<int, 2>{}); break;
+      case 3: go(std::integral_constant<int, 3>{}); break;
+      case 4: go(std::integral_constant<int, 4>{}); break;
+      case 5: go(std::integral_constant<int, 5>{}); break;
+      case 6: go(std::integral_constant<int, 6>{}); break;
+      default: go(std::integral_constant<int, 7>{}); break;
+    }
+  };
+
+  // ---- B fragment offsets: column (ni * 32 + l31) -> (tau, rho) -> tau * W + rho, k half h -> row h
+  int voff[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    int col = ni * 32 + l31;
+    col = col < NCOL ? col : NCOL - 1;
+    voff[ni] = (col / D) * W + (col % D) + h * XV;
+  }
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  // A fragments: one float4 per lane = the 4 k-steps (8 channels) of one (chunk, half, tap) block, packed in the order the
+  // loop walks them: [point][32-row subtile][block][lane]
+  const int nsub = a.C / 32;
+  const int nblk = a.nchunk * NS * 2;
+  const f32x4* wp[MI];
+  f32x4 av[MI], avn[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * MI + mi) * nblk * 64 + lane;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) av[mi] = wp[mi][0];
+  stage_load(0);
+  stage_store(lds);
+  if (nround > 1) stage_load(1);
+  __syncthreads();
+
+  int blk = 0;
+  auto run_taps = [&]() __attribute__((always_inline)) {
+    if (a.dbg & 2) {
+      blk += NS;
+      return;
+    }
+    const float* bj[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bj[ni] = vp + voff[ni];
+#pragma unroll
+    for (int j = 0; j < NS; ++j, ++blk) {
+      const int bn = (blk + 1 < nblk) ? blk + 1 : nblk - 1;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][(size_t)bn * 64];
+      float bk[4][NI];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bk[s][ni] = bj[ni][s * 2 * XV + j * DIL];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][s], bk[s][ni], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) av[mi] = avn[mi];
+    }
+  };
+
+  // One barrier per round: at the top of round rd the window of round rd + 1 goes into the other buffer (every wave finished
+  // reading it before the barrier that closed round rd - 1) and the loads of round rd + 2 are issued
+  for (int rd = 0; rd < nround; ++rd) {
+    const float* raw = lds + (rd & 1) * (CPR * CHF);
+    if (rd + 1 < nround) stage_store(lds + ((rd + 1) & 1) * (CPR * CHF));
+    if (rd + 2 < nround) stage_load(rd + 2);
+#pragma unroll
+    for (int sc = 0; sc < CPR / 8; ++sc) {
+      transform8(raw + (sc * 8) * CHF);
+      run_taps();
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue, 32 rows at a time: the 8 waves put their Y_p into LDS; one thread per (row, column) applies A^T -- all
+  // six outputs of the column from its eight Y values, sharing the sums and differences of the +- point pairs (22
+  // operations for 6 outputs; eight 4-byte LDS reads, lanes on neighbouring columns) -- and scatters them into an output
+  // tile in LDS; then one thread per 4 consecutive outputs adds bias / residual / the MRF mode and stores 16 bytes.
+  // (The first version applied A^T per output quad straight from the Y tiles: eight 16-byte reads and ~10 operations per
+  // OUTPUT, with divisions by D for odd D; the epilogue was 16-21 % of a k = 7 / C = 64 layer.)
+  float* const yb = lds;                 // [8][RPP][YS]
+  float* const ot = lds + G::Y_FLOATS;   // [RPP][OS]
+  if (a.dbg & 4) {
+    if (acc[0][0][0] == 123.f) a.out[0] = 1.f;
+    return;
+  }
+  const int epi = a.epi;
+  const size_t ob = (size_t)b * a.o_bstride;
+  constexpr int OS = G::OS;
+  constexpr int NQ = RPP * (OT / 4), NIT = (NQ + NTH - 1) / NTH;
+  constexpr int NCI = RPP * NCOL, NCT = (NCI + NTH - 1) / NTH;
+  static_assert(OT % 4 == 0, "a tile is a whole number of output quads");
+  constexpr int PS = RPP * YS;  // point stride
+  constexpr int NPASS = 32 * MI / RPP;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    constexpr int dummy_ = 0;
+    (void)dummy_;
+    const int mi = ps * RPP / 32;          // compile-time after unrolling
+    const int sp = (ps * RPP % 32) / 16;   // which 16-row half of the 32-row block (RPP = 16)
+    // residual quads of the pass, fetched before the exchange
+    f32x4 pres[NIT];
+    if (epi != EPI_STORE) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NTH;
+        const int row = idx / (OT / 4), qi = idx - row * (OT / 4);
+        const int n0 = t0 + 4 * qi;
+        if (idx < NQ && n0 + 4 <= len)
+          pres[it] = *reinterpret_cast<const f32x4*>(a.res + ob + (size_t)(mt * (32 * MI) + ps * RPP + row) * a.ldo + n0);
+      }
+    }
+    if (ps > 0) __syncthreads();  // the previous pass has read its output tile and its Y tiles
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (RPP == 32) {
+          yb[(p * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * YS + ni * 32 + l31] = acc[mi][ni][r];
+        } else {
+          if ((r >> 3) == sp) yb[(p * 16 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h) * YS + ni * 32 + l31] = acc[mi][ni][r];
+        }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NCT; ++it) {
+      const int idx = tid + it * NTH;
+      if (idx >= NCI) continue;
+      const int row = idx / NCOL, c = idx - row * NCOL;
+      const int tau = c / D, rho = c - tau * D;
+      const float* yc = yb + row * YS + c;
+      const float y0 = yc[0], y1 = yc[PS], y2 = yc[2 * PS], y3 = yc[3 * PS], y4 = yc[4 * PS], y5 = yc[5 * PS], y6 = yc[6 * PS],
+                  y7 = yc[7 * PS];
+      const float s12 = y1 + y2, d12 = y1 - y2, s34 = y3 + y4, d34 = y3 - y4, s56 = y5 + y6, d56 = y5 - y6;
+      float* op = ot + row * OS + 6 * D * tau + rho;
+      op[0] = (y0 + s12) + (s34 + s56);
+      op[D] = fmaf(2.f, d34, fmaf(0.5f, d56, d12));
+      op[2 * D] = fmaf(4.f, s34, fmaf(0.25f, s56, s12));
+      op[3 * D] = fmaf(8.f, d34, fmaf(0.125f, d56, d12));
+      op[4 * D] = fmaf(16.f, s34, fmaf(0.0625f, s56, s12));
+      op[5 * D] = fmaf(32.f, d34, fmaf(0.03125f, d56, d12)) + y7;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * NTH;
+      if (idx >= NQ) continue;
+      const int row = idx / (OT / 4), qi = idx - row * (OT / 4);
+      const int n0 = t0 + 4 * qi;
+      if (n0 >= len) continue;
+      const int grow = mt * (32 * MI) + ps * RPP + row;
+      const float bz = a.bias[grow];
+      f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * OS + 4 * qi);
+      v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
+      const size_t ix = ob + (size_t)grow * a.ldo + n0;
+      if (n0 + 4 <= len) {
+        if (epi == EPI_STORE) {
+          *reinterpret_cast<f32x4*>(a.out + ix) = v;
+        } else {
+          const f32x4 rs = pres[it];
+          v[0] += rs[0]; v[1] += rs[1]; v[2] += rs[2]; v[3] += rs[3];
+          if (epi == EPI_RES) {
+            *reinterpret_cast<f32x4*>(a.out + ix) = v;
+          } else if (epi == EPI_MRF_SET) {
+            *reinterpret_cast<f32x4*>(a.acc + ix) = v;
+          } else {
+            const f32x4 ac = *reinterpret_cast<const f32x4*>(a.acc + ix);
+            v[0] = ac[0] + v[0]; v[1] = ac[1] + v[1]; v[2] = ac[2] + v[2]; v[3] = ac[3] + v[3];
+            if (epi == EPI_MRF_DIV) {
+              v[0] = __fdiv_rn(v[0], a.mrf_div); v[1] = __fdiv_rn(v[1], a.mrf_div);
+              v[2] = __fdiv_rn(v[2], a.mrf_div); v[3] = __fdiv_rn(v[3], a.mrf_div);
+            }
+            *reinterpret_cast<f32x4*>(a.acc + ix) = v;
+          }
+        }
+      } else {
+        for (int e = 0; e < len - n0; ++e) {
+          float x = v[e];
+          if (epi == EPI_STORE) {
+            a.out[ix + e] = x;
+          } else {
+            x += a.res[ix + e];
+            if (epi == EPI_RES) {
+              a.out[ix + e] = x;
+            } else if (epi == EPI_MRF_SET) {
+              a.acc[ix + e] = x;
+            } else {
+              x = a.acc[ix + e] + x;
+              if (epi == EPI_MRF_DIV) x = __fdiv_rn(x, a.mrf_div);
+              a.acc[ix + e] = x;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+bool wino8_supported(int Cout, int Cin, int KS, int dil) {
+  return Cout == Cin && (Cout == 64 || Cout == 128 || Cout == 256 || Cout == 512) && (KS == 7 || KS == 11) &&
+         (dil == 1 || dil == 3 || dil == 5);
+}
+
+int g_wino8_mask = 0x31;  // "wino8_mask" option: which (stage width, kernel size) pairs the generator uses it for --
+                          // bit 2 * cls + (k == 11), cls = 0 for C = 64, 1 for C = 128, 2 for C >= 256
+bool wino8_wanted(int C, int KS) {
+  if (!g_wino8 || !g_wino || C < g_wino_min_c || !wino8_supported(C, C, KS, 1)) return false;
+  const int cls = C >= 256 ? 2 : C >= 128 ? 1 : 0;
+  return (g_wino8_mask >> (2 * cls + (KS == 11 ? 1 : 0))) & 1;
+}
+
+// w: [C][C][KS] -> U[p][co][ci][j] = sum_i G[p][i] w[co][ci][j + NS i], packed in A-fragment order (make_wino's, 8 points)
+int make_wino8(const float* w, const float* bias, int C, int KS, int dil, DevConv& dc) {
+  const int NS = (KS + 2) / 3;
+  if (C % 32 != 0 || C % KC != 0) {
+    set_error("make_wino8: C = %d is not a multiple of the row tile", C);
+    return DISSC_EINVAL;
+  }
+  const int nchunk = C / KC, nsub = C / 32;
+  std::vector<float> packed((size_t)8 * nsub * nchunk * 2 * NS * 64 * 4);
+  size_t o = 0;
+  for (int p = 0; p < 8; ++p)
+    for (int ms = 0; ms < nsub; ++ms)
+      for (int c = 0; c < nchunk; ++c)
+        for (int hf = 0; hf < 2; ++hf)
+          for (int j = 0; j < NS; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 4; ++e) {
+                const int co = ms * 32 + (lane & 31), ci = c * KC + 8 * hf + 2 * e + (lane >> 5);
+                double u = 0.0;
+                for (int i = 0; i < 3; ++i) {
+                  const int tap = j + NS * i;
+                  if (tap < KS) u += kW8G[p][i] * (double)w[((size_t)co * C + ci) * KS + tap];
+                }
+                packed[o++] = (float)u;
+              }
+  std::vector<float> b(C, 0.f);
+  if (bias) memcpy(b.data(), bias, C * sizeof(float));
+  dc.CIN = C; dc.M = C; dc.KS = KS; dc.dil = dil; dc.nchunk = nchunk; dc.up = 1;
+  dc.groups = 1; dc.Mpad = C; dc.stride = 1; dc.pad_left = -1; dc.m32 = 1; dc.prec = 0;
+  dc.macs_per_t = (double)C * C * KS;  // algorithmic (direct-form) MACs
+  dc.wino = 2;
+  int rc = upload(packed, &dc.wpack);
+  if (rc) return rc;
+  return upload(b, &dc.bias);
+}
+
+// MACs the matrix pipe executes per output position (8 NS / 6 per input/output channel pair)
+double wino8_executed_macs_per_t(int C, int KS) { return (double)C * C * 8.0 * ((KS + 2) / 3) / 6.0; }
+
+template <int NS, int DIL, int MI, int NI>
+static int launch_wino8_t(const Wino8Args& a, int B, int Lmax, hipStream_t stream) {
+  using G = Wino8Geo<NS, DIL, MI, NI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<NS, DIL, MI, NI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  Wino8Args aa = a;
+  aa.gx = (Lmax + G::OT - 1) / G::OT;
+  aa.gy = a.C / (32 * MI);
+  aa.B = B;
+  if (aa.gy < 1 || 8 % aa.gy != 0) {
+    set_error("launch_wino8: %d row tiles do not divide the 8 XCDs", aa.gy);
+    return DISSC_EINVAL;
+  }
+  const int per = 8 / aa.gy;
+  dim3 grid(8 * ((aa.gx * B + per - 1) / per));
+  hipLaunchKernelGGL((conv_wino8_kernel<NS, DIL, MI, NI>), grid, dim3(512), (size_t)G::LDS_FLOATS * sizeof(float), stream, aa);
+  DISSC_HIP_CHECK(hipGetLastError());
+  return DISSC_OK;
+}
+
+int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, float* acc, const int32_t* lengths,
+              int len_default, int len_mul, int B, int ldx, int ldo, int Lmax, float slope, int epi, float mrf_div,
+              hipStream_t stream) {
+  Wino8Args a;
+  a.x = x; a.wpack = dc.wpack; a.bias = dc.bias; a.res = res; a.out = out; a.acc = acc;
+  a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul;
+  a.C = dc.M; a.nchunk = dc.nchunk; a.pad = (dc.KS - 1) * dc.dil / 2;
+  a.ldx = ldx; a.ldo = ldo;
+  a.x_bstride = (long long)dc.M * ldx; a.o_bstride = (long long)dc.M * ldo;
+  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = g_wino8_dbg;
+  a.gx = a.gy = a.B = 0;
+  auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
+  if (ldx < 4 || ldx % 4 || ldo % 4 || misaligned(x) || misaligned(out) || misaligned(res) || misaligned(acc)) {
+    set_error("run_wino8: rows must be 16-byte aligned (ldx %d, ldo %d: multiples of 4 floats, ldx >= 4)", ldx, ldo);
+    return DISSC_EINVAL;
+  }
+  if (B <= 0 || Lmax <= 0 || !wino8_supported(dc.M, dc.M, dc.KS, dc.dil)) {
+    set_error("run_wino8: unsupported call (B %d, Lmax %d, C %d, k %d, d %d)", B, Lmax, dc.M, dc.KS, dc.dil);
+    return DISSC_EINVAL;
+  }
+  const int ns = (dc.KS + 2) / 3;
+  // wave tile = workgroup tile: 128 rows x 64 columns for C >= 128, 64 x 128 ("wino8_c64_wide", default) or 64 x 64 for C = 64
+#define DISSC_W8(NS_, D_)                                                                            \
+  if (ns == NS_ && dc.dil == D_)                                                                     \
+    return dc.M >= 128 ? launch_wino8_t<NS_, D_, 4, 2>(a, B, Lmax, stream)                         \
+                       : (g_wino8_c64_wide ? launch_wino8_t<NS_, D_, 2, 4>(a, B, Lmax, stream) : launch_wino8_t<NS_, D_, 2, 2>(a, B, Lmax, stream));
+  DISSC_W8(3, 1) DISSC_W8(3, 3) DISSC_W8(3, 5) DISSC_W8(4, 1) DISSC_W8(4, 3) DISSC_W8(4, 5)
+#undef DISSC_W8
+  set_error("run_wino8: k = %d, dilation %d unsupported", dc.KS, dc.dil);
+  return DISSC_EINVAL;
+}
+
+}  // namespace dissc

@@ -250,7 +250,9 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         snprintf(name, sizeof(name), "resblocks.%d.convs1.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
         const bool wino = prec == 0 && wino_wanted(ch, rk) && wino_supported(ch, ch, rk, d);
-        if ((rc = wino ? make_wino(w, b, ch, rk, d, g->rb1[idx]) : make_conv(w, b, ch, ch, rk, d, g->rb1[idx])))
+        const bool w8 = wino && wino8_wanted(ch, rk) && wino8_supported(ch, ch, rk, d);  // F(6,3) on 8-wave workgroups
+        if ((rc = w8 ? make_wino8(w, b, ch, rk, d, g->rb1[idx])
+                     : wino ? make_wino(w, b, ch, rk, d, g->rb1[idx]) : make_conv(w, b, ch, ch, rk, d, g->rb1[idx])))
           return fail(rc);
         const float* w1c = w;
         const float* b1c = b;
@@ -263,7 +265,8 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         snprintf(name, sizeof(name), "resblocks.%d.convs2.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
         const bool wino2 = wino;
-        if ((rc = wino2 ? make_wino(w, b, ch, rk, 1, g->rb2[idx]) : make_conv(w, b, ch, ch, rk, 1, g->rb2[idx])))
+        if ((rc = w8 ? make_wino8(w, b, ch, rk, 1, g->rb2[idx])
+                     : wino2 ? make_wino(w, b, ch, rk, 1, g->rb2[idx]) : make_conv(w, b, ch, ch, rk, 1, g->rb2[idx])))
           return fail(rc);
         // the whole pair as one transform-domain launch (respair_wino.hip): C = 32, k = 7 / 11 and C = 64, k = 3
         // (C = 64: only a chain's FIRST pair -- the later ones update x_k in place, which a fused pair cannot)
@@ -358,7 +361,9 @@ double dissc_gen_flops_executed(dissc_gen_t g, int64_t frames) {
   double macs = g->conv_pre.macs_per_t;
   int mul = 1;
   const int nk = g->cfg.num_kernels;
-  auto ex = [](const DevConv& c) { return c.wino ? wino_executed_macs_per_t(c.M, c.KS) : c.macs_per_t; };
+  auto ex = [](const DevConv& c) {
+    return c.wino == 2 ? wino8_executed_macs_per_t(c.M, c.KS) : c.wino ? wino_executed_macs_per_t(c.M, c.KS) : c.macs_per_t;
+  };
   for (int i = 0; i < g->cfg.num_upsamples; ++i) {
     for (auto& c : g->ups[i]) macs += c.macs_per_t * mul;
     mul = g->stage_mul[i];
@@ -576,15 +581,15 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
         }
         if (g->rb1[idx].wino && g->rb2[idx].wino) {
           // Toom-Cook F(4,3) form (conv_wino.hip): t = conv_d(lrelu(x)); x = x + conv_1(lrelu(t)) / MRF update
-          if ((rc = run_wino(g->rb1[idx], xin, TMPc, nullptr, nullptr, lengths, L, mul, B, ld, ld, L, 0.1f, EPI_STORE,
-                             1.f, sj)))
+          auto runw = g->rb1[idx].wino == 2 ? run_wino8 : run_wino;  // F(6,3) on 8 waves (k = 7 / 11) or F(4,3) on 12
+          if ((rc = runw(g->rb1[idx], xin, TMPc, nullptr, nullptr, lengths, L, mul, B, ld, ld, L, 0.1f, EPI_STORE, 1.f, sj)))
             return rc;
           int epiw = EPI_RES;
           if (m == 2) {
             epiw = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET) : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
             if (multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));
           }
-          if ((rc = run_wino(g->rb2[idx], TMPc, XKc, xin, ACC, lengths, L, mul, B, ld, ld, L, 0.1f, epiw, (float)nk, sj)))
+          if ((rc = runw(g->rb2[idx], TMPc, XKc, xin, ACC, lengths, L, mul, B, ld, ld, L, 0.1f, epiw, (float)nk, sj)))
             return rc;
           continue;
         }
@@ -648,11 +653,12 @@ int dissc_conv1d(const float* x, const float* w_host, const float* bias_host, fl
     return DISSC_EINVAL;
   }
   DevConv dc;
-  if (g_wino >= 2 && wino_supported(Cout, Cin, k, dilation)) {  // "wino" = 2: the stand-alone entry uses it too (tests)
-    int rc = make_wino(w_host, bias_host, Cout, k, dilation, dc);
+  const bool use8 = g_wino8 >= 2 && wino8_supported(Cout, Cin, k, dilation);  // "wino8" = 2: the stand-alone entry uses it (tests)
+  if (use8 || (g_wino >= 2 && wino_supported(Cout, Cin, k, dilation))) {  // "wino" = 2: likewise for the F(4,3) form
+    int rc = use8 ? make_wino8(w_host, bias_host, Cout, k, dilation, dc) : make_wino(w_host, bias_host, Cout, k, dilation, dc);
     if (rc) return rc;
-    rc = run_wino(dc, x, y, nullptr, nullptr, lengths, Lmax, 1, B, ldx, ldo, Lmax, in_slope, EPI_STORE, 1.f,
-                  (hipStream_t)stream);
+    rc = (use8 ? run_wino8 : run_wino)(dc, x, y, nullptr, nullptr, lengths, Lmax, 1, B, ldx, ldo, Lmax, in_slope, EPI_STORE, 1.f,
+                                       (hipStream_t)stream);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     free_conv(dc);
     if (rc) return rc;
@@ -849,6 +855,10 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "wino") == 0) { g_wino = value; return DISSC_OK; }
   if (strcmp(key, "wino_min_c") == 0) { g_wino_min_c = value; return DISSC_OK; }
   if (strcmp(key, "wino_dbg") == 0) { g_wino_dbg = value; return DISSC_OK; }
+  if (strcmp(key, "wino8") == 0) { g_wino8 = value; return DISSC_OK; }
+  if (strcmp(key, "wino8_dbg") == 0) { g_wino8_dbg = value; return DISSC_OK; }
+  if (strcmp(key, "wino8_c64_wide") == 0) { g_wino8_c64_wide = value; return DISSC_OK; }
+  if (strcmp(key, "wino8_mask") == 0) { g_wino8_mask = value; return DISSC_OK; }
   if (strcmp(key, "wino_cpr") == 0) { g_wino_cpr = value; return DISSC_OK; }
   if (strcmp(key, "wino_sv") == 0) { g_wino_sv = value; return DISSC_OK; }
   if (strcmp(key, "wino_small") == 0) { g_wino_small = value; return DISSC_OK; }
@@ -889,9 +899,11 @@ int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int e
   }
   DevConv dc;
   g_conv_prec = g_precision;  // diagnostics follow the "precision" option like the generator does
-  const bool wino = (flags & 2) && wino_supported(Cout, Cin, k, dilation);
-  int rc = wino ? make_wino(w.data(), bias.data(), Cout, k, dilation, dc)
-                : make_conv(w.data(), bias.data(), Cout, Cin, k, dilation, dc);
+  const bool w8 = (flags & 4) && wino8_supported(Cout, Cin, k, dilation);
+  const bool wino = w8 || ((flags & 2) && wino_supported(Cout, Cin, k, dilation));
+  int rc = w8 ? make_wino8(w.data(), bias.data(), Cout, k, dilation, dc)
+              : wino ? make_wino(w.data(), bias.data(), Cout, k, dilation, dc)
+                     : make_conv(w.data(), bias.data(), Cout, Cin, k, dilation, dc);
   g_conv_prec = 0;
   if (rc) return rc;
   const int ld = (L + 3) / 4 * 4;
@@ -915,7 +927,8 @@ int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int e
   const int saved_cls = (flags >> 16) & 0xf;
   if (flags & 0x8000) conv_set_cfg(saved_cls, (flags >> 8) & 0x3f);
   auto once = [&]() {
-    return wino ? run_wino(dc, x, y, r, a, nullptr, L, 1, B, ld, ld, L, (flags & 1) ? 1.0f : 0.1f, epi, 3.f, nullptr)
+    return w8 ? run_wino8(dc, x, y, r, a, nullptr, L, 1, B, ld, ld, L, (flags & 1) ? 1.0f : 0.1f, epi, 3.f, nullptr)
+         : wino ? run_wino(dc, x, y, r, a, nullptr, L, 1, B, ld, ld, L, (flags & 1) ? 1.0f : 0.1f, epi, 3.f, nullptr)
                 : run_conv(dc, x, y, r, a, nullptr, L, 1, B, Cin, ld, ld, L, (flags & 1) ? 1.0f : 0.1f, epi, 3.f, nullptr);
   };
   for (int it = 0; it < 2 && !rc; ++it) rc = once();
