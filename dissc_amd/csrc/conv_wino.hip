@@ -67,6 +67,9 @@ struct WinoArgs {
 #ifndef DISSC_WINO_LB
 #define DISSC_WINO_LB 3
 #endif
+#ifndef DISSC_WINO_EPI2
+#define DISSC_WINO_EPI2 1  // epilogue: A^T per column through an output tile in LDS (0: per output quad straight from the Y tiles)
+#endif
 
 // polyphase row length: indices 0 .. 4 NTU + 7 are touched (the last aligned 16-byte read of a lane starts at
 // 4 (NTU - 1) + 8), rounded up so that RL / 4 makes the 16 lanes of a quarter wave start in 16 different bank groups
@@ -432,6 +435,12 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   // (16-byte residual / accumulator / output accesses) of one row: output u = 4 g + e of unit tau comes from column
   // (tau, u % D) with A^T row a = u / D
   float* yb = lds;  // [6][32][YS]
+  // epilogue form: A^T per column through an output tile in LDS for the steps D that are neither 1 nor a multiple of 4
+  // (k = 7 and the dilated k = 3 instances, whose per-quad form needs per-element divisions by D); per output quad
+  // straight from the Y tiles otherwise (measured: the D % 4 == 0 instances are 1-4 % SLOWER through the output tile)
+  constexpr bool EPI2 = DISSC_WINO_EPI2 && D != 1 && D % 4 != 0;
+  constexpr int OSW = 4 * D * NTU + 4;     // row stride of the output tile of a pass (one column half)
+  float* const ot = lds + 6 * 32 * YS;     // [32][OSW]
   if (a.dbg & 4) {
     if (acc[0][0][0] == 123.f) a.out[0] = 1.f;
     return;
@@ -467,6 +476,33 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
           yb[(p * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * YS + ni * 32 + l31] = acc[mi][ni][r];
     }
     __syncthreads();
+    if constexpr (EPI2) {
+    // A^T per COLUMN: one thread forms the four outputs of a column from its six Y values (sums and differences of the +-
+    // point pairs shared: 10 operations for 4 outputs, six 4-byte LDS reads with the lanes on neighbouring columns) and
+    // scatters them into an output tile in LDS; the quad loop below only adds bias / residual / MRF mode and stores.
+    // (Per output QUAD straight from the Y tiles it was six 16-byte reads and 6 operations per OUTPUT, per-element
+    // divisions by D for odd D: 9-23 % of a C = 64 layer, conv_wino8.hip has the before / after.)
+    {
+      constexpr int NCI = 32 * NCOL, NCT = (NCI + NTH - 1) / NTH;
+#pragma unroll
+      for (int it = 0; it < NCT; ++it) {
+        const int idx = tid + it * NTH;
+        if (idx >= NCI) continue;
+        const int row = idx / NCOL, c = idx - row * NCOL;
+        const int tau = c / D, rho = c - tau * D;
+        const float* yc = yb + row * YS + c;
+        const float y0 = yc[0], y1 = yc[32 * YS], y2 = yc[2 * 32 * YS], y3 = yc[3 * 32 * YS], y4 = yc[4 * 32 * YS],
+                    y5 = yc[5 * 32 * YS];
+        const float s12 = y1 + y2, d12 = y1 - y2;
+        float* op = ot + row * OSW + 4 * D * tau + rho;
+        op[0] = (y0 + s12) + (y3 + y4);
+        op[D] = d12 + fmaf(2.f, y3, -0.5f * y4);
+        op[2 * D] = s12 + fmaf(4.f, y3, 0.25f * y4);
+        op[3 * D] = d12 + fmaf(8.f, y3, -0.125f * y4) + y5;
+      }
+    }
+    __syncthreads();
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = tid + it * NTH;
@@ -477,9 +513,12 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
       if (n0 >= len) continue;
       const int grow = mt * (32 * MI * RH) + (RH == 2 ? ps * 32 : mi * 32) + row;
       const float bz = a.bias[grow];
-      const float* yr = yb + row * YS + tau * D;
       f32x4 v;
-      if constexpr (D == 1) {
+      const float* yr = yb + row * YS + tau * D;
+      if constexpr (EPI2) {
+        v = *reinterpret_cast<const f32x4*>(ot + row * OSW + 4 * D * tau + 4 * g);
+        v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
+      } else if constexpr (D == 1) {
         const float y0 = yr[0], y1 = yr[32 * YS], y2 = yr[2 * 32 * YS], y3 = yr[3 * 32 * YS], y4 = yr[4 * 32 * YS],
                     y5 = yr[5 * 32 * YS];
         const float s12 = y1 + y2, d12 = y1 - y2;
@@ -639,7 +678,8 @@ static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
   constexpr int D = DIL * NS, NTU = 32 * TW / D, OT = 4 * D * NTU * CHV, RAW = OT + DIL * (3 * NS - 1), XRW = (RAW + 6) / 4 * 4;
   constexpr int RL = wino_row_len(D, NTU * CHV, XRW);
   size_t lds_f = (size_t)2 * CPR * D * RL + 12 * 8 * 112;
-  if (lds_f < (size_t)6 * 32 * (32 * TW + 4)) lds_f = (size_t)6 * 32 * (32 * TW + 4);
+  const size_t epi_f = (size_t)6 * 32 * (32 * TW + 4) + ((DISSC_WINO_EPI2 && D != 1 && D % 4 != 0) ? (size_t)32 * (4 * D * NTU + 4) : 0);
+  if (lds_f < epi_f) lds_f = epi_f;
   static bool attr_done = false;
   if (!attr_done) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, DIL, CPR, RH, TW, SHV>),
