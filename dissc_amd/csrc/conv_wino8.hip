@@ -30,16 +30,17 @@
 
 namespace dissc {
 
-int g_wino8 = 0;      // "wino8" option (read at dissc_gen_create): 0 (default) = not used; 1 = the k = 7 / 11 ResBlock convs the
-                      // "wino8_mask" names use this kernel instead of conv_wino's F(4,3) form; 2 = the stand-alone dissc_conv1d
-                      // entry uses it too (tests).  Off by default: per launch it is 3-17 % faster than the F(4,3) form on 26 of
-                      // the 36 (C, k, d, epilogue) shapes of the generator (tools/wino8_gate.py) and 4-9 % slower on the d = 1 shapes
-                      // of the 128-channel stage (864 workgroups = 3.4 rounds of 256 CUs where the F(4,3) tiles make exactly 5.0),
-                      // but in the whole forward -- three chains overlapping on their streams -- the best mask (0x31: C >= 256 both
-                      // kernel sizes, C = 64 k = 7) is worth 35.25 against 35.51 ms (serial launches: 36.96 against 37.49), while the
-                      // executed-FLOP utilisation falls from 0.618 to 0.603 (11 % fewer products on those layers).
+int g_wino8 = 1;      // "wino8" option (read at dissc_gen_create): 1 (default) = the k = 7 / 11 ResBlock convs the "wino8_mask" names use
+                      // this kernel instead of conv_wino's F(4,3) form; 0 = none; 2 = the stand-alone dissc_conv1d entry uses it too
+                      // (tests).  Per launch it is 3-17 % faster than the F(4,3) form on 26 of the 36 (C, k, d, epilogue) shapes of the
+                      // generator (tools/wino8_gate.py) and 4-9 % slower on the d = 1 shapes of the 128-channel stage (864 workgroups
+                      // = 3.4 rounds of 256 CUs where the F(4,3) tiles make exactly 5.0): the default mask leaves that stage alone.
+                      // Whole forward, same box, two runs each: 35.17 / 35.27 -> 34.84 / 34.91 ms (1.0 %), executed-FLOP utilisation
+                      // 0.62 -> 0.60 (11 % fewer products on those layers in 1 % less time), in-run parity rms 5.5e-7 -> 6.5e-7.
 int g_wino8_dbg = 0;  // diagnostics: knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue
-int g_wino8_c64_wide = 1;  // "wino8_c64_wide" option: C = 64 instances on 64 x 128 tiles (768 outputs) instead of 64 x 64
+int g_wino8_c64_wide = 3;  // "wino8_c64_wide" option, C = 64 instances: 1 = 64 x 128 tiles (768 outputs), 0 = 64 x 64, 2 = 64 x 64 built for TWO
+                           // workgroups per CU (<= 128 registers, <= 80 KB LDS: their phases overlap; +3-9 % on k = 11, mixed on
+                           // k = 7), 3 (default) = 1 for k = 7, 2 for k = 11
 
 struct Wino8Args {
   const float* x;
@@ -108,7 +109,9 @@ constexpr int w8_row_len(int D, int NTU, int need) {
   return best;
 }
 
-template <int NS, int DIL, int MI, int NI>
+// WPS: waves per SIMD the instance is built for -- 2: one 8-wave workgroup per CU (up to 256 registers); 4: TWO workgroups
+// per CU (<= 128 registers and <= 80 KB of LDS each: windows of 8 channels, epilogue passes of 16 rows), whose phases overlap
+template <int NS, int DIL, int MI, int NI, int WPS = 2>
 struct Wino8Geo {
   static constexpr int NTH = 512;
   static constexpr int D = DIL * NS, W = DIL * (2 * NS - 1);
@@ -124,8 +127,8 @@ struct Wino8Geo {
   static constexpr int RL_MIN = w8_rup(((XRW - 1 + OFF * D) / D + 1) > (6 * NTU + OFF + 10) ? ((XRW - 1 + OFF * D) / D + 1) : (6 * NTU + OFF + 10), 2);
   static constexpr int RL = w8_row_len(D, NTU, RL_MIN);  // bumped so that the 8-byte transform reads of a half wave spread over the banks
   static constexpr int CHF = D * RL;
-  static constexpr int CPR = NI == 4 ? 8 : 16;         // channels of the window per round (LDS budget of the 128-column tile)
-  static constexpr int RPP = NI == 4 ? 16 : 32;        // rows per epilogue pass (likewise)
+  static constexpr int CPR = (NI == 4 || WPS == 4) ? 8 : 16;   // channels of the window per round (LDS budget)
+  static constexpr int RPP = (NI == 4 || WPS == 4) ? 16 : 32;  // rows per epilogue pass (likewise)
   static constexpr int CG = NCW / 64 > 0 ? NCW / 64 : 1;  // 64-column groups a lane transforms
   static constexpr int XV = NTU * W <= 112 ? 112 : 240; // V row stride (% 32 == 16: the two k halves of a fragment read hit different banks)
   static constexpr int YS = NCW + 4;
@@ -136,12 +139,12 @@ struct Wino8Geo {
   static constexpr int EPI_FLOATS = Y_FLOATS + RPP * OS;
   static constexpr int LDS_FLOATS = (WIN_FLOATS + V_FLOATS) > EPI_FLOATS ? (WIN_FLOATS + V_FLOATS) : EPI_FLOATS;
   static_assert(NTU >= 1 && NTU * W <= XV && OT % 4 == 0 && RL % 2 == 0, "tile geometry");
-  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
+  static_assert(LDS_FLOATS * 4 <= (WPS == 4 ? 80 : 160) * 1024, "LDS");
 };
 
-template <int NS, int DIL, int MI, int NI>
-__global__ void __launch_bounds__(512, 2) conv_wino8_kernel(const Wino8Args a) {
-  using G = Wino8Geo<NS, DIL, MI, NI>;
+template <int NS, int DIL, int MI, int NI, int WPS = 2>
+__global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a) {
+  using G = Wino8Geo<NS, DIL, MI, NI, WPS>;
   constexpr int NTH = G::NTH, D = G::D, W = G::W, NCW = G::NCW, NTU = G::NTU, NCOL = G::NCOL, OT = G::OT, NV = G::NV, RL = G::RL,
                 CHF = G::CHF, CPR = G::CPR, XV = G::XV, YS = G::YS, OFF = G::OFF, RPP = G::RPP, CG = G::CG;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -495,7 +498,7 @@ bool wino8_supported(int Cout, int Cin, int KS, int dil) {
          (dil == 1 || dil == 3 || dil == 5);
 }
 
-int g_wino8_mask = 0x31;  // "wino8_mask" option: which (stage width, kernel size) pairs the generator uses it for --
+int g_wino8_mask = 0x33;  // "wino8_mask" option (default: C = 64 and C >= 256, both kernel sizes): which (stage width, kernel size) pairs the generator uses it for --
                           // bit 2 * cls + (k == 11), cls = 0 for C = 64, 1 for C = 128, 2 for C >= 256
 bool wino8_wanted(int C, int KS) {
   if (!g_wino8 || !g_wino || C < g_wino_min_c || !wino8_supported(C, C, KS, 1)) return false;
@@ -542,12 +545,12 @@ int make_wino8(const float* w, const float* bias, int C, int KS, int dil, DevCon
 // MACs the matrix pipe executes per output position (8 NS / 6 per input/output channel pair)
 double wino8_executed_macs_per_t(int C, int KS) { return (double)C * C * 8.0 * ((KS + 2) / 3) / 6.0; }
 
-template <int NS, int DIL, int MI, int NI>
+template <int NS, int DIL, int MI, int NI, int WPS = 2>
 static int launch_wino8_t(const Wino8Args& a, int B, int Lmax, hipStream_t stream) {
-  using G = Wino8Geo<NS, DIL, MI, NI>;
+  using G = Wino8Geo<NS, DIL, MI, NI, WPS>;
   static bool attr_done = false;
   if (!attr_done) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<NS, DIL, MI, NI>),
+    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<NS, DIL, MI, NI, WPS>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -561,7 +564,7 @@ static int launch_wino8_t(const Wino8Args& a, int B, int Lmax, hipStream_t strea
   }
   const int per = 8 / aa.gy;
   dim3 grid(8 * ((aa.gx * B + per - 1) / per));
-  hipLaunchKernelGGL((conv_wino8_kernel<NS, DIL, MI, NI>), grid, dim3(512), (size_t)G::LDS_FLOATS * sizeof(float), stream, aa);
+  hipLaunchKernelGGL((conv_wino8_kernel<NS, DIL, MI, NI, WPS>), grid, dim3(512), (size_t)G::LDS_FLOATS * sizeof(float), stream, aa);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
@@ -587,11 +590,15 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
     return DISSC_EINVAL;
   }
   const int ns = (dc.KS + 2) / 3;
+  // C = 64: k = 7 on 64 x 128 tiles, k = 11 on 64 x 64 tiles built for two workgroups per CU (measured per shape, tools/wino8_c64.py)
+  const int c64_mode = g_wino8_c64_wide == 3 ? (dc.KS == 11 ? 2 : 1) : g_wino8_c64_wide;
   // wave tile = workgroup tile: 128 rows x 64 columns for C >= 128, 64 x 128 ("wino8_c64_wide", default) or 64 x 64 for C = 64
 #define DISSC_W8(NS_, D_)                                                                            \
   if (ns == NS_ && dc.dil == D_)                                                                     \
     return dc.M >= 128 ? launch_wino8_t<NS_, D_, 4, 2>(a, B, Lmax, stream)                         \
-                       : (g_wino8_c64_wide ? launch_wino8_t<NS_, D_, 2, 4>(a, B, Lmax, stream) : launch_wino8_t<NS_, D_, 2, 2>(a, B, Lmax, stream));
+                       : (c64_mode == 1 ? launch_wino8_t<NS_, D_, 2, 4>(a, B, Lmax, stream)                  \
+                          : c64_mode == 2 ? launch_wino8_t<NS_, D_, 2, 2, 4>(a, B, Lmax, stream)            \
+                                          : launch_wino8_t<NS_, D_, 2, 2>(a, B, Lmax, stream));
   DISSC_W8(3, 1) DISSC_W8(3, 3) DISSC_W8(3, 5) DISSC_W8(4, 1) DISSC_W8(4, 3) DISSC_W8(4, 5)
 #undef DISSC_W8
   set_error("run_wino8: k = %d, dilation %d unsupported", dc.KS, dc.dil);

@@ -149,6 +149,10 @@ def main():
             import re
             k = int(re.search(r" k(\d+) ", name + " ").group(1))
             fx = fl * 6.0 * ((k + 2) // 3) / (4.0 * k)
+        if "conv_wino8_kernel" in names[i][0]:  # Toom-Cook F(6,3): 8 ceil(k / 3) / 6 products per output
+            import re
+            k = int(re.search(r" k(\d+) ", name + " ").group(1))
+            fx = fl * 8.0 * ((k + 2) // 3) / (6.0 * k)
         row = [str(i), name, names[i][0][:44], f"{d:.0f}", f"{fl / 1e9:.1f}", f"{fl / d / 1e6:.1f}" if fl else "-",
                f"{fx / d / 1e6:.1f}" if fl else "-", f"{by / 1e9:.3f}", f"{by / d / 1e3:.0f}"]
         g = name.split()[0] if a.what == "gen" else ("attention" if "attention" in name else "linear" if ("->" in name and "conv" not in name)

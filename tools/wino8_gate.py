@@ -29,7 +29,7 @@ def conv1d(x, w, b, lengths, d, slope, form):
                          w.shape[0], w.shape[2], d, ld, ld, int(lengths.max()), ctypes.c_float(slope), None), "conv1d")
     torch.cuda.synchronize()
     L.dissc_set_option(b"wino", 1)
-    L.dissc_set_option(b"wino8", 1)
+    L.dissc_set_option(b"wino8", 1)  # (the default)
     return y
 
 
