@@ -103,6 +103,20 @@ def test_sr_inference_two_ranks_equal_one_process(gpu, golden_dir, tmp_path):
         assert open(f"{td}/out/{fn}", "rb").read() == open(f"{td}/out_single/{fn}", "rb").read(), fn
 
 
+def _assert_wav_close(data, ref, fn):
+    """Generated files are int16-TRUNCATED and then divided by their peak (reference sr/inference.py:73-75,206): a ~1e-6
+    difference of the waveform moves a sample by one int16 LSB (1 / peak ~ 3e-5) now and then -- and when that sample is
+    the PEAK itself, every sample of the file is rescaled by one part in ~30 000.  So: the best-fit scale between the two
+    files may differ from 1 by at most one LSB of the peak; after it, a few per cent of the samples differ by one LSB,
+    everything else is bit-identical."""
+    s = float(np.dot(ref.astype(np.float64), data.astype(np.float64)) / max(np.dot(data.astype(np.float64), data.astype(np.float64)), 1e-30))
+    assert abs(s - 1.0) <= 6e-5, (fn, s)
+    d = np.abs(data.astype(np.float64) * s - ref)
+    assert d.max() <= 1e-4, (fn, d.max())
+    assert np.sqrt(np.mean(d ** 2)) <= 1e-5, (fn, np.sqrt(np.mean(d ** 2)))
+    assert (d > 1e-6).mean() <= 0.04, (fn, (d > 1e-6).mean())
+
+
 def _check_wavs(out_dir, g, prefix):
     want_files = sorted(k[len(prefix):] for k in g.files if k.startswith(prefix))
     assert sorted(os.listdir(out_dir)) == want_files
@@ -113,10 +127,7 @@ def _check_wavs(out_dir, g, prefix):
         if fn.endswith("_gt.wav"):
             np.testing.assert_array_equal(data, ref)
         else:
-            d = np.abs(data - ref)
-            assert d.max() <= 1e-4, (fn, d.max())
-            assert np.sqrt(np.mean(d ** 2)) <= 1e-5
-            assert (d > 1e-6).mean() <= 0.02
+            _assert_wav_close(data, ref, fn)
 
 
 def test_sr_inference_unseen_speaker_f0_stats_parts_and_sample_df(gpu, golden_dir, tmp_path):
@@ -172,12 +183,7 @@ def test_sr_inference_cli_matches_reference(gpu, golden_dir, tmp_path):
         if fn.endswith("_gt.wav"):
             np.testing.assert_array_equal(data, ref)
         else:
-            # int16 truncation of a ~1e-6-different waveform can move a sample by one LSB
-            # (1/peak ~ 3e-5); everything else is bit-identical
-            d = np.abs(data - ref)
-            assert d.max() <= 1e-4, (fn, d.max())
-            assert np.sqrt(np.mean(d ** 2)) <= 1e-5
-            assert (d > 1e-6).mean() <= 0.02
+            _assert_wav_close(data, ref, fn)
 
 
 def test_encode_cli_roundtrip(gpu, golden_dir, tmp_path):
