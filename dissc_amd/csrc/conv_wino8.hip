@@ -494,16 +494,17 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
 // host side
 // ---------------------------------------------------------------------------------------------
 bool wino8_supported(int Cout, int Cin, int KS, int dil) {
-  return Cout == Cin && (Cout == 64 || Cout == 128 || Cout == 256 || Cout == 512) && (KS == 7 || KS == 11) &&
+  return Cout == Cin && (Cout == 64 || Cout == 128 || Cout == 256 || Cout == 512) && (KS == 3 || KS == 7 || KS == 11) &&
          (dil == 1 || dil == 3 || dil == 5);
 }
 
-int g_wino8_mask = 0x33;  // "wino8_mask" option (default: C = 64 and C >= 256, both kernel sizes): which (stage width, kernel size) pairs the generator uses it for --
-                          // bit 2 * cls + (k == 11), cls = 0 for C = 64, 1 for C = 128, 2 for C >= 256
+int g_wino8_mask = 0606;  // "wino8_mask" option (octal digits = classes; default: k = 7 / 11 at C = 64 and C >= 256): which (stage width,
+                          // kernel size) pairs the generator uses it for -- bit 3 * cls + {k = 3: 0, 7: 1, 11: 2}, cls = 0 for C = 64, 1 for
+                          // C = 128, 2 for C >= 256
 bool wino8_wanted(int C, int KS) {
   if (!g_wino8 || !g_wino || C < g_wino_min_c || !wino8_supported(C, C, KS, 1)) return false;
   const int cls = C >= 256 ? 2 : C >= 128 ? 1 : 0;
-  return (g_wino8_mask >> (2 * cls + (KS == 11 ? 1 : 0))) & 1;
+  return (g_wino8_mask >> (3 * cls + (KS == 11 ? 2 : KS == 7 ? 1 : 0))) & 1;
 }
 
 // w: [C][C][KS] -> U[p][co][ci][j] = sum_i G[p][i] w[co][ci][j + NS i], packed in A-fragment order (make_wino's, 8 points)
@@ -591,15 +592,15 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
   }
   const int ns = (dc.KS + 2) / 3;
   // C = 64: k = 7 on 64 x 128 tiles, k = 11 on 64 x 64 tiles built for two workgroups per CU (measured per shape, tools/wino8_c64.py)
-  const int c64_mode = g_wino8_c64_wide == 3 ? (dc.KS == 11 ? 2 : 1) : g_wino8_c64_wide;
+  const int c64_mode = g_wino8_c64_wide == 3 ? (dc.KS == 7 ? 1 : 2) : g_wino8_c64_wide;
   // wave tile = workgroup tile: 128 rows x 64 columns for C >= 128, 64 x 128 ("wino8_c64_wide", default) or 64 x 64 for C = 64
 #define DISSC_W8(NS_, D_)                                                                            \
   if (ns == NS_ && dc.dil == D_)                                                                     \
-    return dc.M >= 128 ? launch_wino8_t<NS_, D_, 4, 2>(a, B, Lmax, stream)                         \
+    return dc.M >= 128 ? launch_wino8_t<NS_, D_, 4, 2>(a, B, Lmax, stream)                                                \
                        : (c64_mode == 1 ? launch_wino8_t<NS_, D_, 2, 4>(a, B, Lmax, stream)                  \
                           : c64_mode == 2 ? launch_wino8_t<NS_, D_, 2, 2, 4>(a, B, Lmax, stream)            \
                                           : launch_wino8_t<NS_, D_, 2, 2>(a, B, Lmax, stream));
-  DISSC_W8(3, 1) DISSC_W8(3, 3) DISSC_W8(3, 5) DISSC_W8(4, 1) DISSC_W8(4, 3) DISSC_W8(4, 5)
+  DISSC_W8(1, 1) DISSC_W8(1, 3) DISSC_W8(1, 5) DISSC_W8(3, 1) DISSC_W8(3, 3) DISSC_W8(3, 5) DISSC_W8(4, 1) DISSC_W8(4, 3) DISSC_W8(4, 5)
 #undef DISSC_W8
   set_error("run_wino8: k = %d, dilation %d unsupported", dc.KS, dc.dil);
   return DISSC_EINVAL;

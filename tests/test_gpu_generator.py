@@ -383,7 +383,7 @@ def _generator_with(lib, synth, **options):
         gd(code=torch.from_numpy(c1), f0=torch.from_numpy(f1), spkr=torch.from_numpy(s1))  # the native handle is built here
     finally:
         for k in options:
-            lib.dissc_set_option(k.encode(), {"pair_wino": 0, "wino": 1, "wino8": 1, "wino8_mask": 0x33}.get(k, saved.get(k, 0)))
+            lib.dissc_set_option(k.encode(), {"pair_wino": 0, "wino": 1, "wino8": 1, "wino8_mask": 0o606}.get(k, saved.get(k, 0)))
     return gd
 
 
@@ -481,7 +481,7 @@ def test_f63_generator_agrees_with_the_default_generator(env):
     lib, synth = env["lib"], env["synth"]
     gd = _generator_with(lib, synth, wino8=0)
     assert env["g"].flops_executed(1000) < gd.flops_executed(1000)
-    g8 = _generator_with(lib, synth, wino8=1, wino8_mask=63)
+    g8 = _generator_with(lib, synth, wino8=1, wino8_mask=0o777)
     assert g8.flops_executed(1000) < env["g"].flops_executed(1000) and g8.flops(1000) == gd.flops(1000)
     for code, f0, spkr, lengths in _pair_cases(synth):
         kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),

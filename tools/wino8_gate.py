@@ -37,7 +37,7 @@ if "check" in what:
     torch.manual_seed(0)
     worst = 0.0
     for C in (64, 128, 256):
-        for k in (7, 11):
+        for k in (3, 7, 11):
             for d in (1, 3, 5):
                 lens = [1000, 1, 7, 359, 360, 361, 613, 997]
                 ld = 1000
@@ -70,7 +70,7 @@ if "check" in what:
 if "time" in what:
     ms = ctypes.c_float()
     for C, Ls in ((256, 2500), (128, 10000), (64, 40000)):
-        for k in (7, 11):
+        for k in (3, 7, 11):
             for d in (1, 3, 5):
                 row = []
                 for epi in (0, 1, 3):
