@@ -385,7 +385,7 @@ def strong_leg(synth, g, dev, rank, world, dist, fake=False, reps=3):
         for n in [int(v) for v in emu.split(",") if v.strip()]:
             parts = harness.lpt_shard(lengths, n)
             bud = harness.overlap_budget(lengths, parts, None)   # the round cut of the N-rank run
-            rf = None if bud is None else bud * 320
+            rf = None if bud is None else ([b * 320 for b in bud] if isinstance(bud, list) else bud * 320)
             walls, spans, rounds = [], [], 0
             for r in range(n):
                 sub = [jobs[i] for i in parts[r]]
@@ -406,6 +406,7 @@ def strong_leg(synth, g, dev, rank, world, dist, fake=False, reps=3):
             out["emulated"][str(n)] = {
                 "share_wall_ms": [ms(v) for v in walls], "share_gpu_span_ms": [ms(v) for v in spans], "rounds": len(full),
                 "sent_bytes_per_rank": 4 * sum(harness.buffer_floats(a, b) for a, b in n_cap_dc),
+                "round_fractions": [round(sum(lengths[i] for p in sh for i in p) / float(sum(lengths)), 4) for sh in full],
                 "load_imbalance": round(float(harness.imbalance(lengths, parts)), 4)}
         out["emulated"]["what"] = ("each rank's share at N ranks (same partition, rounds and batches) computed alone in one "
                                    "process: host batching + H2D + generator + post-processing + ragged pack, no exchange")

@@ -79,17 +79,19 @@ def plan_rounds(lengths, parts, budget=None):
     """Cut every rank's share (longest first) into rounds of at most ``budget`` length units (a round
     always takes at least one job).  Every rank derives the same plan; the number of rounds is the
     maximum over ranks (a rank that runs out contributes empty rounds, it still joins the collectives).
-    Returns list[round] of list[world_size] of job-index lists.  ``budget`` None = one round."""
+    Returns list[round] of list[world_size] of job-index lists.  ``budget`` None = one round; a sequence = the
+    budgets of rounds 0, 1, ... (``overlap_budget``'s tapered cut; its last entry serves any further round)."""
+    seq = None if budget is None else ([int(b) for b in budget] if isinstance(budget, (list, tuple)) else [int(budget)])
     per_rank = []
     for p in parts:
         ids = sorted(p, key=lambda i: (-int(lengths[i]), i))
-        if budget is None:
+        if seq is None:
             per_rank.append([ids])
             continue
         rounds, cur, tot = [], [], 0
         for i in ids:
             n = int(lengths[i])
-            if cur and tot + n > budget:
+            if cur and tot + n > seq[min(len(rounds), len(seq) - 1)]:
                 rounds.append(cur)
                 cur, tot = [], 0
             cur.append(i)
@@ -660,21 +662,31 @@ def init_distributed(default_port, backend_env="DISSC_DIST_BACKEND"):
 
 OVERLAP_ROUND_FRAMES = 8000  # smallest round worth cutting for overlap: batches under ~4 000 frames lose > 10 %
 OVERLAP_MAX_ROUNDS = 4
+OVERLAP_MIN_LAST = 4000  # frames per rank the last (smallest) round of the taper must still hold
 
 
 def overlap_budget(lengths, parts, budget):
-    """Round budget (length units per rank and round) when rounds are delivered while the next one computes: a run that
-    would fit ONE round is still cut into up to OVERLAP_MAX_ROUNDS rounds of >= OVERLAP_ROUND_FRAMES frames per rank, so
-    that only the last round's exchange + device-to-host copy + sink is exposed.  Derived from the global job list:
-    every rank gets the same answer."""
+    """Round budgets (length units per rank and round) when rounds are delivered while the next one computes: a run that
+    would fit ONE round is still cut into up to OVERLAP_MAX_ROUNDS rounds of >= OVERLAP_ROUND_FRAMES frames per rank on
+    average, so that only the LAST round's exchange + device-to-host copy + sink is exposed -- and the rounds TAPER
+    (n : n - 1 : ... : 1 of the largest share), so that the exposed one is the smallest: with n rounds the tail is
+    2 / (n (n + 1)) of the run's delivery instead of 1 / n.  ``budget`` (the memory bound of a round, or None) caps every
+    entry.  Derived from the global job list: every rank gets the same answer.  Returns ``budget`` itself when the
+    run is too short to cut, else a list for plan_rounds."""
     share = max((sum(int(lengths[i]) for i in p) for p in parts), default=0)
     n = min(OVERLAP_MAX_ROUNDS, share // OVERLAP_ROUND_FRAMES)
+    while n >= 2 and share // (n * (n + 1) // 2) < OVERLAP_MIN_LAST:
+        n -= 1
     if n < 2:
         return budget
-    # plan_rounds closes a round when the next job would exceed the budget, so a round holds more than
-    # budget - longest job: with share / n + longest job as the budget there are at most n rounds
-    cut = -(-share // n) + max((int(v) for v in lengths), default=0)
-    return cut if budget is None else min(budget, cut)
+    # plan_rounds closes a round when the next job would exceed its budget, so a round holds between budget - longest
+    # job and budget: centred on the taper the first n - 1 rounds leave the last one its share give or take
+    # (n - 1) / 2 jobs; the last round takes whatever is left (up to the memory bound)
+    longest = max((int(v) for v in lengths), default=0)
+    tri = n * (n + 1) // 2
+    cuts = [-(-share * (n - k) // tri) + longest // 2 for k in range(n - 1)]
+    cuts.append(share if budget is None else int(budget))
+    return cuts if budget is None else [min(int(budget), c) for c in cuts]
 
 
 def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist=None, max_batch=128,
@@ -687,8 +699,8 @@ def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist
     sink receives are views of a reused page-locked buffer, valid until it returns).  ``own_rows=True``: every rank
     delivers the rows it decoded itself instead (Exchange).
     Rounds: one unless a rank's share exceeds ``round_floats`` output samples -- or, with a sink on a GPU
-    (``overlap``, default on), up to 4 rounds of >= 8 000 frames per rank, delivered by a worker thread WHILE the
-    next round computes (Exchange; with a sink the callback therefore runs on that thread).
+    (``overlap``, default on), up to 4 tapering rounds (>= 8 000 frames per rank on average), delivered by a worker
+    thread WHILE the next round computes (Exchange; with a sink the callback therefore runs on that thread).
     ``postprocess(wav[B,1,L], n_samples[B])`` runs on the GPU in place.  ``stats`` (a dict) is filled with
     per-rank timing and traffic figures."""
     import time
@@ -701,7 +713,10 @@ def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist
     dev = torch.device(device)
     cuda = dev.type == "cuda"
     ex = Exchange(rank, world_size, dev, dist, unpack_ranks, own_rows, sink, stats, overlap=overlap)
-    budget = None if round_floats is None else max(1, round_floats // hop)
+    if isinstance(round_floats, (list, tuple)):  # explicit per-round budgets (bench.py's emulation of an N-rank run)
+        budget = [max(1, int(f) // hop) for f in round_floats]
+    else:
+        budget = None if round_floats is None else max(1, round_floats // hop)
     if ex.overlap:
         budget = overlap_budget(lengths, parts, budget)
     rounds = plan_rounds(lengths, parts, budget)

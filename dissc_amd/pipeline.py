@@ -202,8 +202,8 @@ class Converter:
                               decode=lambda got: self._decode(got, target_ids), overlap=overlap)
         if ex.overlap:  # input frames (320 samples) as the length unit of the overlap rule
             b = harness.overlap_budget([n // 320 for n in n_samples], parts, None)
-            if b is not None:
-                budget = b * 320 if budget is None else min(budget, b * 320)
+            if b is not None:  # (a list: the tapered cut)
+                budget = [v * 320 if budget is None else min(budget, v * 320) for v in b]
         try:
             for shares in harness.plan_rounds(n_samples, parts, budget):
                 store = harness.WaveStore(self.generator.device)

@@ -202,7 +202,17 @@ def test_overlap_budget_rule():
         rounds = harness.plan_rounds(lengths, parts, b)
         assert len(rounds) == want, (world, len(rounds))
         assert sorted(i for sh in rounds for p in sh for i in p) == list(range(1024))
-    assert harness.overlap_budget(lengths, harness.lpt_shard(lengths, 1), 1000) == 1000  # a tighter budget wins
+        # the rounds taper (n : n - 1 : ... : 1): the exposed last one is the smallest, and still worth a batch
+        sizes = [max(sum(lengths[i] for i in p) for p in sh) for sh in rounds]
+        assert all(a >= b_ for a, b_ in zip(sizes, sizes[1:])), sizes
+        tri = want * (want + 1) // 2
+        assert harness.OVERLAP_MIN_LAST - 175 * want <= sizes[-1] <= sum(sizes) // tri + 175 * want, sizes
+    capped = harness.overlap_budget(lengths, harness.lpt_shard(lengths, 1), 1000)  # a tighter (memory) budget wins
+    assert capped == [1000] * 4
+    assert len(harness.plan_rounds(lengths, harness.lpt_shard(lengths, 1), capped)) == -(-1024 * 175 // (1000 // 175 * 175))
+    # a share just over the 4-round rule whose fourth round would be too small for a batch gets three
+    short = [100] * 330
+    assert len(harness.plan_rounds(short, [list(range(330))], harness.overlap_budget(short, [list(range(330))], None))) == 3
 
 
 def test_numa_cpu_assignment():

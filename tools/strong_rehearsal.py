@@ -19,8 +19,9 @@ One process runs `bench.py --strong-only` with DISSC_STRONG_EMULATE=<ns> and yie
 
 Model: rounds of one run are pipelined -- round k is delivered while round k + 1 computes -- so
 
-    T_N = max_r C_r  +  G_last + D / R_N            (exposed tail = the last round's gather + delivery)
-    T_N >= C_first + sum G + D                       (delivery-bound floor: rank 0 cannot deliver faster than D)
+    T_N = max_r C_r  +  f_last (G + D)              (exposed tail = the last round's gather + delivery; f_k = round k's
+                                                      share of the payload -- rounds taper, the last is the smallest)
+    T_N >= f_first max_r C_r + G + D                 (delivery-bound floor: rank 0 cannot deliver faster than D)
 
 with C_r the solo wall of rank r's share, R_N the rounds of the run, G a modelled RCCL all-gather of the round's
 exchange buffers at XGMI_RING_GBPS (bench.py; conservative single-ring figure).  Efficiency_N = T_1 / (N * T_N).
@@ -68,11 +69,11 @@ def model(one, xgmi_gbps):
         n = int(key)
         solo, rounds, sent = e["share_wall_ms"], e["rounds"], e["sent_bytes_per_rank"]
         g_total = sent * (n - 1) / (xgmi_gbps * 1e9) * 1e3 if n > 1 else 0.0   # ring: every rank receives (N-1) buffers
-        g_last = g_total / rounds
+        frac = e.get("round_fractions") or [1.0 / rounds] * rounds   # rounds taper: the last one is the smallest
         c_max = max(solo)
-        tail = g_last + d_total / rounds
+        tail = (g_total + d_total) * frac[-1]
         t_pipe = c_max + tail
-        t_floor = c_max / rounds + g_total + d_total           # delivery-bound floor
+        t_floor = c_max * frac[0] + g_total + d_total          # delivery-bound floor
         t_n = max(t_pipe, t_floor)
         per_n[key] = {
             "predicted_wall_ms": round(t_n, 2), "predicted_speedup": round(t1 / t_n, 3),
@@ -82,7 +83,7 @@ def model(one, xgmi_gbps):
             "sum_solo_compute_ms": round(sum(solo), 2),
             "exposed_tail_ms": round(tail, 2), "modelled_allgather_ms_total": round(g_total, 2),
             "delivery_ms_total": round(d_total, 2), "delivery_bound": bool(t_floor > t_pipe),
-            "load_imbalance": e["load_imbalance"],
+            "load_imbalance": e["load_imbalance"], "round_fractions": frac,
         }
     return {"what": "strong-scaling prediction from a one-GPU rehearsal (tools/strong_rehearsal.py; model: DESIGN.md section 7)",
             "jobs": one["jobs"], "audio_sec": one["audio_sec"], "payload_bytes": one["exchange"]["payload_bytes_this_rank"],
