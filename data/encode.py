@@ -57,6 +57,32 @@ def wav_frames(path):
 _TRACKER = {}
 
 
+class _Timing:
+    """DISSC_CLI_TIMING=1 (tools/encode_wall.py): seconds per phase, printed as one `CLI_TIMING {json}` line at exit"""
+
+    def __init__(self):
+        self.on = os.environ.get('DISSC_CLI_TIMING') == '1'
+        self.acc = {}
+        if self.on:
+            import time
+
+            import psutil
+            self.now = time.time
+            self.last = psutil.Process().create_time()
+            self.add('imports')
+
+    def add(self, name):
+        if self.on:
+            t = self.now()
+            self.acc[name + '_s'] = self.acc.get(name + '_s', 0.0) + t - self.last
+            self.last = t
+
+    def dump(self, **extra):
+        if self.on:
+            out = {k: round(v, 4) for k, v in self.acc.items()}
+            print('CLI_TIMING ' + json.dumps(dict(out, total_s=round(sum(self.acc.values()), 4), **extra)), flush=True)
+
+
 def track_f0(wav, ns, frames, args):
     """F0 per unit frame for a batch: YAAPT at a 5 ms hop on the GPU (dissc_amd/f0.py), then the
     mean of the voiced values of each 20 ms unit -- list of lists of Hz, 0.0 = unvoiced."""
@@ -68,6 +94,7 @@ def track_f0(wav, ns, frames, args):
 
 
 def main(argv=None):
+    tm = _Timing()
     parser = argparse.ArgumentParser()
     parser.add_argument('--model_name', default='hubert-base-ls960', help='Name for pretrained dense model name')
     parser.add_argument('--quantizer_name', default='kmeans', help='Name for quantising the hidden units')
@@ -91,6 +118,7 @@ def main(argv=None):
                                     vocab_size=args.vocab_size, deduplicate=False,
                                     checkpoint_dir=args.checkpoint_dir).to(args.device)
     os.makedirs(Path(args.out_file).parent.absolute(), exist_ok=True)
+    tm.add('encoder_load')
     files = os.listdir(args.base_dir)
     # Pass 1: sample counts only (wav headers), so the batches can be formed without holding every
     # waveform in memory; pass 2 loads one batch at a time.
@@ -131,6 +159,7 @@ def main(argv=None):
         if where:
             print(f"resuming from {partial}: {len(where)} of {len(lengths)} files already encoded")
     order = [f for f in order if f not in where]
+    tm.add('scan_headers')
     i = 0
     while i < len(order):
         n0 = lengths[order[i]]
@@ -144,9 +173,12 @@ def main(argv=None):
         for k, x in enumerate(xs):
             wav[k, :len(x)] = x
         del xs
+        tm.add('read_wavs')
         out = encoder.model(torch.from_numpy(wav), n_samples=torch.from_numpy(ns), want_dense=False)
         units = out["units"].cpu()
+        tm.add('hubert_units')
         f0s = track_f0(wav, ns, [int(t) for t in out["frames"]], args) if args.f0 == 'yaapt' else None
+        tm.add('f0')
         with open(partial, 'ab') as fo:
             for k, f in enumerate(batch):
                 T = int(out["frames"][k])
@@ -155,6 +187,7 @@ def main(argv=None):
                 raw = (json.dumps({"units": u, "f0": f0, "durations": [1] * T, "audio": f}) + "\n").encode()
                 where[f] = (fo.tell(), len(raw))
                 fo.write(raw)
+        tm.add('json_lines')
     if where:
         with open(args.out_file, 'ab') as fo, open(partial, 'rb') as fi:
             for f in files:
@@ -163,6 +196,8 @@ def main(argv=None):
                     fo.write(fi.read(where[f][1]))
     if os.path.exists(partial):
         os.remove(partial)
+    tm.add('ordered_manifest')
+    tm.dump(files=len(where))
 
 
 if __name__ == '__main__':
