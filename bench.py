@@ -652,14 +652,14 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": hbm_traffic(B, T)[0], "traffic_source": hbm_traffic(B, T)[1],
-                         "kernel": "all generator convs: conv_wino_kernel / conv_wino8_kernel (Toom-Cook F(4,3) on 12-wave and F(6,3) on 8-wave "
-                                   "workgroups over 3-tap sub-filters, fp32 v_mfma_f32_32x32x2) on the ResBlocks of the C >= 64 stages, "
+                         "kernel": "all generator convs: conv_wino_kernel / conv_wino8_kernel (Toom-Cook F(4,3) on 12-wave workgroups, F(6,3) and "
+                                   "F(5,4) on 8-wave workgroups, over 3- or 4-tap sub-filters, fp32 v_mfma_f32_32x32x2) on the ResBlocks of the C >= 64 stages, "
                                    "conv_mfma32_kernel (direct, same MFMA) for conv_pre and the ConvTranspose layers, respair32/respair16 "
                                    "fused residual pairs on the C = 32 / 16 stages",
                          "algorithmic_tflops": round(ach_alg, 2),
                          "algorithmic_frac": round(ach_alg / FP32_MFMA_PEAK_TFLOPS, 4),
                          "note": "achieved / frac = EXECUTED matrix-pipe FLOPs / time (<= peak by construction; the Toom-Cook layers "
-                                 "execute 6 ceil(k/3) / 4 -- F(4,3) -- or 8 ceil(k/3) / 6 -- F(6,3) -- products per output instead of k); algorithmic_tflops / algorithmic_frac = "
+                                 "execute 6 ceil(k/3) / 4 -- F(4,3) --, 8 ceil(k/3) / 6 -- F(6,3) -- or 8 ceil(k/4) / 5 -- F(5,4) -- products per output instead of k); algorithmic_tflops / algorithmic_frac = "
                                  "direct-form FLOPs (SURVEY 8d: 321.664 MFLOP per frame) / time -- an effective rate, not pipe utilisation",
                          "flops_per_step": flops_step, "flops_executed": flops_exec,
                          "kernel_ms_per_step": round(kern_s * 1e3, 3)},

@@ -168,7 +168,8 @@ struct DevConv {
   int m32 = 0;              // packed for the 32x32x2 kernel
   int prec = 0;             // 1: packed as split-bf16 hi/lo fragments
   double macs_per_t = 0;  // MACs per input time step (algorithmic, zero taps excluded)
-  int wino = 0;           // 1: packed for conv_wino_kernel (Toom-Cook F(4,3) transform-domain weights), 2: for conv_wino8_kernel (F(6,3))
+  int wino = 0;           // 1: packed for conv_wino_kernel (Toom-Cook F(4,3) transform-domain weights), 2: for conv_wino8_kernel
+  int wr = 3;             // conv_wino8_kernel: taps per sub-filter (3: F(6,3), 4: F(5,4))
 };
 // Per-call extras of run_conv_ex (strided / valid convolutions with their own output lengths).
 struct ConvIO {
@@ -217,9 +218,13 @@ extern int g_wino8_dbg;
 extern int g_wino8_c64_wide;
 extern int g_wino8_mask;
 bool wino8_supported(int Cout, int Cin, int KS, int dil);
-bool wino8_wanted(int C, int KS);
-int make_wino8(const float* w, const float* bias, int C, int KS, int dil, DevConv& dc);  // sets dc.wino = 2
-double wino8_executed_macs_per_t(int C, int KS);
+bool wino8_wanted(int C, int KS, int dil);
+extern int g_wino8_r4;   // "wino8_r4" option: the eight points as F(5,4) (4-tap sub-filters) where wino8_r4_mask says so
+extern int g_wino8_r4_mask;
+bool wino8_r4_supported(int C, int KS, int dil);
+int wino8_taps(int C, int KS, int dil);  // 3 or 4: the generator's policy for a wino8 layer
+int make_wino8(const float* w, const float* bias, int C, int KS, int dil, DevConv& dc, int R = 3);  // sets dc.wino = 2, dc.wr = R
+double wino8_executed_macs_per_t(int C, int KS, int R);
 int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, float* acc, const int32_t* lengths,
               int len_default, int len_mul, int B, int ldx, int ldo, int Lmax, float slope, int epi, float mrf_div,
               hipStream_t stream);

@@ -19,6 +19,10 @@
 // channels for its point (8 neighbouring samples = four aligned 8-byte reads) into a private tile; A fragments streamed
 // from L2 one tap ahead; epilogue: the 8 waves exchange Y_p through LDS 32 rows at a time, one thread applies A^T, bias
 // and the residual / MRF mode to 4 consecutive outputs.
+// R = 4 (template parameter; "wino8_r4" option): the same eight points used as F(5,4) -- FIVE outputs of a FOUR-tap sub-filter
+// from the same 8 products, NS = ceil(k / 4): 8 NS / 5 = 3.2 products per output for k = 7 (4.0 as F(6,3), 7 direct), 4.8 for
+// k = 11 (5.33 / 11).  B^T depends on the points only, so the transform is the same; a unit advances 5 D samples instead of
+// 6 D (its 8-byte window reads are then only 4-byte aligned), G has a fourth column and A^T five rows.
 // Rounding: per layer 1.8x the F(4,3) form's error (numpy model of a C = 256 layer, k = 11: rms 1.5e-7 vs 8.3e-8 on O(0.3)
 // outputs, direct 9.3e-8); DESIGN.md section 4.
 #include <string.h>
@@ -60,15 +64,16 @@ struct Wino8Args {
   int gx, gy, B;  // time tiles, row tiles, utterances
 };
 
-// G rows of F(6,3) at the points 0, 1, -1, 2, -2, 1/2, -1/2, inf (host, double); B^T and A^T are written out below
-static const double kW8G[8][3] = {{-1.0, 0.0, 0.0},
-                                  {-2.0 / 9.0, -2.0 / 9.0, -2.0 / 9.0},
-                                  {-2.0 / 9.0, 2.0 / 9.0, -2.0 / 9.0},
-                                  {1.0 / 90.0, 1.0 / 45.0, 2.0 / 45.0},
-                                  {1.0 / 90.0, -1.0 / 45.0, 2.0 / 45.0},
-                                  {32.0 / 45.0, 16.0 / 45.0, 8.0 / 45.0},
-                                  {32.0 / 45.0, -16.0 / 45.0, 8.0 / 45.0},
-                                  {0.0, 0.0, 1.0}};
+// G (host, double) at the points 0, 1, -1, 2, -2, 1/2, -1/2, inf: row p = scale_p * (1, x_p, x_p^2 [, x_p^3]) for the finite points,
+// the last unit vector for inf -- three columns as F(6,3), four as F(5,4); B^T and A^T are written out below
+static const double kW8Pt[7] = {0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5};
+static const double kW8Scale[7] = {-1.0, -2.0 / 9.0, -2.0 / 9.0, 1.0 / 90.0, 1.0 / 90.0, 32.0 / 45.0, 32.0 / 45.0};
+static double w8_g(int p, int i, int R) {
+  if (p == 7) return i == R - 1 ? 1.0 : 0.0;
+  double v = kW8Scale[p];
+  for (int e = 0; e < i; ++e) v *= kW8Pt[p];
+  return v;
+}
 
 // row P of B^T (all entries exactly representable) applied to eight neighbouring samples
 template <int P>
@@ -86,21 +91,22 @@ __device__ __forceinline__ float w8_bt(float r0, float r1, float r2, float r3, f
 
 constexpr int w8_rup(int n, int m) { return (n + m - 1) / m * m; }
 
-// polyphase row length >= need (even): lane = tau * D + phi of the transform reads 8 bytes at float offset phi * RL + 6 tau
+// polyphase row length >= need (even): lane = tau * D + phi of the transform reads 8 bytes at float offset phi * RL + MO tau
 // (+ 2 q); a ds_read_b64 is serviced 32 lanes at a time over 64 banks of 4 bytes -- pick the RL (<= need + 62) whose worst
 // 32-lane group touches the fewest lanes per bank pair
-constexpr int w8_row_len(int D, int NTU, int need) {
+constexpr int w8_row_len(int D, int NTU, int need, int MO) {
   int best = need, best_cost = 1 << 30;
   for (int rl = need; rl <= need + 62; rl += 2) {
     int cost = 0;
     for (int g0 = 0; g0 < 64; g0 += 32) {
-      int cnt[32] = {0};
+      int cnt[64] = {0};  // lanes per 4-byte bank (MO = 5: the reads start on odd floats too)
       for (int l = g0; l < g0 + 32; ++l) {
         const int c = l < NTU * D ? l : NTU * D - 1;
-        const int slot = (((c % D) * rl + 6 * (c / D)) / 2) % 32;
-        ++cnt[slot];
+        const int at = (c % D) * rl + MO * (c / D);
+        ++cnt[at % 64];
+        ++cnt[(at + 1) % 64];
       }
-      for (int i = 0; i < 32; ++i)
+      for (int i = 0; i < 64; ++i)
         if (cnt[i] > cost) cost = cnt[i];
     }
     if (cost < best_cost) { best_cost = cost; best = rl; }
@@ -111,21 +117,25 @@ constexpr int w8_row_len(int D, int NTU, int need) {
 
 // WPS: waves per SIMD the instance is built for -- 2: one 8-wave workgroup per CU (up to 256 registers); 4: TWO workgroups
 // per CU (<= 128 registers and <= 80 KB of LDS each: windows of 8 channels, epilogue passes of 16 rows), whose phases overlap
-template <int NS, int DIL, int MI, int NI, int WPS = 2>
+// R: taps per sub-filter (3: F(6,3), 4: F(5,4)); MO = 9 - R outputs per unit
+template <int NS, int DIL, int MI, int NI, int WPS = 2, int R = 3>
 struct Wino8Geo {
   static constexpr int NTH = 512;
+  static constexpr int MO = 9 - R;
   static constexpr int D = DIL * NS, W = DIL * (2 * NS - 1);
   static constexpr int NCW = 32 * NI;
   static constexpr int NTU0 = NCW / D;
-  static constexpr int NTU = (D % 2 == 1 && NTU0 % 2 == 1) ? NTU0 - 1 : NTU0;  // (an odd D takes an even unit count: OT % 4 == 0)
+  // units per tile.  F(6,3): an odd D takes an even count, so that the tile is a whole number of output quads; F(5,4) takes
+  // them all (8 tiles instead of 9 on a 2 500-sample row) and stores the quads it shares with its neighbours element by element
+  static constexpr int NTU = (R == 3 && D % 2 == 1 && NTU0 % 2 == 1) ? NTU0 - 1 : NTU0;
   static constexpr int NCOL = NTU * D;
-  static constexpr int OT = 6 * D * NTU;               // outputs per workgroup tile
-  static constexpr int RAW = OT + D + W;                // input samples the transforms touch
+  static constexpr int OT = MO * D * NTU;              // outputs per workgroup tile
+  static constexpr int RAW = OT + (R - 2) * D + W;      // input samples the transforms touch: units of MO D, 8 samples D apart, W entries
   static constexpr int XRW = w8_rup(RAW + 3 + 3, 4);    // staged positions per channel (alignment shift <= 3)
   static constexpr int NV = XRW / 4;
-  static constexpr int OFF = 2;                         // polyphase index offset: window sample x at [(x + OFF D) % D][(x + OFF D) / D]
-  static constexpr int RL_MIN = w8_rup(((XRW - 1 + OFF * D) / D + 1) > (6 * NTU + OFF + 10) ? ((XRW - 1 + OFF * D) / D + 1) : (6 * NTU + OFF + 10), 2);
-  static constexpr int RL = w8_row_len(D, NTU, RL_MIN);  // bumped so that the 8-byte transform reads of a half wave spread over the banks
+  static constexpr int OFF = D >= 2 ? 2 : 4;            // polyphase index offset (even, OFF D >= 3): window sample x at [(x + OFF D) % D][(x + OFF D) / D]
+  static constexpr int RL_MIN = w8_rup(((XRW - 1 + OFF * D) / D + 1) > (MO * NTU + OFF + 10) ? ((XRW - 1 + OFF * D) / D + 1) : (MO * NTU + OFF + 10), 2);
+  static constexpr int RL = w8_row_len(D, NTU, RL_MIN, MO);  // bumped so that the 8-byte transform reads of a half wave spread over the banks
   static constexpr int CHF = D * RL;
   static constexpr int CPR = (NI == 4 || WPS == 4) ? 8 : 16;   // channels of the window per round (LDS budget)
   static constexpr int RPP = (NI == 4 || WPS == 4) ? 16 : 32;  // rows per epilogue pass (likewise)
@@ -135,17 +145,17 @@ struct Wino8Geo {
   static constexpr int WIN_FLOATS = 2 * CPR * CHF;
   static constexpr int V_FLOATS = 8 * 8 * XV;
   static constexpr int Y_FLOATS = 8 * RPP * YS;
-  static constexpr int OS = OT + 4;                     // row stride of the epilogue's output tile (16-byte aligned rows)
+  static constexpr int OS = w8_rup(OT, 4) + 4;          // row stride of the epilogue's output tile (16-byte aligned rows)
   static constexpr int EPI_FLOATS = Y_FLOATS + RPP * OS;
   static constexpr int LDS_FLOATS = (WIN_FLOATS + V_FLOATS) > EPI_FLOATS ? (WIN_FLOATS + V_FLOATS) : EPI_FLOATS;
-  static_assert(NTU >= 1 && NTU * W <= XV && OT % 4 == 0 && RL % 2 == 0, "tile geometry");
+  static_assert(NTU >= 1 && NTU * W <= XV && RL % 2 == 0, "tile geometry");
   static_assert(LDS_FLOATS * 4 <= (WPS == 4 ? 80 : 160) * 1024, "LDS");
 };
 
-template <int NS, int DIL, int MI, int NI, int WPS = 2>
+template <int NS, int DIL, int MI, int NI, int WPS = 2, int R = 3>
 __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a) {
-  using G = Wino8Geo<NS, DIL, MI, NI, WPS>;
-  constexpr int NTH = G::NTH, D = G::D, W = G::W, NCW = G::NCW, NTU = G::NTU, NCOL = G::NCOL, OT = G::OT, NV = G::NV, RL = G::RL,
+  using G = Wino8Geo<NS, DIL, MI, NI, WPS, R>;
+  constexpr int NTH = G::NTH, D = G::D, W = G::W, NCOL = G::NCOL, OT = G::OT, NV = G::NV, RL = G::RL, MO = G::MO,
                 CHF = G::CHF, CPR = G::CPR, XV = G::XV, YS = G::YS, OFF = G::OFF, RPP = G::RPP, CG = G::CG;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const vbuf = lds + G::WIN_FLOATS;  // [8 waves][8][XV]
@@ -228,7 +238,7 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool ok = (t + e) >= 0 && (t + e) < len;
-          const int xs = 4 * v + e - sh + OFF * D;  // >= OFF D - 3 >= 0 (D >= 3)
+          const int xs = 4 * v + e - sh + OFF * D;  // >= OFF D - 3 >= 0
           rowp[(xs % D) * RL + xs / D] = ok ? lrelu(val[e], slope) : 0.f;
         }
       }
@@ -239,7 +249,7 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
   };
 
   // ---- transform: lane <-> column (tau, phi) (+ 64 per column group); entries w = phi and w = phi + D of unit tau: samples
-  // 6 tau + OFF (+ 1) + q
+  // MO tau + OFF (+ 1) + q
   int toff[CG], e0[CG], e1[CG];
   bool ok1[CG];
 #pragma unroll
@@ -247,13 +257,13 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
     const int c0 = lane + 64 * g;
     const int tcol = c0 < NCOL ? c0 : NCOL - 1;
     const int ttau = tcol / D, tphi = tcol % D;
-    toff[g] = tphi * RL + 6 * ttau + OFF;  // even: 8-byte aligned reads
+    toff[g] = tphi * RL + MO * ttau + OFF;  // F(6,3): even, 8-byte aligned reads
     e0[g] = ttau * W + tphi;
     ok1[g] = tphi + D < W;
     e1[g] = ok1[g] ? e0[g] + D : e0[g];
   }
   float* const vp = vbuf + p * (8 * XV);
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2a __attribute__((ext_vector_type(2)));
   auto transform8 = [&](const float* raw8) __attribute__((always_inline)) {
     if (a.dbg & 1) return;
     auto go = [&](auto pc) __attribute__((always_inline)) {
@@ -263,8 +273,13 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
 #pragma unroll
         for (int g = 0; g < CG; ++g) {
           const float* rw = raw8 + i * CHF + toff[g];
-          const f32x2 q0 = *reinterpret_cast<const f32x2*>(rw), q1 = *reinterpret_cast<const f32x2*>(rw + 2),
-                      q2 = *reinterpret_cast<const f32x2*>(rw + 4), q3 = *reinterpret_cast<const f32x2*>(rw + 6);
+          f32x2a q0, q1, q2, q3;
+          if constexpr (MO % 2 == 0) {
+            q0 = *reinterpret_cast<const f32x2a*>(rw); q1 = *reinterpret_cast<const f32x2a*>(rw + 2);
+            q2 = *reinterpret_cast<const f32x2a*>(rw + 4); q3 = *reinterpret_cast<const f32x2a*>(rw + 6);
+          } else {  // (F(5,4): units start on odd floats too -- scalar reads, which the compiler pairs as far as 4-byte alignment allows)
+            q0[0] = rw[0]; q0[1] = rw[1]; q1[0] = rw[2]; q1[1] = rw[3]; q2[0] = rw[4]; q2[1] = rw[5]; q3[0] = rw[6]; q3[1] = rw[7];
+          }
           const float v0 = w8_bt<P>(q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]);
           vp[i * XV + e0[g]] = v0;
           if constexpr (NS > 1) {
@@ -381,9 +396,15 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
   const int epi = a.epi;
   const size_t ob = (size_t)b * a.o_bstride;
   constexpr int OS = G::OS;
-  constexpr int NQ = RPP * (OT / 4), NIT = (NQ + NTH - 1) / NTH;
+  // Output quads are aligned in ABSOLUTE time.  A tile of OT outputs with OT % 4 != 0 (F(5,4) with an odd unit count) starts
+  // qsh = t0 & 3 samples into its first quad: that quad and the last one are shared with the neighbouring tiles and stored
+  // element by element, the full ones read their four values from the output tile with 4-byte reads.
+  constexpr bool AL = OT % 4 == 0;
+  constexpr int QPR = AL ? OT / 4 : (OT + 3) / 4 + 1;  // quads a row can touch
+  constexpr int NQ = RPP * QPR, NIT = (NQ + NTH - 1) / NTH;
+  const int qsh = AL ? 0 : (t0 & 3);
+  const int tend = (t0 + OT < len) ? t0 + OT : len;     // this tile's outputs: [t0, tend)
   constexpr int NCI = RPP * NCOL, NCT = (NCI + NTH - 1) / NTH;
-  static_assert(OT % 4 == 0, "a tile is a whole number of output quads");
   constexpr int PS = RPP * YS;  // point stride
   constexpr int NPASS = 32 * MI / RPP;
 #pragma unroll
@@ -398,9 +419,9 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * NTH;
-        const int row = idx / (OT / 4), qi = idx - row * (OT / 4);
-        const int n0 = t0 + 4 * qi;
-        if (idx < NQ && n0 + 4 <= len)
+        const int row = idx / QPR, qi = idx - row * QPR;
+        const int n0 = t0 - qsh + 4 * qi;
+        if (idx < NQ && n0 >= t0 && n0 + 4 <= tend)
           pres[it] = *reinterpret_cast<const f32x4*>(a.res + ob + (size_t)(mt * (32 * MI) + ps * RPP + row) * a.ldo + n0);
       }
     }
@@ -426,28 +447,40 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
       const float y0 = yc[0], y1 = yc[PS], y2 = yc[2 * PS], y3 = yc[3 * PS], y4 = yc[4 * PS], y5 = yc[5 * PS], y6 = yc[6 * PS],
                   y7 = yc[7 * PS];
       const float s12 = y1 + y2, d12 = y1 - y2, s34 = y3 + y4, d34 = y3 - y4, s56 = y5 + y6, d56 = y5 - y6;
-      float* op = ot + row * OS + 6 * D * tau + rho;
+      float* op = ot + row * OS + MO * D * tau + rho;
       op[0] = (y0 + s12) + (s34 + s56);
       op[D] = fmaf(2.f, d34, fmaf(0.5f, d56, d12));
       op[2 * D] = fmaf(4.f, s34, fmaf(0.25f, s56, s12));
       op[3 * D] = fmaf(8.f, d34, fmaf(0.125f, d56, d12));
-      op[4 * D] = fmaf(16.f, s34, fmaf(0.0625f, s56, s12));
-      op[5 * D] = fmaf(32.f, d34, fmaf(0.03125f, d56, d12)) + y7;
+      if constexpr (MO == 6) {
+        op[4 * D] = fmaf(16.f, s34, fmaf(0.0625f, s56, s12));
+        op[5 * D] = fmaf(32.f, d34, fmaf(0.03125f, d56, d12)) + y7;
+      } else {  // F(5,4): the point at infinity belongs to the fifth (last) output
+        op[4 * D] = fmaf(16.f, s34, fmaf(0.0625f, s56, s12)) + y7;
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = tid + it * NTH;
       if (idx >= NQ) continue;
-      const int row = idx / (OT / 4), qi = idx - row * (OT / 4);
-      const int n0 = t0 + 4 * qi;
-      if (n0 >= len) continue;
+      const int row = idx / QPR, qi = idx - row * QPR;
+      const int n0 = t0 - qsh + 4 * qi;
+      const int lo = n0 > t0 ? n0 : t0, hi = n0 + 4 < tend ? n0 + 4 : tend;  // this tile's elements of the quad: [lo, hi)
+      if (hi <= lo) continue;
       const int grow = mt * (32 * MI) + ps * RPP + row;
       const float bz = a.bias[grow];
-      f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * OS + 4 * qi);
+      f32x4 v;
+      if constexpr (AL) {
+        v = *reinterpret_cast<const f32x4*>(ot + row * OS + 4 * qi);
+      } else {
+        const float* src = ot + row * OS + (4 * qi - qsh);  // (elements outside [lo, hi) are read as far as the row reaches, never used)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (4 * qi - qsh + e >= 0) ? src[e] : 0.f;
+      }
       v[0] += bz; v[1] += bz; v[2] += bz; v[3] += bz;
       const size_t ix = ob + (size_t)grow * a.ldo + n0;
-      if (n0 + 4 <= len) {
+      if (hi - lo == 4) {
         if (epi == EPI_STORE) {
           *reinterpret_cast<f32x4*>(a.out + ix) = v;
         } else {
@@ -468,7 +501,7 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
           }
         }
       } else {
-        for (int e = 0; e < len - n0; ++e) {
+        for (int e = lo - n0; e < hi - n0; ++e) {
           float x = v[e];
           if (epi == EPI_STORE) {
             a.out[ix + e] = x;
@@ -498,18 +531,39 @@ bool wino8_supported(int Cout, int Cin, int KS, int dil) {
          (dil == 1 || dil == 3 || dil == 5);
 }
 
-int g_wino8_mask = 0606;  // "wino8_mask" option (octal digits = classes; default: k = 7 / 11 at C = 64 and C >= 256): which (stage width,
-                          // kernel size) pairs the generator uses it for -- bit 3 * cls + {k = 3: 0, 7: 1, 11: 2}, cls = 0 for C = 64, 1 for
-                          // C = 128, 2 for C >= 256
-bool wino8_wanted(int C, int KS) {
-  if (!g_wino8 || !g_wino || C < g_wino_min_c || !wino8_supported(C, C, KS, 1)) return false;
+// Which form a ResBlock conv of the C >= 64 stages takes is decided per SHAPE (stage width class, kernel size, dilation), from the
+// per-launch measurements of tools/wino8_gate.py and same-box forward A/Bs (tools/opt_ab.sh): bit 9 cls + 3 ki + di with
+// cls = 0 / 1 / 2 for C = 64 / 128 / >= 256, ki = 0 / 1 / 2 for k = 3 / 7 / 11, di = 0 / 1 / 2 for dilation 1 / 3 / 5 -- in octal
+// three digits per class (k = 11, k = 7, k = 3 from the left), each digit = the dilations d5 d3 d1.
+static int w8_shape_bit(int C, int KS, int dil) {
   const int cls = C >= 256 ? 2 : C >= 128 ? 1 : 0;
-  return (g_wino8_mask >> (3 * cls + (KS == 11 ? 2 : KS == 7 ? 1 : 0))) & 1;
+  return 9 * cls + 3 * (KS == 11 ? 2 : KS == 7 ? 1 : 0) + (dil == 1 ? 0 : dil == 3 ? 1 : 2);
+}
+int g_wino8_mask = 0770670770;  // "wino8_mask" option: the shapes that run on conv_wino8_kernel (the others stay on conv_wino's F(4,3)) --
+                                // default: k = 7 / 11 everywhere except C = 128, k = 11, d = 1
+bool wino8_wanted(int C, int KS, int dil) {
+  if (!g_wino8 || !g_wino || C < g_wino_min_c || !wino8_supported(C, C, KS, dil)) return false;
+  return (g_wino8_mask >> w8_shape_bit(C, KS, dil)) & 1;
 }
 
-// w: [C][C][KS] -> U[p][co][ci][j] = sum_i G[p][i] w[co][ci][j + NS i], packed in A-fragment order (make_wino's, 8 points)
-int make_wino8(const float* w, const float* bias, int C, int KS, int dil, DevConv& dc) {
-  const int NS = (KS + 2) / 3;
+int g_wino8_r4 = 1;        // "wino8_r4" option (read at dissc_gen_create): 1 = the layers "wino8_r4_mask" names run the eight points as
+                           // F(5,4) (k = 7: 2 sub-filters of 4 taps, k = 11: 3) instead of F(6,3); 2 = dissc_conv1d too (tests); 0 = never
+int g_wino8_r4_mask = 0770670010;  // "wino8_r4_mask" option, same bit layout as wino8_mask (k = 3 bits ignored) -- default: every wino8 shape
+                                   // of the C >= 128 stages, and k = 7, d = 1 at C = 64 (the rest of that stage is faster as F(6,3))
+bool wino8_r4_supported(int C, int KS, int dil) { return wino8_supported(C, C, KS, dil) && (KS == 7 || KS == 11); }
+int wino8_taps(int C, int KS, int dil) {  // taps per sub-filter the generator's policy picks for a wino8 layer
+  if (!g_wino8_r4 || !wino8_r4_supported(C, KS, dil)) return 3;
+  return ((g_wino8_r4_mask >> w8_shape_bit(C, KS, dil)) & 1) ? 4 : 3;
+}
+
+// w: [C][C][KS] -> U[p][co][ci][j] = sum_i G[p][i] w[co][ci][j + NS i], packed in A-fragment order (make_wino's, 8 points);
+// R = taps per sub-filter (3: F(6,3), 4: F(5,4)), NS = ceil(KS / R)
+int make_wino8(const float* w, const float* bias, int C, int KS, int dil, DevConv& dc, int R) {
+  if (R != 3 && !(R == 4 && wino8_r4_supported(C, KS, dil))) {
+    set_error("make_wino8: no instance with %d-tap sub-filters for C = %d, k = %d, dilation %d", R, C, KS, dil);
+    return DISSC_EINVAL;
+  }
+  const int NS = (KS + R - 1) / R;
   if (C % 32 != 0 || C % KC != 0) {
     set_error("make_wino8: C = %d is not a multiple of the row tile", C);
     return DISSC_EINVAL;
@@ -526,9 +580,9 @@ int make_wino8(const float* w, const float* bias, int C, int KS, int dil, DevCon
               for (int e = 0; e < 4; ++e) {
                 const int co = ms * 32 + (lane & 31), ci = c * KC + 8 * hf + 2 * e + (lane >> 5);
                 double u = 0.0;
-                for (int i = 0; i < 3; ++i) {
+                for (int i = 0; i < R; ++i) {
                   const int tap = j + NS * i;
-                  if (tap < KS) u += kW8G[p][i] * (double)w[((size_t)co * C + ci) * KS + tap];
+                  if (tap < KS) u += w8_g(p, i, R) * (double)w[((size_t)co * C + ci) * KS + tap];
                 }
                 packed[o++] = (float)u;
               }
@@ -538,20 +592,21 @@ int make_wino8(const float* w, const float* bias, int C, int KS, int dil, DevCon
   dc.groups = 1; dc.Mpad = C; dc.stride = 1; dc.pad_left = -1; dc.m32 = 1; dc.prec = 0;
   dc.macs_per_t = (double)C * C * KS;  // algorithmic (direct-form) MACs
   dc.wino = 2;
+  dc.wr = R;
   int rc = upload(packed, &dc.wpack);
   if (rc) return rc;
   return upload(b, &dc.bias);
 }
 
-// MACs the matrix pipe executes per output position (8 NS / 6 per input/output channel pair)
-double wino8_executed_macs_per_t(int C, int KS) { return (double)C * C * 8.0 * ((KS + 2) / 3) / 6.0; }
+// MACs the matrix pipe executes per output position: 8 NS / (9 - R) per input/output channel pair
+double wino8_executed_macs_per_t(int C, int KS, int R) { return (double)C * C * 8.0 * ((KS + R - 1) / R) / (9.0 - R); }
 
-template <int NS, int DIL, int MI, int NI, int WPS = 2>
+template <int NS, int DIL, int MI, int NI, int WPS = 2, int R = 3>
 static int launch_wino8_t(const Wino8Args& a, int B, int Lmax, hipStream_t stream) {
-  using G = Wino8Geo<NS, DIL, MI, NI, WPS>;
+  using G = Wino8Geo<NS, DIL, MI, NI, WPS, R>;
   static bool attr_done = false;
   if (!attr_done) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<NS, DIL, MI, NI, WPS>),
+    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<NS, DIL, MI, NI, WPS, R>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -565,7 +620,7 @@ static int launch_wino8_t(const Wino8Args& a, int B, int Lmax, hipStream_t strea
   }
   const int per = 8 / aa.gy;
   dim3 grid(8 * ((aa.gx * B + per - 1) / per));
-  hipLaunchKernelGGL((conv_wino8_kernel<NS, DIL, MI, NI, WPS>), grid, dim3(512), (size_t)G::LDS_FLOATS * sizeof(float), stream, aa);
+  hipLaunchKernelGGL((conv_wino8_kernel<NS, DIL, MI, NI, WPS, R>), grid, dim3(512), (size_t)G::LDS_FLOATS * sizeof(float), stream, aa);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
@@ -590,17 +645,20 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
     set_error("run_wino8: unsupported call (B %d, Lmax %d, C %d, k %d, d %d)", B, Lmax, dc.M, dc.KS, dc.dil);
     return DISSC_EINVAL;
   }
-  const int ns = (dc.KS + 2) / 3;
+  const int R = dc.wr == 4 ? 4 : 3;
+  const int ns = (dc.KS + R - 1) / R;
   // C = 64: k = 7 on 64 x 128 tiles, k = 11 on 64 x 64 tiles built for two workgroups per CU (measured per shape, tools/wino8_c64.py)
   const int c64_mode = g_wino8_c64_wide == 3 ? (dc.KS == 7 ? 1 : 2) : g_wino8_c64_wide;
   // wave tile = workgroup tile: 128 rows x 64 columns for C >= 128, 64 x 128 ("wino8_c64_wide", default) or 64 x 64 for C = 64
-#define DISSC_W8(NS_, D_)                                                                            \
-  if (ns == NS_ && dc.dil == D_)                                                                     \
-    return dc.M >= 128 ? launch_wino8_t<NS_, D_, 4, 2>(a, B, Lmax, stream)                                                \
-                       : (c64_mode == 1 ? launch_wino8_t<NS_, D_, 2, 4>(a, B, Lmax, stream)                  \
-                          : c64_mode == 2 ? launch_wino8_t<NS_, D_, 2, 2, 4>(a, B, Lmax, stream)            \
-                                          : launch_wino8_t<NS_, D_, 2, 2>(a, B, Lmax, stream));
-  DISSC_W8(1, 1) DISSC_W8(1, 3) DISSC_W8(1, 5) DISSC_W8(3, 1) DISSC_W8(3, 3) DISSC_W8(3, 5) DISSC_W8(4, 1) DISSC_W8(4, 3) DISSC_W8(4, 5)
+#define DISSC_W8(R_, NS_, D_)                                                                        \
+  if (R == R_ && ns == NS_ && dc.dil == D_)                                                          \
+    return dc.M >= 128 ? launch_wino8_t<NS_, D_, 4, 2, 2, R_>(a, B, Lmax, stream)                   \
+                       : (c64_mode == 1 ? launch_wino8_t<NS_, D_, 2, 4, 2, R_>(a, B, Lmax, stream)  \
+                          : c64_mode == 2 ? launch_wino8_t<NS_, D_, 2, 2, 4, R_>(a, B, Lmax, stream) \
+                                          : launch_wino8_t<NS_, D_, 2, 2, 2, R_>(a, B, Lmax, stream));
+  DISSC_W8(3, 1, 1) DISSC_W8(3, 1, 3) DISSC_W8(3, 1, 5) DISSC_W8(3, 3, 1) DISSC_W8(3, 3, 3) DISSC_W8(3, 3, 5)
+  DISSC_W8(3, 4, 1) DISSC_W8(3, 4, 3) DISSC_W8(3, 4, 5)
+  DISSC_W8(4, 2, 1) DISSC_W8(4, 2, 3) DISSC_W8(4, 2, 5) DISSC_W8(4, 3, 1) DISSC_W8(4, 3, 3) DISSC_W8(4, 3, 5)
 #undef DISSC_W8
   set_error("run_wino8: k = %d, dilation %d unsupported", dc.KS, dc.dil);
   return DISSC_EINVAL;

@@ -250,8 +250,8 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         snprintf(name, sizeof(name), "resblocks.%d.convs1.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
         const bool wino = prec == 0 && wino_wanted(ch, rk) && wino_supported(ch, ch, rk, d);
-        const bool w8 = wino && wino8_wanted(ch, rk) && wino8_supported(ch, ch, rk, d);  // F(6,3) on 8-wave workgroups
-        if ((rc = w8 ? make_wino8(w, b, ch, rk, d, g->rb1[idx])
+        const bool w8 = wino && wino8_wanted(ch, rk, d);  // the eight-point forms on 8-wave workgroups (per shape: conv_wino8.hip)
+        if ((rc = w8 ? make_wino8(w, b, ch, rk, d, g->rb1[idx], wino8_taps(ch, rk, d))
                      : wino ? make_wino(w, b, ch, rk, d, g->rb1[idx]) : make_conv(w, b, ch, ch, rk, d, g->rb1[idx])))
           return fail(rc);
         const float* w1c = w;
@@ -265,7 +265,8 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         snprintf(name, sizeof(name), "resblocks.%d.convs2.%d.bias", i * nk + j, m);
         if ((rc = get(name, {ch}, &b))) return fail(rc);
         const bool wino2 = wino;
-        if ((rc = w8 ? make_wino8(w, b, ch, rk, 1, g->rb2[idx])
+        const bool w82 = wino && wino8_wanted(ch, rk, 1);
+        if ((rc = w82 ? make_wino8(w, b, ch, rk, 1, g->rb2[idx], wino8_taps(ch, rk, 1))
                      : wino2 ? make_wino(w, b, ch, rk, 1, g->rb2[idx]) : make_conv(w, b, ch, ch, rk, 1, g->rb2[idx])))
           return fail(rc);
         // the whole pair as one transform-domain launch (respair_wino.hip): C = 32, k = 7 / 11 and C = 64, k = 3
@@ -362,7 +363,7 @@ double dissc_gen_flops_executed(dissc_gen_t g, int64_t frames) {
   int mul = 1;
   const int nk = g->cfg.num_kernels;
   auto ex = [](const DevConv& c) {
-    return c.wino == 2 ? wino8_executed_macs_per_t(c.M, c.KS) : c.wino ? wino_executed_macs_per_t(c.M, c.KS) : c.macs_per_t;
+    return c.wino == 2 ? wino8_executed_macs_per_t(c.M, c.KS, c.wr) : c.wino ? wino_executed_macs_per_t(c.M, c.KS) : c.macs_per_t;
   };
   for (int i = 0; i < g->cfg.num_upsamples; ++i) {
     for (auto& c : g->ups[i]) macs += c.macs_per_t * mul;
@@ -581,7 +582,9 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
         }
         if (g->rb1[idx].wino && g->rb2[idx].wino) {
           // Toom-Cook F(4,3) form (conv_wino.hip): t = conv_d(lrelu(x)); x = x + conv_1(lrelu(t)) / MRF update
-          auto runw = g->rb1[idx].wino == 2 ? run_wino8 : run_wino;  // F(6,3) on 8 waves (k = 7 / 11) or F(4,3) on 12
+          // per conv: the eight-point forms on 8 waves (conv_wino8.hip) or F(4,3) on 12 (conv_wino.hip)
+          auto runw = g->rb1[idx].wino == 2 ? run_wino8 : run_wino;
+          auto runw2 = g->rb2[idx].wino == 2 ? run_wino8 : run_wino;
           if ((rc = runw(g->rb1[idx], xin, TMPc, nullptr, nullptr, lengths, L, mul, B, ld, ld, L, 0.1f, EPI_STORE, 1.f, sj)))
             return rc;
           int epiw = EPI_RES;
@@ -589,7 +592,7 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
             epiw = (j == 0) ? (nk == 1 ? EPI_MRF_DIV : EPI_MRF_SET) : (j == nk - 1 ? EPI_MRF_DIV : EPI_MRF_ADD);
             if (multi && j > 0) DISSC_HIP_CHECK(hipStreamWaitEvent(sj, g->ev_fin[j - 1], 0));
           }
-          if ((rc = runw(g->rb2[idx], TMPc, XKc, xin, ACC, lengths, L, mul, B, ld, ld, L, 0.1f, epiw, (float)nk, sj)))
+          if ((rc = runw2(g->rb2[idx], TMPc, XKc, xin, ACC, lengths, L, mul, B, ld, ld, L, 0.1f, epiw, (float)nk, sj)))
             return rc;
           continue;
         }
@@ -655,7 +658,8 @@ int dissc_conv1d(const float* x, const float* w_host, const float* bias_host, fl
   DevConv dc;
   const bool use8 = g_wino8 >= 2 && wino8_supported(Cout, Cin, k, dilation);  // "wino8" = 2: the stand-alone entry uses it (tests)
   if (use8 || (g_wino >= 2 && wino_supported(Cout, Cin, k, dilation))) {  // "wino" = 2: likewise for the F(4,3) form
-    int rc = use8 ? make_wino8(w_host, bias_host, Cout, k, dilation, dc) : make_wino(w_host, bias_host, Cout, k, dilation, dc);
+    const int taps = g_wino8_r4 >= 2 && wino8_r4_supported(Cout, k, dilation) ? 4 : 3;  // "wino8_r4" = 2: F(5,4) (tests)
+    int rc = use8 ? make_wino8(w_host, bias_host, Cout, k, dilation, dc, taps) : make_wino(w_host, bias_host, Cout, k, dilation, dc);
     if (rc) return rc;
     rc = (use8 ? run_wino8 : run_wino)(dc, x, y, nullptr, nullptr, lengths, Lmax, 1, B, ldx, ldo, Lmax, in_slope, EPI_STORE, 1.f,
                                        (hipStream_t)stream);
@@ -859,6 +863,8 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "wino8_dbg") == 0) { g_wino8_dbg = value; return DISSC_OK; }
   if (strcmp(key, "wino8_c64_wide") == 0) { g_wino8_c64_wide = value; return DISSC_OK; }
   if (strcmp(key, "wino8_mask") == 0) { g_wino8_mask = value; return DISSC_OK; }
+  if (strcmp(key, "wino8_r4") == 0) { g_wino8_r4 = value; return DISSC_OK; }
+  if (strcmp(key, "wino8_r4_mask") == 0) { g_wino8_r4_mask = value; return DISSC_OK; }
   if (strcmp(key, "wino_cpr") == 0) { g_wino_cpr = value; return DISSC_OK; }
   if (strcmp(key, "wino_sv") == 0) { g_wino_sv = value; return DISSC_OK; }
   if (strcmp(key, "wino_small") == 0) { g_wino_small = value; return DISSC_OK; }
@@ -901,7 +907,7 @@ int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int e
   g_conv_prec = g_precision;  // diagnostics follow the "precision" option like the generator does
   const bool w8 = (flags & 4) && wino8_supported(Cout, Cin, k, dilation);
   const bool wino = w8 || ((flags & 2) && wino_supported(Cout, Cin, k, dilation));
-  int rc = w8 ? make_wino8(w.data(), bias.data(), Cout, k, dilation, dc)
+  int rc = w8 ? make_wino8(w.data(), bias.data(), Cout, k, dilation, dc, (flags & 8) && wino8_r4_supported(Cout, k, dilation) ? 4 : 3)
               : wino ? make_wino(w.data(), bias.data(), Cout, k, dilation, dc)
                      : make_conv(w.data(), bias.data(), Cout, Cin, k, dilation, dc);
   g_conv_prec = 0;

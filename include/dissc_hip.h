@@ -143,11 +143,14 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   cpb2 (0)             k <= value convs stage 32 channels per barrier
  *   pair_max_c (32)      widest fp32 stage whose residual pairs (conv_d -> conv_1 -> +x) run as ONE launch each
  *                        (respair.hip; 0 = every conv its own launch; results are bit-identical either way)
- *   wino8 (1)            read at dissc_gen_create: 1 = the ResBlock convs selected by wino8_mask run in the Toom-Cook
- *                        F(6,3) transform domain on 8-wave workgroups (conv_wino8.hip: 8 ceil(k / 3) / 6 products per output;
- *                        forward 1.0 % faster, per-layer rounding 1.7x the F(4,3) form's); 0 = the F(4,3) form everywhere;
- *                        2 = dissc_conv1d uses it too (tests).  wino8_mask (0606 octal): bit 3 cls + {k = 3: 0, 7: 1, 11: 2}, cls 0 / 1 / 2
- *                        for C = 64 / 128 / >= 256 (default: k = 7 / 11 at C = 64 and C >= 256).  wino8_c64_wide (3): C = 64 instances -- 1 = 64 x 128 tiles, 0 = 64 x 64, 2 = 64 x 64
+ *   wino8 (1)            read at dissc_gen_create: 1 = the ResBlock convs selected by wino8_mask run on conv_wino8.hip's
+ *                        8-wave workgroups (eight Toom-Cook points: F(6,3), 8 ceil(k / 3) / 6 products per output, or F(5,4) with
+ *                        4-tap sub-filters, 8 ceil(k / 4) / 5 -- forward 4 % faster than with F(4,3) everywhere, per-layer rounding
+ *                        1.4-1.7x the F(4,3) form's); 0 = the F(4,3) form everywhere; 2 = dissc_conv1d uses it too (tests).
+ *                        wino8_mask (0770670770 octal): one bit per SHAPE, 9 cls + 3 ki + di with cls 0 / 1 / 2 for C = 64 / 128 / >= 256,
+ *                        ki 0 / 1 / 2 for k = 3 / 7 / 11, di 0 / 1 / 2 for dilation 1 / 3 / 5 (three octal digits per class).
+ *                        wino8_r4 (1): the shapes of wino8_r4_mask (0770670010, same layout) run as F(5,4); 2 = dissc_conv1d too; 0 =
+ *                        never.  wino8_c64_wide (3): C = 64 instances -- 1 = 64 x 128 tiles, 0 = 64 x 64, 2 = 64 x 64
  *                        built for two workgroups per CU, 3 = 1 for k = 7 and 2 for k = 11
  *   ragged_enum (1)      conv_mfma32_kernel on a ragged batch enumerates only the (time tile, utterance) pairs that exist (the
  *                        empty workgroups all sit at the end of the dispatch order); 0 = tile x utterance grid with early exits

@@ -383,7 +383,8 @@ def _generator_with(lib, synth, **options):
         gd(code=torch.from_numpy(c1), f0=torch.from_numpy(f1), spkr=torch.from_numpy(s1))  # the native handle is built here
     finally:
         for k in options:
-            lib.dissc_set_option(k.encode(), {"pair_wino": 0, "wino": 1, "wino8": 1, "wino8_mask": 0o606}.get(k, saved.get(k, 0)))
+            lib.dissc_set_option(k.encode(), {"pair_wino": 0, "wino": 1, "wino8": 1, "wino8_r4": 1, "wino8_mask": 0o770670770,
+                                                     "wino8_r4_mask": 0o770670010}.get(k, saved.get(k, 0)))
     return gd
 
 
@@ -440,21 +441,24 @@ def test_transform_domain_pairs_agree_with_the_unfused_generator(env):
         assert torch.equal(one, yw[0])  # an utterance's samples do not depend on the batch it runs in
 
 
-@pytest.mark.parametrize("C,k,d", [(64, 7, 1), (64, 11, 5), (128, 7, 3), (128, 11, 1), (256, 7, 5), (256, 11, 3)])
-def test_f63_conv_matches_torch_and_the_f43_form(env, C, k, d):
-    """conv_wino8.hip (Toom-Cook F(6,3) on 8-wave workgroups, opt-in) through dissc_conv1d ("wino8" = 2): against a float64
-    F.conv1d with ragged lengths and NaN beyond every utterance, next to the F(4,3) form -- error at most 3x the direct
-    kernel's rms; an utterance alone gives the same bits as inside the batch."""
+@pytest.mark.parametrize("C,k,d", [(64, 7, 1), (64, 11, 5), (128, 7, 3), (128, 11, 1), (256, 7, 5), (256, 11, 3), (64, 11, 3), (128, 7, 5)])
+def test_f63_f54_conv_matches_torch_and_the_f43_form(env, C, k, d):
+    """conv_wino8.hip (the eight Toom-Cook points on 8-wave workgroups as F(6,3), "wino8" = 2, and as F(5,4) with 4-tap
+    sub-filters, "wino8_r4" = 2) through dissc_conv1d: against a float64 F.conv1d with ragged lengths (tiles of 300-384
+    outputs, so 315 / 316 / 629 / 631 straddle the F(5,4) tiles whose 315 outputs are not a whole number of quads) and NaN
+    beyond every utterance, next to the F(4,3) form -- error at most 3x the direct kernel's rms; an utterance alone gives the
+    same bits as inside the batch."""
     lib = env["lib"]
     torch.manual_seed(C + k + d)
-    lens = [1000, 1, 7, 359, 360, 361, 767, 769, 997]
+    lens = [1000, 1, 7, 315, 316, 359, 360, 361, 629, 631, 767, 769, 997]
     x = torch.rand(len(lens), C, 1000) * 2 - 1
     w = (torch.rand(C, C, k) * 2 - 1) * 0.025 * (256 / C) ** 0.5
     b = torch.rand(C) * 0.2 - 0.1
     errs = {}
     try:
-        for form, (wo, w8) in {"direct": (0, 0), "f43": (2, 0), "f63": (1, 2)}.items():
+        for form, (wo, w8, r4) in {"direct": (0, 0, 0), "f43": (2, 0, 0), "f63": (1, 2, 0), "f54": (1, 2, 2)}.items():
             assert lib.dissc_set_option(b"wino", wo) == 0 and lib.dissc_set_option(b"wino8", w8) == 0
+            assert lib.dissc_set_option(b"wino8_r4", r4) == 0
             y = _run_conv(env, x, w, b, lens, k, d, 0.1)
             e2 = n2 = 0.0
             for i, n in enumerate(lens):
@@ -464,35 +468,43 @@ def test_f63_conv_matches_torch_and_the_f43_form(env, C, k, d):
                 e2 += float((e ** 2).sum())
                 n2 += e.numel()
             errs[form] = (e2 / n2) ** 0.5
-            if form == "f63":
-                one = _run_conv(env, x[3:4, :, :lens[3]], w, b, lens[3:4], k, d, 0.1)
-                assert torch.equal(one[0, :, :lens[3]], y[3, :, :lens[3]])
+            if form in ("f63", "f54"):
+                for j in (3, 8):
+                    one = _run_conv(env, x[j:j + 1, :, :lens[j]], w, b, lens[j:j + 1], k, d, 0.1)
+                    assert torch.equal(one[0, :, :lens[j]], y[j, :, :lens[j]])
     finally:
         lib.dissc_set_option(b"wino", 1)
         lib.dissc_set_option(b"wino8", 1)
-    print(f"C={C} k={k} d={d}: rms error direct {errs['direct']:.2e}, F(4,3) {errs['f43']:.2e}, F(6,3) {errs['f63']:.2e}")
-    assert errs["f63"] <= 3.0 * errs["direct"] + 1e-8
+        lib.dissc_set_option(b"wino8_r4", 1)
+    print(f"C={C} k={k} d={d}: rms error direct {errs['direct']:.2e}, F(4,3) {errs['f43']:.2e}, F(6,3) {errs['f63']:.2e}, "
+          f"F(5,4) {errs['f54']:.2e}")
+    assert errs["f63"] <= 3.0 * errs["direct"] + 1e-8 and errs["f54"] <= 3.0 * errs["direct"] + 1e-8
+    assert errs["f54"] != errs["f63"]  # (the two forms really ran)
 
 
-def test_f63_generator_agrees_with_the_default_generator(env):
-    """the default instance (F(6,3) layers on the 64- and >= 256-channel stages) and one with every (width, kernel size)
-    class enabled against an instance built with "wino8" = 0 (F(4,3) everywhere): same waveform to fp32 rounding, fewer
-    executed FLOPs, batch-independent samples"""
+def test_eight_point_generators_agree_with_the_f43_generator(env):
+    """the default instance (per shape: F(5,4), F(6,3) or F(4,3) -- conv_wino8.hip's masks), one with EVERY k = 7 / 11 layer
+    of the C >= 64 stages as F(5,4) and one with all of them (and the k = 3 layers) as F(6,3), against an instance built with
+    "wino8" = 0 (F(4,3) everywhere): same waveform to fp32 rounding, fewer executed FLOPs, batch-independent samples"""
     lib, synth = env["lib"], env["synth"]
     gd = _generator_with(lib, synth, wino8=0)
     assert env["g"].flops_executed(1000) < gd.flops_executed(1000)
-    g8 = _generator_with(lib, synth, wino8=1, wino8_mask=0o777)
-    assert g8.flops_executed(1000) < env["g"].flops_executed(1000) and g8.flops(1000) == gd.flops(1000)
+    g6 = _generator_with(lib, synth, wino8=1, wino8_r4=0, wino8_mask=0o777777777)
+    g5 = _generator_with(lib, synth, wino8=1, wino8_r4=1, wino8_mask=0o777777777, wino8_r4_mask=0o777777777)
+    assert g5.flops_executed(1000) < g6.flops_executed(1000) < gd.flops_executed(1000)
+    assert g5.flops_executed(1000) < env["g"].flops_executed(1000) and g5.flops(1000) == gd.flops(1000) == g6.flops(1000)
     for code, f0, spkr, lengths in _pair_cases(synth):
         kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
                   lengths=torch.from_numpy(lengths))
-        y8, yd = g8(**kw).cpu(), gd(**kw).cpu()
+        yd = gd(**kw).cpu()
         y1 = env["g"](**kw).cpu()
-        assert torch.isfinite(y8).all() and not torch.equal(y8, yd) and not torch.equal(y1, yd)
-        assert float((y1 - yd).double().pow(2).mean().sqrt()) <= 5e-6
-        e = (y8 - yd).double()
-        rms = float(e.pow(2).mean().sqrt())
-        print(f"B={code.shape[0]} T={code.shape[1]}: F(6,3) layers vs default: rms {rms:.2e}, max {float(e.abs().max()):.2e}")
-        assert rms <= 5e-6 and float(e.abs().max()) <= 1e-4
-        one = g8(code=kw["code"][:1], f0=kw["f0"][:1], spkr=kw["spkr"][:1], lengths=kw["lengths"][:1]).cpu()[0]
-        assert torch.equal(one, y8[0])
+        assert not torch.equal(y1, yd) and float((y1 - yd).double().pow(2).mean().sqrt()) <= 5e-6
+        for name, g8 in (("F(6,3)", g6), ("F(5,4)", g5)):
+            y8 = g8(**kw).cpu()
+            assert torch.isfinite(y8).all() and not torch.equal(y8, yd) and not torch.equal(y8, y1)
+            e = (y8 - yd).double()
+            rms = float(e.pow(2).mean().sqrt())
+            print(f"B={code.shape[0]} T={code.shape[1]}: {name} layers vs F(4,3): rms {rms:.2e}, max {float(e.abs().max()):.2e}")
+            assert rms <= 5e-6 and float(e.abs().max()) <= 1e-4
+            one = g8(code=kw["code"][:1], f0=kw["f0"][:1], spkr=kw["spkr"][:1], lengths=kw["lengths"][:1]).cpu()[0]
+            assert torch.equal(one, y8[0])

@@ -149,10 +149,14 @@ def main():
             import re
             k = int(re.search(r" k(\d+) ", name + " ").group(1))
             fx = fl * 6.0 * ((k + 2) // 3) / (4.0 * k)
-        if "conv_wino8_kernel" in names[i][0]:  # Toom-Cook F(6,3): 8 ceil(k / 3) / 6 products per output
+        if "conv_wino8_kernel" in names[i][0]:
+            # the eight-point forms: 8 ceil(k / R) / (9 - R) products per output -- R = the instance's sixth template
+            # argument (3: F(6,3), 4: F(5,4))
             import re
             k = int(re.search(r" k(\d+) ", name + " ").group(1))
-            fx = fl * 8.0 * ((k + 2) // 3) / (6.0 * k)
+            targs = [int(v) for v in re.search(r"conv_wino8_kernel<([^>]*)>", names[i][0]).group(1).split(",")]
+            R = targs[5] if len(targs) > 5 else 3
+            fx = fl * 8.0 * ((k + R - 1) // R) / ((9.0 - R) * k)
         row = [str(i), name, names[i][0][:44], f"{d:.0f}", f"{fl / 1e9:.1f}", f"{fl / d / 1e6:.1f}" if fl else "-",
                f"{fx / d / 1e6:.1f}" if fl else "-", f"{by / 1e9:.3f}", f"{by / d / 1e3:.0f}"]
         g = name.split()[0] if a.what == "gen" else ("attention" if "attention" in name else "linear" if ("->" in name and "conv" not in name)

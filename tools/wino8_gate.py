@@ -18,9 +18,10 @@ dev = "cuda:0"
 what = sys.argv[1:] or ["check", "time"]
 
 
-def conv1d(x, w, b, lengths, d, slope, form):
+def conv1d(x, w, b, lengths, d, slope, form):  # form: 0 direct, 4 F(4,3), 6 F(6,3), 5 F(5,4) (where there is an instance)
     assert L.dissc_set_option(b"wino", 2 if form == 4 else 1) == 0
-    assert L.dissc_set_option(b"wino8", 2 if form == 6 else 0) == 0
+    assert L.dissc_set_option(b"wino8", 2 if form in (5, 6) else 0) == 0
+    assert L.dissc_set_option(b"wino8_r4", 2 if form == 5 else 0) == 0
     if form == 0:
         assert L.dissc_set_option(b"wino", 0) == 0
     B, C, ld = x.shape
@@ -29,7 +30,8 @@ def conv1d(x, w, b, lengths, d, slope, form):
                          w.shape[0], w.shape[2], d, ld, ld, int(lengths.max()), ctypes.c_float(slope), None), "conv1d")
     torch.cuda.synchronize()
     L.dissc_set_option(b"wino", 1)
-    L.dissc_set_option(b"wino8", 1)  # (the default)
+    L.dissc_set_option(b"wino8", 1)  # (the defaults)
+    L.dissc_set_option(b"wino8_r4", 1)
     return y
 
 
@@ -37,7 +39,7 @@ if "check" in what:
     torch.manual_seed(0)
     worst = 0.0
     for C in (64, 128, 256):
-        for k in (3, 7, 11):
+        for k in (7, 11):
             for d in (1, 3, 5):
                 lens = [1000, 1, 7, 359, 360, 361, 613, 997]
                 ld = 1000
@@ -48,7 +50,8 @@ if "check" in what:
                 w = (torch.rand(C, C, k) * 2 - 1) * 0.025 * (256 / C) ** 0.5
                 b = torch.rand(C) * 0.2 - 0.1
                 errs = {}
-                for form in (0, 4, 6):
+                r4 = True
+                for form in (0, 4, 6) + ((5,) if r4 else ()):
                     y = conv1d(x, w, b, lengths, d, 0.1, form)
                     e2 = n2 = 0.0
                     mx = 0.0
@@ -62,21 +65,24 @@ if "check" in what:
                         e2 += float((e ** 2).sum()); n2 += e.numel(); mx = max(mx, float(e.abs().max()))
                     errs[form] = ((e2 / n2) ** 0.5, mx)
                 print(f"C={C} k={k} d={d}: rms / max error  direct {errs[0][0]:.2e} / {errs[0][1]:.2e}   F(4,3) {errs[4][0]:.2e} / {errs[4][1]:.2e}"
-                      f"   F(6,3) {errs[6][0]:.2e} / {errs[6][1]:.2e}", flush=True)
-                worst = max(worst, errs[6][1])
-                assert errs[6][0] <= 4.0 * errs[0][0] + 1e-8 and errs[6][1] <= 2e-5
-    print(f"check ok, worst F(6,3) max error {worst:.2e}")
+                      f"   F(6,3) {errs[6][0]:.2e} / {errs[6][1]:.2e}" + (f"   F(5,4) {errs[5][0]:.2e} / {errs[5][1]:.2e}" if r4 else ""), flush=True)
+                for form in (6, 5) if r4 else (6,):
+                    worst = max(worst, errs[form][1])
+                    assert errs[form][0] <= 4.0 * errs[0][0] + 1e-8 and errs[form][1] <= 2e-5, form
+    print(f"check ok, worst F(6,3) / F(5,4) max error {worst:.2e}")
 
 if "time" in what:
     ms = ctypes.c_float()
     for C, Ls in ((256, 2500), (128, 10000), (64, 40000)):
-        for k in (3, 7, 11):
+        for k in (7, 11):
             for d in (1, 3, 5):
                 row = []
                 for epi in (0, 1, 3):
                     t = {}
-                    for flag in (2, 4):
+                    r4 = True
+                    for flag in (2, 4) + ((12,) if r4 else ()):
                         check(L.dissc_conv_bench(32, C, C, k, d, Ls, epi, 20, flag, ctypes.byref(ms)), "conv_bench")
                         t[flag] = ms.value * 1e3
-                    row.append(f"epi {epi}: F(4,3) {t[2]:6.0f} us, F(6,3) {t[4]:6.0f} us ({t[2] / t[4]:.2f}x)")
+                    row.append(f"epi {epi}: F(4,3) {t[2]:6.0f} us, F(6,3) {t[4]:6.0f} us ({t[2] / t[4]:.2f}x)" +
+                               (f", F(5,4) {t[12]:6.0f} us ({t[2] / t[12]:.2f}x)" if r4 else ""))
                 print(f"C={C} L={Ls} k={k} d={d}:  " + "   ".join(row), flush=True)
