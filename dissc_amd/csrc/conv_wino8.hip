@@ -647,8 +647,9 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
   }
   const int R = dc.wr == 4 ? 4 : 3;
   const int ns = (dc.KS + R - 1) / R;
-  // C = 64: k = 7 on 64 x 128 tiles, k = 11 on 64 x 64 tiles built for two workgroups per CU (measured per shape, tools/wino8_c64.py)
-  const int c64_mode = g_wino8_c64_wide == 3 ? (dc.KS == 7 ? 1 : 2) : g_wino8_c64_wide;
+  // C = 64 (measured per shape, tools/wino8_c64.py): k = 7 as F(6,3) on 64 x 128 tiles, everything else -- k = 11, and k = 7 as
+  // F(5,4) -- on 64 x 64 tiles built for two workgroups per CU (4 = the round's earlier policy: k = 7 wide in both forms)
+  const int c64_mode = g_wino8_c64_wide == 3 ? ((dc.KS == 7 && R == 3) ? 1 : 2) : g_wino8_c64_wide == 4 ? (dc.KS == 7 ? 1 : 2) : g_wino8_c64_wide;
   // wave tile = workgroup tile: 128 rows x 64 columns for C >= 128, 64 x 128 ("wino8_c64_wide", default) or 64 x 64 for C = 64
 #define DISSC_W8(R_, NS_, D_)                                                                        \
   if (R == R_ && ns == NS_ && dc.dil == D_)                                                          \
