@@ -44,7 +44,7 @@ int g_wino8 = 1;      // "wino8" option (read at dissc_gen_create): 1 (default) 
 int g_wino8_dbg = 0;  // diagnostics: knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue
 int g_wino8_c64_wide = 3;  // "wino8_c64_wide" option, C = 64 instances: 1 = 64 x 128 tiles (768 outputs), 0 = 64 x 64, 2 = 64 x 64 built for TWO
                            // workgroups per CU (<= 128 registers, <= 80 KB LDS: their phases overlap; +3-9 % on k = 11, mixed on
-                           // k = 7), 3 (default) = 1 for k = 7, 2 for k = 11
+                           // k = 7 as F(6,3), +2-8 % on k = 7 as F(5,4)), 3 (default) = 1 for k = 7 as F(6,3), 2 otherwise (run_wino8)
 
 struct Wino8Args {
   const float* x;

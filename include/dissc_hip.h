@@ -151,7 +151,7 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *                        ki 0 / 1 / 2 for k = 3 / 7 / 11, di 0 / 1 / 2 for dilation 1 / 3 / 5 (three octal digits per class).
  *                        wino8_r4 (1): the shapes of wino8_r4_mask (0770670010, same layout) run as F(5,4); 2 = dissc_conv1d too; 0 =
  *                        never.  wino8_c64_wide (3): C = 64 instances -- 1 = 64 x 128 tiles, 0 = 64 x 64, 2 = 64 x 64
- *                        built for two workgroups per CU, 3 = 1 for k = 7 and 2 for k = 11
+ *                        built for two workgroups per CU, 3 = 1 for k = 7 as F(6,3) and 2 for everything else (k = 11; k = 7 as F(5,4))
  *   ragged_enum (1)      conv_mfma32_kernel on a ragged batch enumerates only the (time tile, utterance) pairs that exist (the
  *                        empty workgroups all sit at the end of the dispatch order); 0 = tile x utterance grid with early exits
  *   pair_wino (0)        read at dissc_gen_create: 0 = off (default: the whole-forward gain is 0.2 %); 1 = the residual pairs this measured faster for (C = 32, k = 11, d = 1 / 3;

@@ -493,7 +493,10 @@ def test_eight_point_generators_agree_with_the_f43_generator(env):
     g5 = _generator_with(lib, synth, wino8=1, wino8_r4=1, wino8_mask=0o777777777, wino8_r4_mask=0o777777777)
     assert g5.flops_executed(1000) < g6.flops_executed(1000) < gd.flops_executed(1000)
     assert g5.flops_executed(1000) < env["g"].flops_executed(1000) and g5.flops(1000) == gd.flops(1000) == g6.flops(1000)
-    for code, f0, spkr, lengths in _pair_cases(synth):
+    # + three long ragged utterances (63 / 62.6 / ... frames x 320: tens of tiles per row at every stage, tile ends that are
+    # not whole output quads, utterance ends inside a tile)
+    long_case = synth.synth_generator_inputs(3, 1203, seed=5, ragged=True)
+    for code, f0, spkr, lengths in _pair_cases(synth) + [long_case]:
         kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
                   lengths=torch.from_numpy(lengths))
         yd = gd(**kw).cpu()
