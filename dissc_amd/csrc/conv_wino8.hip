@@ -413,16 +413,22 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
     (void)dummy_;
     const int mi = ps * RPP / 32;          // compile-time after unrolling
     const int sp = (ps * RPP % 32) / 16;   // which 16-row half of the 32-row block (RPP = 16)
-    // residual quads of the pass, fetched before the exchange
-    f32x4 pres[NIT];
+    // residual quads of the pass -- and, in the read-modify-write MRF modes, the accumulator's -- fetched before the exchange.
+    // (Loaded inside the store loop the accumulator quads cannot be hoisted over the previous iterations' stores to the same
+    // array: NIT dependent round trips to HBM per pass, 47-112 us per MRF launch of the 128-channel stage.)
+    f32x4 pres[NIT], pacc[NIT];
+    const bool rmw = epi != EPI_STORE && epi != EPI_RES && epi != EPI_MRF_SET;
     if (epi != EPI_STORE) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * NTH;
         const int row = idx / QPR, qi = idx - row * QPR;
         const int n0 = t0 - qsh + 4 * qi;
-        if (idx < NQ && n0 >= t0 && n0 + 4 <= tend)
-          pres[it] = *reinterpret_cast<const f32x4*>(a.res + ob + (size_t)(mt * (32 * MI) + ps * RPP + row) * a.ldo + n0);
+        if (idx < NQ && n0 >= t0 && n0 + 4 <= tend) {
+          const size_t ixp = ob + (size_t)(mt * (32 * MI) + ps * RPP + row) * a.ldo + n0;
+          pres[it] = *reinterpret_cast<const f32x4*>(a.res + ixp);
+          if (rmw) pacc[it] = *reinterpret_cast<const f32x4*>(a.acc + ixp);
+        }
       }
     }
     if (ps > 0) __syncthreads();  // the previous pass has read its output tile and its Y tiles
@@ -491,7 +497,7 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
           } else if (epi == EPI_MRF_SET) {
             *reinterpret_cast<f32x4*>(a.acc + ix) = v;
           } else {
-            const f32x4 ac = *reinterpret_cast<const f32x4*>(a.acc + ix);
+            const f32x4 ac = pacc[it];
             v[0] = ac[0] + v[0]; v[1] = ac[1] + v[1]; v[2] = ac[2] + v[2]; v[3] = ac[3] + v[3];
             if (epi == EPI_MRF_DIV) {
               v[0] = __fdiv_rn(v[0], a.mrf_div); v[1] = __fdiv_rn(v[1], a.mrf_div);
