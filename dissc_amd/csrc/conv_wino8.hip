@@ -545,8 +545,8 @@ static int w8_shape_bit(int C, int KS, int dil) {
   const int cls = C >= 256 ? 2 : C >= 128 ? 1 : 0;
   return 9 * cls + 3 * (KS == 11 ? 2 : KS == 7 ? 1 : 0) + (dil == 1 ? 0 : dil == 3 ? 1 : 2);
 }
-int g_wino8_mask = 0770670770;  // "wino8_mask" option: the shapes that run on conv_wino8_kernel (the others stay on conv_wino's F(4,3)) --
-                                // default: k = 7 / 11 everywhere except C = 128, k = 11, d = 1
+int g_wino8_mask = 0770770770;  // "wino8_mask" option: the shapes that run on conv_wino8_kernel (the others stay on conv_wino's F(4,3)) --
+                                // default: every k = 7 / 11 shape
 bool wino8_wanted(int C, int KS, int dil) {
   if (!g_wino8 || !g_wino || C < g_wino_min_c || !wino8_supported(C, C, KS, dil)) return false;
   return (g_wino8_mask >> w8_shape_bit(C, KS, dil)) & 1;
@@ -554,8 +554,8 @@ bool wino8_wanted(int C, int KS, int dil) {
 
 int g_wino8_r4 = 1;        // "wino8_r4" option (read at dissc_gen_create): 1 = the layers "wino8_r4_mask" names run the eight points as
                            // F(5,4) (k = 7: 2 sub-filters of 4 taps, k = 11: 3) instead of F(6,3); 2 = dissc_conv1d too (tests); 0 = never
-int g_wino8_r4_mask = 0770670010;  // "wino8_r4_mask" option, same bit layout as wino8_mask (k = 3 bits ignored) -- default: every wino8 shape
-                                   // of the C >= 128 stages, and k = 7, d = 1 at C = 64 (the rest of that stage is faster as F(6,3))
+int g_wino8_r4_mask = 0770770010;  // "wino8_r4_mask" option, same bit layout as wino8_mask (k = 3 bits ignored) -- default: every k = 7 / 11
+                                   // shape of the C >= 128 stages, and k = 7, d = 1 at C = 64 (the rest of that stage is faster as F(6,3))
 bool wino8_r4_supported(int C, int KS, int dil) { return wino8_supported(C, C, KS, dil) && (KS == 7 || KS == 11); }
 int wino8_taps(int C, int KS, int dil) {  // taps per sub-filter the generator's policy picks for a wino8 layer
   if (!g_wino8_r4 || !wino8_r4_supported(C, KS, dil)) return 3;
