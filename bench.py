@@ -384,7 +384,7 @@ def strong_leg(synth, g, dev, rank, world, dist, fake=False, reps=3):
         out["emulated"] = {}
         for n in [int(v) for v in emu.split(",") if v.strip()]:
             parts = harness.lpt_shard(lengths, n)
-            bud = harness.overlap_budget(lengths, parts, None)   # the round cut of the N-rank run
+            bud = harness.overlap_budget(lengths, parts, harness.ROUND_FLOATS // 320, cap=harness.OVERLAP_CAP_FLOATS // 320)   # the round cut of the N-rank run
             rf = None if bud is None else ([b * 320 for b in bud] if isinstance(bud, list) else bud * 320)
             walls, spans, rounds = [], [], 0
             for r in range(n):

@@ -663,16 +663,19 @@ def init_distributed(default_port, backend_env="DISSC_DIST_BACKEND"):
 OVERLAP_ROUND_FRAMES = 8000  # smallest round worth cutting for overlap: batches under ~4 000 frames lose > 10 %
 OVERLAP_MAX_ROUNDS = 4
 OVERLAP_MIN_LAST = 4000  # frames per rank the last (smallest) round of the taper must still hold
+OVERLAP_CAP_FLOATS = 1 << 26  # output samples per rank and overlapped round: bounds the two page-locked round buffers (256 MB each
+                              # per source rank) and the exposed last round of a long run; longer runs simply take more rounds
 
 
-def overlap_budget(lengths, parts, budget):
+def overlap_budget(lengths, parts, budget, cap=None):
     """Round budgets (length units per rank and round) when rounds are delivered while the next one computes: a run that
     would fit ONE round is still cut into up to OVERLAP_MAX_ROUNDS rounds of >= OVERLAP_ROUND_FRAMES frames per rank on
     average, so that only the LAST round's exchange + device-to-host copy + sink is exposed -- and the rounds TAPER
     (n : n - 1 : ... : 1 of the largest share), so that the exposed one is the smallest: with n rounds the tail is
     2 / (n (n + 1)) of the run's delivery instead of 1 / n.  ``budget`` (the memory bound of a round, or None) caps every
-    entry.  Derived from the global job list: every rank gets the same answer.  Returns ``budget`` itself when the
-    run is too short to cut, else a list for plan_rounds."""
+    entry, and so does ``cap`` (length units per overlapped round, OVERLAP_CAP_FLOATS / hop: a run too long for four rounds
+    of that size takes more of them, all but the last of the cap's size).  Derived from the global job list: every rank
+    gets the same answer.  Returns ``budget`` itself when the run is too short to cut, else a list for plan_rounds."""
     share = max((sum(int(lengths[i]) for i in p) for p in parts), default=0)
     n = min(OVERLAP_MAX_ROUNDS, share // OVERLAP_ROUND_FRAMES)
     while n >= 2 and share // (n * (n + 1) // 2) < OVERLAP_MIN_LAST:
@@ -686,7 +689,8 @@ def overlap_budget(lengths, parts, budget):
     tri = n * (n + 1) // 2
     cuts = [-(-share * (n - k) // tri) + longest // 2 for k in range(n - 1)]
     cuts.append(share if budget is None else int(budget))
-    return cuts if budget is None else [min(int(budget), c) for c in cuts]
+    lim = min(v for v in (budget, cap, share) if v is not None)
+    return [min(int(lim), c) for c in cuts]
 
 
 def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist=None, max_batch=128,
@@ -718,7 +722,7 @@ def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist
     else:
         budget = None if round_floats is None else max(1, round_floats // hop)
     if ex.overlap:
-        budget = overlap_budget(lengths, parts, budget)
+        budget = overlap_budget(lengths, parts, budget, cap=max(1, OVERLAP_CAP_FLOATS // hop))
     rounds = plan_rounds(lengths, parts, budget)
     t_run = time.perf_counter()
     try:

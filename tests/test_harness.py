@@ -207,6 +207,11 @@ def test_overlap_budget_rule():
         assert all(a >= b_ for a, b_ in zip(sizes, sizes[1:])), sizes
         tri = want * (want + 1) // 2
         assert harness.OVERLAP_MIN_LAST - 175 * want <= sizes[-1] <= sum(sizes) // tri + 175 * want, sizes
+    # a long run takes more rounds of the cap's size instead of ever larger ones (page-locked round buffers stay bounded)
+    long_run = harness.overlap_budget(lengths, harness.lpt_shard(lengths, 1), None, cap=30000)
+    assert long_run == [30000] * 4
+    sizes = [sum(lengths[i] for i in sh[0]) for sh in harness.plan_rounds(lengths, harness.lpt_shard(lengths, 1), long_run)]
+    assert len(sizes) == 6 and max(sizes) <= 30000 and sizes[-1] <= sizes[0]
     capped = harness.overlap_budget(lengths, harness.lpt_shard(lengths, 1), 1000)  # a tighter (memory) budget wins
     assert capped == [1000] * 4
     assert len(harness.plan_rounds(lengths, harness.lpt_shard(lengths, 1), capped)) == -(-1024 * 175 // (1000 // 175 * 175))

@@ -76,7 +76,15 @@ def main():
             wall = time.time() - t0
             if r.returncode != 0:
                 raise SystemExit(r.stdout[-2000:] + r.stderr[-4000:])
-            phases = [json.loads(ln.split(" ", 1)[1]) for ln in r.stdout.splitlines() if ln.startswith("CLI_TIMING ")]
+            # (the ranks of a multi-process run share the pipe: two records can land on one line)
+            phases, dec, pos = [], json.JSONDecoder(), 0
+            while True:
+                pos = r.stdout.find("CLI_TIMING {", pos)
+                if pos < 0:
+                    break
+                obj, end = dec.raw_decode(r.stdout, pos + len("CLI_TIMING "))
+                phases.append(obj)
+                pos = end
             files = [f for f in os.listdir(out_dir) if f.endswith("_gen.wav")]
             nbytes = sum(os.path.getsize(os.path.join(out_dir, f)) for f in files)
             rec = {"ranks": n, "rep": rep, "writers": a.writers if n > 1 else "rank0 (N = 1)", "outer_wall_s": round(wall, 3),
