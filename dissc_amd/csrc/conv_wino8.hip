@@ -1,5 +1,6 @@
-// conv_wino8_kernel: the k = 7 / 11 ResBlock convs of the wide stages (C -> C channels, dilation 1 / 3 / 5; reference
-// sr/models.py:16-41) in the Toom-Cook F(6,3) transform domain: 6 outputs of a 3-tap filter from 8 products (evaluation
+// conv_wino8_kernel: the k = 7 / 11 (and some k = 3) ResBlock convs of the C >= 64 stages (C -> C channels, dilation 1 / 3 / 5;
+// reference sr/models.py:16-41) in a Toom-Cook transform domain of EIGHT points -- as F(6,3) (described first) or, template
+// parameter R = 4, as F(5,4) (below); which shape takes which form: wino8_mask / wino8_r4_mask.  F(6,3): 6 outputs of a 3-tap filter from 8 products (evaluation
 // points 0, +-1, +-2, +-1/2, inf) instead of F(4,3)'s 4 from 6 (conv_wino.hip) -- 8 ceil(k / 3) / 6 MFMA products per
 // output, 11 % fewer -- still fp32 operands, fp32 products, fp32 accumulation on v_mfma_f32_32x32x2_f32.
 //
@@ -409,8 +410,6 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
   constexpr int NPASS = 32 * MI / RPP;
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
-    constexpr int dummy_ = 0;
-    (void)dummy_;
     const int mi = ps * RPP / 32;          // compile-time after unrolling
     const int sp = (ps * RPP % 32) / 16;   // which 16-row half of the 32-row block (RPP = 16)
     // residual quads of the pass -- and, in the read-modify-write MRF modes, the accumulator's -- fetched before the exchange.
@@ -545,8 +544,9 @@ static int w8_shape_bit(int C, int KS, int dil) {
   const int cls = C >= 256 ? 2 : C >= 128 ? 1 : 0;
   return 9 * cls + 3 * (KS == 11 ? 2 : KS == 7 ? 1 : 0) + (dil == 1 ? 0 : dil == 3 ? 1 : 2);
 }
-int g_wino8_mask = 0770770770;  // "wino8_mask" option: the shapes that run on conv_wino8_kernel (the others stay on conv_wino's F(4,3)) --
-                                // default: every k = 7 / 11 shape
+int g_wino8_mask = 0770770771;  // "wino8_mask" option: the shapes that run on conv_wino8_kernel (the others stay on conv_wino's F(4,3)) --
+                                // default: every k = 7 / 11 shape, and k = 3, d = 1 at C = 64 (as F(6,3) on the two-per-CU tiles: 4 of the
+                                // 6 launches of that chain, forward 33.47 -> 33.16 ms; the other k = 3 shapes measured neutral)
 bool wino8_wanted(int C, int KS, int dil) {
   if (!g_wino8 || !g_wino || C < g_wino_min_c || !wino8_supported(C, C, KS, dil)) return false;
   return (g_wino8_mask >> w8_shape_bit(C, KS, dil)) & 1;

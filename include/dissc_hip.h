@@ -147,7 +147,7 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *                        8-wave workgroups (eight Toom-Cook points: F(6,3), 8 ceil(k / 3) / 6 products per output, or F(5,4) with
  *                        4-tap sub-filters, 8 ceil(k / 4) / 5 -- forward 4 % faster than with F(4,3) everywhere, per-layer rounding
  *                        1.4-1.7x the F(4,3) form's); 0 = the F(4,3) form everywhere; 2 = dissc_conv1d uses it too (tests).
- *                        wino8_mask (0770770770 octal): one bit per SHAPE, 9 cls + 3 ki + di with cls 0 / 1 / 2 for C = 64 / 128 / >= 256,
+ *                        wino8_mask (0770770771 octal): one bit per SHAPE, 9 cls + 3 ki + di with cls 0 / 1 / 2 for C = 64 / 128 / >= 256,
  *                        ki 0 / 1 / 2 for k = 3 / 7 / 11, di 0 / 1 / 2 for dilation 1 / 3 / 5 (three octal digits per class).
  *                        wino8_r4 (1): the shapes of wino8_r4_mask (0770770010, same layout) run as F(5,4); 2 = dissc_conv1d too; 0 =
  *                        never.  wino8_c64_wide (3): C = 64 instances -- 1 = 64 x 128 tiles, 0 = 64 x 64, 2 = 64 x 64

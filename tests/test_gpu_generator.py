@@ -383,7 +383,7 @@ def _generator_with(lib, synth, **options):
         gd(code=torch.from_numpy(c1), f0=torch.from_numpy(f1), spkr=torch.from_numpy(s1))  # the native handle is built here
     finally:
         for k in options:
-            lib.dissc_set_option(k.encode(), {"pair_wino": 0, "wino": 1, "wino8": 1, "wino8_r4": 1, "wino8_mask": 0o770770770,
+            lib.dissc_set_option(k.encode(), {"pair_wino": 0, "wino": 1, "wino8": 1, "wino8_r4": 1, "wino8_mask": 0o770770771,
                                                      "wino8_r4_mask": 0o770770010}.get(k, saved.get(k, 0)))
     return gd
 
