@@ -506,18 +506,30 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
           }
         }
       } else {
-        for (int e = lo - n0; e < hi - n0; ++e) {
+        // a quad shared with the neighbouring tile, or cut by the utterance's end: element by element -- every load first (loaded
+        // inside the store loop, an element's residual could not be hoisted over the previous element's store: up to three
+        // dependent HBM round trips per quad, +50-90 us on the F(5,4) layers whose tiles are not whole quads)
+        float rr[4], aa[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = n0 + e >= lo && n0 + e < hi;
+          rr[e] = (ok && epi != EPI_STORE) ? a.res[ix + e] : 0.f;
+          aa[e] = (ok && rmw) ? a.acc[ix + e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n0 + e < lo || n0 + e >= hi) continue;
           float x = v[e];
           if (epi == EPI_STORE) {
             a.out[ix + e] = x;
           } else {
-            x += a.res[ix + e];
+            x += rr[e];
             if (epi == EPI_RES) {
               a.out[ix + e] = x;
             } else if (epi == EPI_MRF_SET) {
               a.acc[ix + e] = x;
             } else {
-              x = a.acc[ix + e] + x;
+              x = aa[e] + x;
               if (epi == EPI_MRF_DIV) x = __fdiv_rn(x, a.mrf_div);
               a.acc[ix + e] = x;
             }
