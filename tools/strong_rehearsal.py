@@ -24,7 +24,8 @@ Model: rounds of one run are pipelined -- round k is deliv
     T_N >= f_first max_r C_r + G + D                 (delivery-bound floor: rank 0 cannot deliver faster than D)
 
 with C_r the solo wall of rank r's share, R_N the rounds of the run, G a modelled RCCL all-gather of the round's
-exchange buffers at XGMI_RING_GBPS (bench.py; conservative single-ring figure).  Efficiency_N = T_1 / (N * T_N).
+exchange buffers at XGMI_RING_GBPS (bench.py; conservative single-ring figure).  Efficiency_N = T_1 / (N * T_N), T_1 the
+model's own one-rank wall (the measured one is printed next to it).
 Writes <out>/strong_model.json (read back by bench.py -> `strong.predicted`) and <out>/strong_model.md.
 """
 import argparse
@@ -63,6 +64,7 @@ def run_bench(n, timeout, env_extra):
 
 def model(one, xgmi_gbps):
     t1 = one["wall_ms"]
+    t1_model = t1
     d_total = one["rank0_delivery"]["d2h_unpack_ms"] + one["rank0_delivery"]["sink_ms"]
     per_n = {}
     for key, e in sorted(((k, v) for k, v in one["emulated"].items() if k != "what"), key=lambda kv: int(kv[0])):
@@ -75,9 +77,11 @@ def model(one, xgmi_gbps):
         t_pipe = c_max + tail
         t_floor = c_max * frac[0] + g_total + d_total          # delivery-bound floor
         t_n = max(t_pipe, t_floor)
+        if n == 1:
+            t1_model = t_n   # speed-ups are taken against the MODEL's one-rank wall: the measured one carries that run's host noise
         per_n[key] = {
-            "predicted_wall_ms": round(t_n, 2), "predicted_speedup": round(t1 / t_n, 3),
-            "predicted_efficiency": round(t1 / t_n / n, 3), "rounds": rounds,
+            "predicted_wall_ms": round(t_n, 2), "predicted_speedup": round(t1_model / t_n, 3),
+            "predicted_efficiency": round(t1_model / t_n / n, 3), "rounds": rounds,
             "solo_compute_ms": solo, "max_solo_compute_ms": round(c_max, 2),
             "mean_solo_compute_ms": round(sum(solo) / len(solo), 2),
             "sum_solo_compute_ms": round(sum(solo), 2),
