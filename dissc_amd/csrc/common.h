@@ -236,7 +236,14 @@ struct DevPairW {
   float* b1 = nullptr;
   float* b2 = nullptr;
   int C = 0, KS = 0, dil = 1;
+  int form = 0;  // 0: respair_wino_kernel (F(4,3), Y exchanged through LDS); 1: respair32_f23_kernel (F(2,3), register-only)
 };
+// register-only F(2,3) pairs of the 32-channel stage, k = 11 (respair_f23.hip)
+extern int g_pair_f23;   // "pair_f23" option (read at dissc_gen_create)
+bool pair_f23_supported(int C, int KS, int dil);
+int pack_pair_f23(const float* w, float** dev);
+int launch_pair_f23(const DevPairW& pw, const float* x, float* out, float* acc, const int32_t* lengths, int len_default,
+                    int len_mul, int B, int Lmax, int ld, float slope, int epi, float mrf_div, hipStream_t stream);
 extern int g_pair_wino;  // "pair_wino" option (read at dissc_gen_create)
 extern int g_pairw_chv;  // "pairw_chv" option
 bool pairw_supported(int C, int KS, int dil);

@@ -371,7 +371,8 @@ double dissc_gen_flops_executed(dissc_gen_t g, int64_t frames) {
     for (int j = 0; j < nk * 3; ++j) {
       const size_t idx = (size_t)i * nk * 3 + j;
       if (g->pw[idx].w1)  // the pair runs as one transform-domain launch (respair_wino.hip)
-        macs += 2.0 * wino_executed_macs_per_t(g->pw[idx].C, g->pw[idx].KS) * mul;
+        macs += (g->pw[idx].form == 1 ? 2.0 * g->pw[idx].C * g->pw[idx].C * 8.0   // F(2,3): 4 products per 2 outputs and sub-filter
+                                      : 2.0 * wino_executed_macs_per_t(g->pw[idx].C, g->pw[idx].KS)) * mul;
       else
         macs += (ex(g->rb1[idx]) + ex(g->rb2[idx])) * mul;
     }
@@ -881,6 +882,7 @@ int dissc_set_option(const char* key, int value) {
   }
   if (strcmp(key, "pair_max_c") == 0) { g_pair_max_c = value; return DISSC_OK; }
   if (strcmp(key, "pair_wino") == 0) { g_pair_wino = value; return DISSC_OK; }
+  if (strcmp(key, "pair_f23") == 0) { g_pair_f23 = value; return DISSC_OK; }
   if (strcmp(key, "pairw_chv") == 0) { g_pairw_chv = value == 2 ? 2 : 1; return DISSC_OK; }
   if (strcmp(key, "pair_pad_lds") == 0) { g_pair_pad_lds = value; return DISSC_OK; }
   if (strcmp(key, "conv_pad_lds") == 0) { g_conv_pad_lds = value; return DISSC_OK; }

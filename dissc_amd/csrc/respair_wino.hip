@@ -588,6 +588,7 @@ bool pairw_supported(int C, int KS, int dil) {
 // exchanges 125 + skeleton (staging, barriers, weight loads, launch) 197 us, nothing overlapping -- one workgroup fills
 // the CU and fp32 VALU work shares the MFMA datapath.  "pair_wino" = 2 takes every supported shape (tests).
 bool pairw_wanted(int C, int KS, int dil) {
+  if (g_pair_f23 && pair_f23_supported(C, KS, dil)) return true;  // (make_pairw then builds the register-only F(2,3) form)
   if (!g_pair_wino || !pairw_supported(C, KS, dil)) return false;
   if (g_pair_wino >= 2) return true;
   if (C == 32) return KS == 11 && dil <= 3;
@@ -623,8 +624,9 @@ int make_pairw(const float* w1, const float* b1, const float* w2, const float* b
     return DISSC_EINVAL;
   }
   pw.C = C; pw.KS = KS; pw.dil = dil;
-  int rc = pack_pairw(w1, C, KS, &pw.w1);
-  if (!rc) rc = pack_pairw(w2, C, KS, &pw.w2);
+  pw.form = (g_pair_f23 && pair_f23_supported(C, KS, dil)) ? 1 : 0;
+  int rc = pw.form ? pack_pair_f23(w1, &pw.w1) : pack_pairw(w1, C, KS, &pw.w1);
+  if (!rc) rc = pw.form ? pack_pair_f23(w2, &pw.w2) : pack_pairw(w2, C, KS, &pw.w2);
   std::vector<float> bb(C, 0.f);
   if (b1) memcpy(bb.data(), b1, C * sizeof(float));
   if (!rc) rc = upload(bb, &pw.b1);
@@ -670,6 +672,7 @@ int launch_respair_wino(const DevPairW& pw, const float* x, float* out, float* a
     set_error("launch_respair_wino: bad argument (C=%d k=%d d=%d ld=%d epi=%d)", pw.C, pw.KS, pw.dil, ld, epi);
     return DISSC_EINVAL;
   }
+  if (pw.form == 1) return launch_pair_f23(pw, x, out, acc, lengths, len_default, len_mul, B, Lmax, ld, slope, epi, mrf_div, stream);
   PairWArgs a;
   a.x = x; a.out = out; a.acc = acc; a.w1 = pw.w1; a.w2 = pw.w2; a.b1 = pw.b1; a.b2 = pw.b2;
   a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul; a.ld = ld;

@@ -383,7 +383,7 @@ def _generator_with(lib, synth, **options):
         gd(code=torch.from_numpy(c1), f0=torch.from_numpy(f1), spkr=torch.from_numpy(s1))  # the native handle is built here
     finally:
         for k in options:
-            lib.dissc_set_option(k.encode(), {"pair_wino": 0, "wino": 1, "wino8": 1, "wino8_r4": 1, "wino8_mask": 0o770770771,
+            lib.dissc_set_option(k.encode(), {"pair_wino": 0, "pair_f23": 1, "wino": 1, "wino8": 1, "wino8_r4": 1, "wino8_mask": 0o770770771,
                                                      "wino8_r4_mask": 0o770770010}.get(k, saved.get(k, 0)))
     return gd
 
@@ -401,7 +401,8 @@ def test_fused_residual_pairs_are_bit_identical_to_separate_launches(env):
     """respair.hip (one launch per residual pair of the narrow stages, direct form) against the same generator with
     every conv as its own launch ("pair_max_c" = 0): identical bits, for a ragged batch (window edges,
     utterance ends inside a window, a 1-frame utterance) and at the BASELINE size."""
-    lib, synth, g = env["lib"], env["synth"], env["g"]
+    lib, synth = env["lib"], env["synth"]
+    g = _generator_with(lib, synth, pair_f23=0)  # (the default's k = 11 pairs of the 32-channel stage are F(2,3): next test)
     cur = ctypes.c_int(0)
     assert lib.dissc_get_option(b"pair_max_c", ctypes.byref(cur)) == 0 and cur.value >= 16
     for code, f0, spkr, lengths in _pair_cases(synth):
@@ -417,15 +418,38 @@ def test_fused_residual_pairs_are_bit_identical_to_separate_launches(env):
         assert torch.equal(y_pair, y_sep)
 
 
+def test_f23_pairs_agree_with_the_direct_pairs(env):
+    """the default instance (k = 11 pairs of the 32-channel stage on respair32_f23_kernel: register-only F(2,3)) against one
+    built with "pair_f23" = 0 (the direct pairs): same waveform to fp32 rounding, ragged (incl. long utterances) and at the
+    BASELINE size, fewer executed FLOPs, batch-independent samples"""
+    lib, synth = env["lib"], env["synth"]
+    gd = _generator_with(lib, synth, pair_f23=0)
+    g = env["g"]
+    assert g.flops_executed(1000) < gd.flops_executed(1000) and g.flops(1000) == gd.flops(1000)
+    for code, f0, spkr, lengths in _pair_cases(synth) + [synth.synth_generator_inputs(3, 1203, seed=5, ragged=True)]:
+        kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
+                  lengths=torch.from_numpy(lengths))
+        y, yd = g(**kw).cpu(), gd(**kw).cpu()
+        assert torch.isfinite(y).all() and not torch.equal(y, yd)
+        e = (y - yd).double()
+        rms = float(e.pow(2).mean().sqrt())
+        print(f"B={code.shape[0]} T={code.shape[1]}: F(2,3) pairs vs direct pairs: rms {rms:.2e}, max {float(e.abs().max()):.2e}")
+        assert rms <= 2e-6 and float(e.abs().max()) <= 5e-5
+        one = g(code=kw["code"][:1], f0=kw["f0"][:1], spkr=kw["spkr"][:1], lengths=kw["lengths"][:1]).cpu()[0]
+        assert torch.equal(one, y[0])
+
+
 def test_transform_domain_pairs_agree_with_the_unfused_generator(env):
     """respair_wino.hip (opt-in, "pair_wino" = 1: the k = 11, d = 1 / 3 pairs of the 32-channel stage and the first k = 3
     pair of the 64-channel stage as ONE transform-domain launch each; = 2: every shape with an instance) against the
     default instance: same waveform to fp32 rounding, ragged and at the BASELINE size; fewer executed FLOPs are
     reported for them."""
     lib, synth = env["lib"], env["synth"]
-    gd = env["g"]                                   # default: "pair_wino" = 0
-    g1 = _generator_with(lib, synth, pair_wino=1)   # the shapes that measured faster per launch
-    ga = _generator_with(lib, synth, pair_wino=2)   # every shape that has an instance
+    # (without the forms that took those shapes over since: the register-only F(2,3) pairs and the k = 3 layers on conv_wino8)
+    base = dict(pair_f23=0, wino8_mask=0o770770770)
+    gd = _generator_with(lib, synth, pair_wino=0, **base)
+    g1 = _generator_with(lib, synth, pair_wino=1, **base)   # the shapes that measured faster per launch
+    ga = _generator_with(lib, synth, pair_wino=2, **base)   # every shape that has an instance
     assert g1.flops_executed(1000) < gd.flops_executed(1000) and g1.flops(1000) == gd.flops(1000)
     assert ga.flops_executed(1000) < g1.flops_executed(1000)
     for g, (code, f0, spkr, lengths) in [(g_, c) for g_ in (g1, ga) for c in _pair_cases(synth)]:

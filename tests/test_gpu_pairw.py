@@ -60,10 +60,13 @@ def _data(C, k, lengths, ld, seed):
 
 @pytest.fixture(params=[1, 2], ids=["two-6-wave-workgroups-per-CU", "one-12-wave-workgroup-per-CU"])
 def chv(request, lib):
-    """both workgroup shapes of the kernel (option "pairw_chv")"""
+    """both workgroup shapes of the kernel (option "pairw_chv"); "pair_f23" off, so that mode 3 builds THIS kernel's form for
+    C = 32, k = 11 too (the default there is the register-only F(2,3) pair, tested below)"""
     assert lib.lib.dissc_set_option(b"pairw_chv", request.param) == 0
+    assert lib.lib.dissc_set_option(b"pair_f23", 0) == 0
     yield request.param
-    lib.lib.dissc_set_option(b"pairw_chv", 1)
+    lib.lib.dissc_set_option(b"pairw_chv", 2)
+    lib.lib.dissc_set_option(b"pair_f23", 1)
 
 
 @pytest.mark.parametrize("C,k,d", SHAPES)
@@ -112,6 +115,49 @@ def test_fused_transform_domain_pair_epilogue_modes(lib, chv, C, k, d):
             if epi == 4:
                 # on the CPU like the reference's xs / num_kernels: a true division (torch's GPU kernel for a scalar
                 # divisor multiplies by the reciprocal; the HIP kernels use __fdiv_rn)
+                want = (want.cpu() / 3.0).to(DEV)
+            assert torch.equal(a[i, :, :n], want), (epi, i)
+            assert torch.equal(a[i, :, n:], acc0[i, :, n:])
+
+
+@pytest.fixture
+def f23(lib):
+    """mode 3 of dissc_respair1d builds the register-only F(2,3) form (respair_f23.hip) for C = 32, k = 11"""
+    assert lib.lib.dissc_set_option(b"pair_f23", 1) == 0  # (the default)
+    yield
+
+
+@pytest.mark.parametrize("d", [1, 3, 5])
+def test_register_only_f23_pair_matches_float64_and_the_direct_pair(lib, f23, d):
+    """respair32_f23_kernel (C = 32, k = 11; tiles of 500 / 492 / 468 outputs): ragged lengths around the tile edges, NaN beyond
+    every utterance, against float64 and the direct pair; batch independence; the MRF modes"""
+    C, k = 32, 11
+    lengths = [2000, 1, 7, 255, 467, 468, 469, 491, 492, 493, 499, 500, 501, 1023, 1999, 12]
+    ld = 2000
+    x, w1, b1, w2, b2 = _data(C, k, lengths, ld, seed=900 + d)
+    ref = _reference(x, w1, b1, w2, b2, lengths, k, d)
+    y3 = _pair(lib, 3, x, w1, b1, w2, b2, lengths, k, d)
+    y1 = _pair(lib, 1, x, w1, b1, w2, b2, lengths, k, d)  # the direct fused pair
+    worst3 = worst1 = 0.0
+    for i, n in enumerate(lengths):
+        assert torch.isfinite(y3[i, :, :n]).all()
+        assert (y3[i, :, n:] == -7.0).all(), f"utterance {i}: wrote beyond its {n} samples"
+        worst3 = max(worst3, (y3[i, :, :n].double() - ref[i, :, :n]).abs().max().item())
+        worst1 = max(worst1, (y1[i, :, :n].double() - ref[i, :, :n]).abs().max().item())
+    r3 = float(((y3[0, :, :2000].double() - ref[0]) ** 2).mean().sqrt())
+    r1 = float(((y1[0, :, :2000].double() - ref[0]) ** 2).mean().sqrt())
+    print(f"C=32 k=11 d={d}: F(2,3) pair max err {worst3:.2e} rms {r3:.2e}; direct pair {worst1:.2e} / {r1:.2e}")
+    assert not torch.equal(y3[0], y1[0])  # (the transform-domain kernel really ran)
+    assert worst3 <= 1e-5 and r3 <= max(3.0 * r1, 1e-6)
+    for i in (5, 13):
+        one = _pair(lib, 3, x[i:i + 1].clone(), w1, b1, w2, b2, lengths[i:i + 1], k, d)
+        assert torch.equal(one[0, :, :lengths[i]], y3[i, :, :lengths[i]])
+    acc0 = torch.rand(len(lengths), C, ld, device=DEV)
+    for epi in (2, 3, 4):
+        a = _pair(lib, 3, x, w1, b1, w2, b2, lengths, k, d, epi=epi, acc=acc0)
+        for i, n in enumerate(lengths):
+            want = y3[i, :, :n] if epi == 2 else acc0[i, :, :n] + y3[i, :, :n]
+            if epi == 4:
                 want = (want.cpu() / 3.0).to(DEV)
             assert torch.equal(a[i, :, :n], want), (epi, i)
             assert torch.equal(a[i, :, n:], acc0[i, :, n:])
