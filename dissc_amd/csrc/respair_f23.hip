@@ -41,6 +41,7 @@ struct PairFArgs {
   long long bstride;
   float slope, mrf_div;
   int epi;
+  int dbg;  // diagnostics ("wino_dbg" option): knock-outs -- bit 0 the tap loops, 1 the T epilogue, 2 the output epilogue
 };
 
 constexpr int f23_round32_16(int n) { return (n - 16 + 31) / 32 * 32 + 16; }  // smallest v >= n with v % 32 == 16
@@ -213,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) respair32_f23_kernel(const PairFArgs a
 
   __syncthreads();
   clear();
-  taps(a.w1, xs, base1, sh, DIL, D1);
+  if (!(a.dbg & 1)) taps(a.w1, xs, base1, sh, DIL, D1);
 
   // ---- T = lrelu(conv_d + b1) inside the utterance, 0 outside, into the same buffer: positions [0, W1) <-> times o0 - P2 + . ----
   __syncthreads();  // every wave is done reading the x window
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(256, 2) respair32_f23_kernel(const PairFArgs a
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int c = wave * 64 + ni * 32 + l31;
-    if (c < NC1) {
+    if (c < NC1 && !(a.dbg & 2)) {
       const int pe = 2 * D1 * (c / D1) + (c % D1), po = pe + D1;
       const int te = o0 - P2 + pe, to = te + D1;
       const bool ine = te >= 0 && te < len, ino = to >= 0 && to < len;
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(256, 2) respair32_f23_kernel(const PairFArgs a
   }
   __syncthreads();
   clear();
-  taps(a.w2, xs, base2, 0, 1, D2);
+  if (!(a.dbg & 1)) taps(a.w2, xs, base2, 0, 1, D2);
 
   // ---- epilogue: y = x + conv_1 + b2 (or an MRF mode), 8 rows at a time through a wave-private patch [8][PW] ----
   __syncthreads();  // every wave is done reading T, which the patches overwrite
@@ -255,6 +256,10 @@ __global__ void __launch_bounds__(256, 2) respair32_f23_kernel(const PairFArgs a
   const bool live = ncol < WOUT && tcol < len;
   const int epi = a.epi;
   const bool rmw = epi != EPI_RES && epi != EPI_MRF_SET;
+  if (a.dbg & 4) {
+    if (acc[0][0][0] == 123.f) a.out[0] = 1.f;
+    return;
+  }
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {  // rows 8 qd .. 8 qd + 7
     f32x4 rv[4], pa[4];
@@ -371,7 +376,7 @@ int launch_pair_f23(const DevPairW& pw, const float* x, float* out, float* acc, 
   PairFArgs a;
   a.x = x; a.out = out; a.acc = acc; a.w1 = pw.w1; a.w2 = pw.w2; a.b1 = pw.b1; a.b2 = pw.b2;
   a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul; a.ld = ld;
-  a.bstride = (long long)pw.C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi;
+  a.bstride = (long long)pw.C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = g_wino_dbg;
   if (pw.dil == 1) return launch_f23_t<1>(a, B, Lmax, stream);
   if (pw.dil == 3) return launch_f23_t<3>(a, B, Lmax, stream);
   if (pw.dil == 5) return launch_f23_t<5>(a, B, Lmax, stream);
