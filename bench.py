@@ -446,7 +446,8 @@ def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_se
 
 
 GEN_KERNEL_SOURCES = ("common.h", "conv_epilogue32.h", "conv_host.hip", "conv_mfma.hip", "conv_mfma32.hip", "conv_wino.hip",
-                      "conv_wino8.hip", "gen_misc.hip", "generator.hip", "respair.hip", "respair_f23.hip", "respair_wino.hip", "wino_common.h")
+                      "conv_wino8.hip", "gen_misc.hip", "generator.hip", "respair.hip", "respair16_f23.hip", "respair_f23.h", "respair_f23.hip", "respair_wino.hip",
+                      "wino_common.h")
 
 
 def kernel_source_hash():
@@ -655,7 +656,7 @@ def main():
                          "kernel": "all generator convs: conv_wino_kernel / conv_wino8_kernel (Toom-Cook F(4,3) on 12-wave workgroups, F(6,3) and "
                                    "F(5,4) on 8-wave workgroups, over 3- or 4-tap sub-filters, fp32 v_mfma_f32_32x32x2) on the ResBlocks of the C >= 64 stages, "
                                    "conv_mfma32_kernel (direct, same MFMA) for conv_pre and the ConvTranspose layers, respair32/respair16 "
-                                   "fused residual pairs on the C = 32 / 16 stages (direct; the C = 32, k = 11 pairs as register-only F(2,3): respair32_f23_kernel)",
+                                   "fused residual pairs on the C = 32 / 16 stages (direct; their k = 11 pairs as register-only F(2,3): respair32_f23_kernel / respair16_f23_kernel)",
                          "algorithmic_tflops": round(ach_alg, 2),
                          "algorithmic_frac": round(ach_alg / FP32_MFMA_PEAK_TFLOPS, 4),
                          "note": "achieved / frac = EXECUTED matrix-pipe FLOPs / time (<= peak by construction; the Toom-Cook layers "

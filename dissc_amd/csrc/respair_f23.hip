@@ -21,30 +21,13 @@
 #include <vector>
 
 #include "common.h"
+#include "respair_f23.h"
 
 namespace dissc {
 
-int g_pair_f23 = 1;  // "pair_f23" option (read at dissc_gen_create): 1 (default) = the C = 32, k = 11 pairs run on this kernel --
-                     // per launch 857 / 894 / 924 us at d = 1 / 3 / 5 against 1 042 / 1 037 / 1 052 for the direct pair (B = 32 x 10 s)
-
-struct PairFArgs {
-  const float* x;
-  float* out;
-  float* acc;
-  const float* w1;  // [chunk 2][sub-filter 4][point 4][half 2][64 lanes][4 k-steps]
-  const float* w2;
-  const float* b1;
-  const float* b2;
-  const int32_t* lengths;
-  int len_default, len_mul;
-  int ld;
-  long long bstride;
-  float slope, mrf_div;
-  int epi;
-  int dbg;  // diagnostics ("wino_dbg" option): knock-outs -- bit 0 the tap loops, 1 the T epilogue, 2 the output epilogue
-};
-
-constexpr int f23_round32_16(int n) { return (n - 16 + 31) / 32 * 32 + 16; }  // smallest v >= n with v % 32 == 16
+int g_pair_f23 = 3;  // "pair_f23" option (read at dissc_gen_create), a bit mask: 1 = the C = 32, k = 11 pairs run on this kernel -- per launch
+                     // 857 / 894 / 924 us at d = 1 / 3 / 5 against 1 042 / 1 037 / 1 052 for the direct pair (B = 32 x 10 s) --, 2 = the
+                     // C = 16, k = 11 pairs on respair16_f23.hip (525 against 604 us at d = 1); default both
 
 template <int DIL>
 struct F23Geo {
@@ -63,42 +46,6 @@ struct F23Geo {
   static_assert(NW * 8 * PW <= C * XW, "the epilogue patches fit the buffer");
   static_assert(W1 <= XW && W2 + REACH2 < XW, "T fits the buffer");
 };
-
-// (b, first output column) of workgroup `lin` when only the tiles that EXIST are enumerated (respair.hip's pair_tile: the
-// workgroups beyond the last real tile all sit at the end of the dispatch order and return at once)
-template <int WOUT>
-__device__ __forceinline__ bool f23_tile(const PairFArgs& a, int B, int& b, int& len, int& o0) {
-  const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-  if (a.lengths == nullptr) {
-    b = blockIdx.y;
-    len = a.len_default;
-    o0 = blockIdx.x * WOUT;
-    return o0 < len;
-  }
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  for (int b0 = 0; b0 < B; b0 += 64) {
-    const int l = b0 + lane < B ? a.lengths[b0 + lane] * a.len_mul : 0;
-    const int nt = (l + WOUT - 1) / WOUT;
-    int incl = nt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-    const int total = __shfl(incl, 63, 64);
-    if (lin < base + total) {
-      const unsigned long long m = __ballot(base + incl > lin);
-      const int lb = __ffsll((long long)m) - 1;
-      b = __builtin_amdgcn_readfirstlane(b0 + lb);
-      len = __builtin_amdgcn_readfirstlane(__shfl(l, lb, 64));
-      o0 = __builtin_amdgcn_readfirstlane((lin - base - __shfl(incl - nt, lb, 64)) * WOUT);
-      return true;
-    }
-    base += total;
-  }
-  return false;
-}
 
 template <int DIL>
 __global__ void __launch_bounds__(256, 2) respair32_f23_kernel(const PairFArgs a) {
@@ -331,10 +278,15 @@ __global__ void __launch_bounds__(256, 2) respair32_f23_kernel(const PairFArgs a
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-bool pair_f23_supported(int C, int KS, int dil) { return C == 32 && KS == 11 && (dil == 1 || dil == 3 || dil == 5); }
+// "pair_f23" is a bit mask: 1 = the 32-channel stage (this file), 2 = the 16-channel stage (respair16_f23.hip)
+bool pair_f23_supported(int C, int KS, int dil) {
+  if (!(KS == 11 && (dil == 1 || dil == 3 || dil == 5))) return false;
+  return (C == 32 && (g_pair_f23 & 1)) || (C == 16 && (g_pair_f23 & 2));
+}
 
 // w: [32][32][11] -> U_p[co][ci][j] = sum_i G[p][i] w[co][ci][j + 4 i] in A-fragment order [chunk][sub-filter][point][half][lane][4]
-int pack_pair_f23(const float* w, float** dev) {
+int pack_pair_f23(const float* w, float** dev, int C_) {
+  if (C_ == 16) return pack_pair16_f23(w, dev);
   static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
   constexpr int C = 32, KS = 11, NS = 4;
   std::vector<float> packed((size_t)2 * NS * 4 * 2 * 64 * 4);
@@ -377,6 +329,7 @@ int launch_pair_f23(const DevPairW& pw, const float* x, float* out, float* acc, 
   a.x = x; a.out = out; a.acc = acc; a.w1 = pw.w1; a.w2 = pw.w2; a.b1 = pw.b1; a.b2 = pw.b2;
   a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul; a.ld = ld;
   a.bstride = (long long)pw.C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = g_wino_dbg;
+  if (pw.C == 16) return launch_pair16_f23(a, pw.dil, B, Lmax, stream);
   if (pw.dil == 1) return launch_f23_t<1>(a, B, Lmax, stream);
   if (pw.dil == 3) return launch_f23_t<3>(a, B, Lmax, stream);
   if (pw.dil == 5) return launch_f23_t<5>(a, B, Lmax, stream);

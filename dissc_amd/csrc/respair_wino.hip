@@ -619,14 +619,14 @@ static int pack_pairw(const float* w, int C, int KS, float** dev) {
 }
 
 int make_pairw(const float* w1, const float* b1, const float* w2, const float* b2, int C, int KS, int dil, DevPairW& pw) {
-  if (!pairw_supported(C, KS, dil)) {
+  pw.form = (g_pair_f23 && pair_f23_supported(C, KS, dil)) ? 1 : 0;
+  if (!pw.form && !pairw_supported(C, KS, dil)) {
     set_error("make_pairw: no instance for C = %d, k = %d, dilation %d", C, KS, dil);
     return DISSC_EINVAL;
   }
   pw.C = C; pw.KS = KS; pw.dil = dil;
-  pw.form = (g_pair_f23 && pair_f23_supported(C, KS, dil)) ? 1 : 0;
-  int rc = pw.form ? pack_pair_f23(w1, &pw.w1) : pack_pairw(w1, C, KS, &pw.w1);
-  if (!rc) rc = pw.form ? pack_pair_f23(w2, &pw.w2) : pack_pairw(w2, C, KS, &pw.w2);
+  int rc = pw.form ? pack_pair_f23(w1, &pw.w1, C) : pack_pairw(w1, C, KS, &pw.w1);
+  if (!rc) rc = pw.form ? pack_pair_f23(w2, &pw.w2, C) : pack_pairw(w2, C, KS, &pw.w2);
   std::vector<float> bb(C, 0.f);
   if (b1) memcpy(bb.data(), b1, C * sizeof(float));
   if (!rc) rc = upload(bb, &pw.b1);

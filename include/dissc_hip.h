@@ -143,9 +143,10 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   cpb2 (0)             k <= value convs stage 32 channels per barrier
  *   pair_max_c (32)      widest fp32 stage whose residual pairs (conv_d -> conv_1 -> +x) run as ONE launch each
  *                        (respair.hip; 0 = every conv its own launch; results are bit-identical either way)
- *   pair_f23 (1)         read at dissc_gen_create: the k = 11 residual pairs of the 32-channel stage run as register-only Toom-Cook
- *                        F(2,3) (respair_f23.hip: 8 products per output instead of 11, no LDS exchange; forward 1.1 % faster; not
- *                        bit-identical to the direct pair, error no larger); 0 = the direct pairs of respair.hip
+ *   pair_f23 (3)         read at dissc_gen_create, a bit mask: 1 = the k = 11 residual pairs of the 32-channel stage, 2 = those of the
+ *                        16-channel stage run as register-only Toom-Cook F(2,3) (respair_f23.hip / respair16_f23.hip: 8 products per
+ *                        output instead of 11, no LDS exchange; forward 1.5 % faster; not bit-identical to the direct pairs, error no
+ *                        larger); 0 = the direct pairs of respair.hip
  *   wino8 (1)            read at dissc_gen_create: 1 = the ResBlock convs selected by wino8_mask run on conv_wino8.hip's
  *                        8-wave workgroups (eight Toom-Cook points: F(6,3), 8 ceil(k / 3) / 6 products per output, or F(5,4) with
  *                        4-tap sub-filters, 8 ceil(k / 4) / 5 -- forward 4 % faster than with F(4,3) everywhere, per-layer rounding

@@ -383,7 +383,7 @@ def _generator_with(lib, synth, **options):
         gd(code=torch.from_numpy(c1), f0=torch.from_numpy(f1), spkr=torch.from_numpy(s1))  # the native handle is built here
     finally:
         for k in options:
-            lib.dissc_set_option(k.encode(), {"pair_wino": 0, "pair_f23": 1, "wino": 1, "wino8": 1, "wino8_r4": 1, "wino8_mask": 0o770770771,
+            lib.dissc_set_option(k.encode(), {"pair_wino": 0, "pair_f23": 3, "wino": 1, "wino8": 1, "wino8_r4": 1, "wino8_mask": 0o770770771,
                                                      "wino8_r4_mask": 0o770770010}.get(k, saved.get(k, 0)))
     return gd
 
@@ -419,7 +419,7 @@ def test_fused_residual_pairs_are_bit_identical_to_separate_launches(env):
 
 
 def test_f23_pairs_agree_with_the_direct_pairs(env):
-    """the default instance (k = 11 pairs of the 32-channel stage on respair32_f23_kernel: register-only F(2,3)) against one
+    """the default instance (k = 11 pairs of the 32- and 16-channel stages on respair32/16_f23_kernel: register-only F(2,3)) against one
     built with "pair_f23" = 0 (the direct pairs): same waveform to fp32 rounding, ragged (incl. long utterances) and at the
     BASELINE size, fewer executed FLOPs, batch-independent samples"""
     lib, synth = env["lib"], env["synth"]

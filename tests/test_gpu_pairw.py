@@ -66,7 +66,7 @@ def chv(request, lib):
     assert lib.lib.dissc_set_option(b"pair_f23", 0) == 0
     yield request.param
     lib.lib.dissc_set_option(b"pairw_chv", 2)
-    lib.lib.dissc_set_option(b"pair_f23", 1)
+    lib.lib.dissc_set_option(b"pair_f23", F23_DEFAULT)
 
 
 @pytest.mark.parametrize("C,k,d", SHAPES)
@@ -120,18 +120,22 @@ def test_fused_transform_domain_pair_epilogue_modes(lib, chv, C, k, d):
             assert torch.equal(a[i, :, n:], acc0[i, :, n:])
 
 
+F23_DEFAULT = 3  # the "pair_f23" mask the library ships with (bit 0: C = 32, bit 1: C = 16)
+
+
 @pytest.fixture
 def f23(lib):
-    """mode 3 of dissc_respair1d builds the register-only F(2,3) form (respair_f23.hip) for C = 32, k = 11"""
-    assert lib.lib.dissc_set_option(b"pair_f23", 1) == 0  # (the default)
+    """mode 3 of dissc_respair1d builds the register-only F(2,3) forms (respair_f23.hip, respair16_f23.hip) for k = 11"""
+    assert lib.lib.dissc_set_option(b"pair_f23", 3) == 0
     yield
+    lib.lib.dissc_set_option(b"pair_f23", F23_DEFAULT)
 
 
-@pytest.mark.parametrize("d", [1, 3, 5])
-def test_register_only_f23_pair_matches_float64_and_the_direct_pair(lib, f23, d):
-    """respair32_f23_kernel (C = 32, k = 11; tiles of 500 / 492 / 468 outputs): ragged lengths around the tile edges, NaN beyond
-    every utterance, against float64 and the direct pair; batch independence; the MRF modes"""
-    C, k = 32, 11
+@pytest.mark.parametrize("C,d", [(32, 1), (32, 3), (32, 5), (16, 1), (16, 3), (16, 5)])
+def test_register_only_f23_pair_matches_float64_and_the_direct_pair(lib, f23, C, d):
+    """respair32_f23_kernel / respair16_f23_kernel (k = 11; tiles of 500 / 492 / 468 outputs): ragged lengths around the tile
+    edges, NaN beyond every utterance, against float64 and the direct pair; batch independence; the MRF modes"""
+    k = 11
     lengths = [2000, 1, 7, 255, 467, 468, 469, 491, 492, 493, 499, 500, 501, 1023, 1999, 12]
     ld = 2000
     x, w1, b1, w2, b2 = _data(C, k, lengths, ld, seed=900 + d)
@@ -146,7 +150,7 @@ def test_register_only_f23_pair_matches_float64_and_the_direct_pair(lib, f23, d)
         worst1 = max(worst1, (y1[i, :, :n].double() - ref[i, :, :n]).abs().max().item())
     r3 = float(((y3[0, :, :2000].double() - ref[0]) ** 2).mean().sqrt())
     r1 = float(((y1[0, :, :2000].double() - ref[0]) ** 2).mean().sqrt())
-    print(f"C=32 k=11 d={d}: F(2,3) pair max err {worst3:.2e} rms {r3:.2e}; direct pair {worst1:.2e} / {r1:.2e}")
+    print(f"C={C} k=11 d={d}: F(2,3) pair max err {worst3:.2e} rms {r3:.2e}; direct pair {worst1:.2e} / {r1:.2e}")
     assert not torch.equal(y3[0], y1[0])  # (the transform-domain kernel really ran)
     assert worst3 <= 1e-5 and r3 <= max(3.0 * r1, 1e-6)
     for i in (5, 13):

@@ -149,7 +149,7 @@ def main():
             import re
             k = int(re.search(r" k(\d+) ", name + " ").group(1))
             fx = fl * 6.0 * ((k + 2) // 3) / (4.0 * k)
-        if "respair32_f23_kernel" in names[i][0]:  # register-only F(2,3) pairs (k = 11: four sub-filters): 8 products per output
+        if "respair32_f23_kernel" in names[i][0] or "respair16_f23_kernel" in names[i][0]:  # register-only F(2,3) pairs (k = 11: four sub-filters): 8 products per output
             fx = fl * 8.0 / 11.0
         if "conv_wino8_kernel" in names[i][0]:
             # the eight-point forms: 8 ceil(k / R) / (9 - R) products per output -- R = the instance's sixth template
