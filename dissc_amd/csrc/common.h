@@ -241,7 +241,7 @@ struct DevPairW {
 // register-only F(2,3) pairs of the 32-channel stage, k = 11 (respair_f23.hip)
 extern int g_pair_f23;   // "pair_f23" option (read at dissc_gen_create)
 bool pair_f23_supported(int C, int KS, int dil);
-int pack_pair_f23(const float* w, float** dev, int C);
+int pack_pair_f23(const float* w, float** dev, int C, int KS);
 int launch_pair_f23(const DevPairW& pw, const float* x, float* out, float* acc, const int32_t* lengths, int len_default,
                     int len_mul, int B, int Lmax, int ld, float slope, int epi, float mrf_div, hipStream_t stream);
 extern int g_pair_wino;  // "pair_wino" option (read at dissc_gen_create)

@@ -371,7 +371,7 @@ double dissc_gen_flops_executed(dissc_gen_t g, int64_t frames) {
     for (int j = 0; j < nk * 3; ++j) {
       const size_t idx = (size_t)i * nk * 3 + j;
       if (g->pw[idx].w1)  // the pair runs as one transform-domain launch (respair_wino.hip)
-        macs += (g->pw[idx].form == 1 ? 2.0 * g->pw[idx].C * g->pw[idx].C * 8.0   // F(2,3): 4 products per 2 outputs and sub-filter
+        macs += (g->pw[idx].form == 1 ? 2.0 * g->pw[idx].C * g->pw[idx].C * 2.0 * ((g->pw[idx].KS + 2) / 3)   // F(2,3): 4 products per 2 outputs and sub-filter
                                       : 2.0 * wino_executed_macs_per_t(g->pw[idx].C, g->pw[idx].KS)) * mul;
       else
         macs += (ex(g->rb1[idx]) + ex(g->rb2[idx])) * mul;

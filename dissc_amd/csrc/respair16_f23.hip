@@ -13,9 +13,9 @@
 
 namespace dissc {
 
-template <int DIL>
+template <int KS_, int DIL>
 struct F23Geo16 {
-  static constexpr int KS = 11, NS = 4, C = 16, NW = 4;
+  static constexpr int KS = KS_, NS = (KS_ + 2) / 3, C = 16, NW = 4;
   static constexpr int P2 = (KS - 1) / 2, P1 = P2 * DIL;
   static constexpr int D1 = DIL * NS, D2 = NS;
   static constexpr int NCOLS = 64 * NW;
@@ -31,9 +31,9 @@ struct F23Geo16 {
   static_assert(W1 <= XW && W2 + REACH2 < XW, "T fits the buffer");
 };
 
-template <int DIL>
+template <int KS_, int DIL>
 __global__ void __launch_bounds__(256, 3) respair16_f23_kernel(const PairFArgs a) {
-  using G = F23Geo16<DIL>;
+  using G = F23Geo16<KS_, DIL>;
   constexpr int C = G::C, NW = G::NW, NT = 64 * NW, NS = G::NS, P2 = G::P2, P1 = G::P1, D1 = G::D1, D2 = G::D2, XW = G::XW,
                 W1 = G::W1, NC1 = G::NC1, NC2 = G::NC2, WOUT = G::WOUT, PW = G::PW, NI = 4;
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [C][XW]
@@ -235,9 +235,10 @@ __global__ void __launch_bounds__(256, 3) respair16_f23_kernel(const PairFArgs a
 
 // w: [16][16][11] -> U_p[co][ci][j] = sum_i G[p][i] w[co][ci][j + 4 i] in A-fragment order [sub-filter][point][lane][k-step]:
 // lane l, k-step cq -> U_p[co = l & 15][ci = 4 cq + (l >> 4)][j]
-int pack_pair16_f23(const float* w, float** dev) {
+int pack_pair16_f23(const float* w, float** dev, int KS) {
   static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
-  constexpr int C = 16, KS = 11, NS = 4;
+  constexpr int C = 16;
+  const int NS = (KS + 2) / 3;
   std::vector<float> packed((size_t)NS * 4 * 64 * 4);
   size_t o = 0;
   for (int j = 0; j < NS; ++j)
@@ -255,20 +256,21 @@ int pack_pair16_f23(const float* w, float** dev) {
   return upload(packed, dev);
 }
 
-template <int DIL>
+template <int KS_, int DIL>
 static int launch_f23_16_t(const PairFArgs& a, int B, int Lmax, hipStream_t stream) {
-  using G = F23Geo16<DIL>;
+  using G = F23Geo16<KS_, DIL>;
   dim3 grid((Lmax + G::WOUT - 1) / G::WOUT, B);
-  hipLaunchKernelGGL((respair16_f23_kernel<DIL>), grid, dim3(256), sizeof(float) * G::C * G::XW, stream, a);
+  hipLaunchKernelGGL((respair16_f23_kernel<KS_, DIL>), grid, dim3(256), sizeof(float) * G::C * G::XW, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
 
-int launch_pair16_f23(const PairFArgs& a, int dil, int B, int Lmax, hipStream_t stream) {
-  if (dil == 1) return launch_f23_16_t<1>(a, B, Lmax, stream);
-  if (dil == 3) return launch_f23_16_t<3>(a, B, Lmax, stream);
-  if (dil == 5) return launch_f23_16_t<5>(a, B, Lmax, stream);
-  set_error("launch_pair16_f23: no instance for dilation %d", dil);
+int launch_pair16_f23(const PairFArgs& a, int KS, int dil, int B, int Lmax, hipStream_t stream) {
+#define DISSC_F23(K_, D_) \
+  if (KS == K_ && dil == D_) return launch_f23_16_t<K_, D_>(a, B, Lmax, stream);
+  DISSC_F23(11, 1) DISSC_F23(11, 3) DISSC_F23(11, 5) DISSC_F23(3, 1) DISSC_F23(3, 3) DISSC_F23(3, 5)
+#undef DISSC_F23
+  set_error("launch_pair16_f23: no instance for k = %d, dilation %d", KS, dil);
   return DISSC_EINVAL;
 }
 

@@ -60,7 +60,7 @@ __device__ __forceinline__ bool f23_tile(const PairFArgs& a, int B, int& b, int&
 }
 
 // respair16_f23.hip
-int pack_pair16_f23(const float* w, float** dev);
-int launch_pair16_f23(const PairFArgs& a, int dil, int B, int Lmax, hipStream_t stream);
+int pack_pair16_f23(const float* w, float** dev, int KS);
+int launch_pair16_f23(const PairFArgs& a, int KS, int dil, int B, int Lmax, hipStream_t stream);
 
 }  // namespace dissc

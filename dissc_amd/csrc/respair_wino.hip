@@ -625,8 +625,8 @@ int make_pairw(const float* w1, const float* b1, const float* w2, const float* b
     return DISSC_EINVAL;
   }
   pw.C = C; pw.KS = KS; pw.dil = dil;
-  int rc = pw.form ? pack_pair_f23(w1, &pw.w1, C) : pack_pairw(w1, C, KS, &pw.w1);
-  if (!rc) rc = pw.form ? pack_pair_f23(w2, &pw.w2, C) : pack_pairw(w2, C, KS, &pw.w2);
+  int rc = pw.form ? pack_pair_f23(w1, &pw.w1, C, KS) : pack_pairw(w1, C, KS, &pw.w1);
+  if (!rc) rc = pw.form ? pack_pair_f23(w2, &pw.w2, C, KS) : pack_pairw(w2, C, KS, &pw.w2);
   std::vector<float> bb(C, 0.f);
   if (b1) memcpy(bb.data(), b1, C * sizeof(float));
   if (!rc) rc = upload(bb, &pw.b1);

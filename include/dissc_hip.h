@@ -146,7 +146,8 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *   pair_f23 (3)         read at dissc_gen_create, a bit mask: 1 = the k = 11 residual pairs of the 32-channel stage, 2 = those of the
  *                        16-channel stage run as register-only Toom-Cook F(2,3) (respair_f23.hip / respair16_f23.hip: 8 products per
  *                        output instead of 11, no LDS exchange; forward 1.5 % faster; not bit-identical to the direct pairs, error no
- *                        larger); 0 = the direct pairs of respair.hip
+ *                        larger); 4 / 8 = their k = 3 pairs too (2 products per output instead of 3: per launch -12 % at C = 32, 0 at
+ *                        C = 16, nothing in the forward -- off); 0 = the direct pairs of respair.hip
  *   wino8 (1)            read at dissc_gen_create: 1 = the ResBlock convs selected by wino8_mask run on conv_wino8.hip's
  *                        8-wave workgroups (eight Toom-Cook points: F(6,3), 8 ceil(k / 3) / 6 products per output, or F(5,4) with
  *                        4-tap sub-filters, 8 ceil(k / 4) / 5 -- forward 4 % faster than with F(4,3) everywhere, per-layer rounding

@@ -126,19 +126,19 @@ F23_DEFAULT = 3  # the "pair_f23" mask the library ships with (bit 0: C = 32, bi
 @pytest.fixture
 def f23(lib):
     """mode 3 of dissc_respair1d builds the register-only F(2,3) forms (respair_f23.hip, respair16_f23.hip) for k = 11"""
-    assert lib.lib.dissc_set_option(b"pair_f23", 3) == 0
+    assert lib.lib.dissc_set_option(b"pair_f23", 15) == 0  # (every shape with an instance)
     yield
     lib.lib.dissc_set_option(b"pair_f23", F23_DEFAULT)
 
 
+@pytest.mark.parametrize("k", [11, 3])
 @pytest.mark.parametrize("C,d", [(32, 1), (32, 3), (32, 5), (16, 1), (16, 3), (16, 5)])
-def test_register_only_f23_pair_matches_float64_and_the_direct_pair(lib, f23, C, d):
-    """respair32_f23_kernel / respair16_f23_kernel (k = 11; tiles of 500 / 492 / 468 outputs): ragged lengths around the tile
-    edges, NaN beyond every utterance, against float64 and the direct pair; batch independence; the MRF modes"""
-    k = 11
-    lengths = [2000, 1, 7, 255, 467, 468, 469, 491, 492, 493, 499, 500, 501, 1023, 1999, 12]
+def test_register_only_f23_pair_matches_float64_and_the_direct_pair(lib, f23, C, d, k):
+    """respair32_f23_kernel / respair16_f23_kernel (k = 11: tiles of 500 / 492 / 468 outputs; k = 3: 508): ragged lengths around
+    the tile edges, NaN beyond every utterance, against float64 and the direct pair; batch independence; the MRF modes"""
+    lengths = [2000, 1, 7, 255, 467, 468, 469, 491, 492, 493, 499, 500, 501, 507, 508, 509, 1023, 1999, 12]
     ld = 2000
-    x, w1, b1, w2, b2 = _data(C, k, lengths, ld, seed=900 + d)
+    x, w1, b1, w2, b2 = _data(C, k, lengths, ld, seed=900 + d + k)
     ref = _reference(x, w1, b1, w2, b2, lengths, k, d)
     y3 = _pair(lib, 3, x, w1, b1, w2, b2, lengths, k, d)
     y1 = _pair(lib, 1, x, w1, b1, w2, b2, lengths, k, d)  # the direct fused pair
@@ -150,10 +150,10 @@ def test_register_only_f23_pair_matches_float64_and_the_direct_pair(lib, f23, C,
         worst1 = max(worst1, (y1[i, :, :n].double() - ref[i, :, :n]).abs().max().item())
     r3 = float(((y3[0, :, :2000].double() - ref[0]) ** 2).mean().sqrt())
     r1 = float(((y1[0, :, :2000].double() - ref[0]) ** 2).mean().sqrt())
-    print(f"C={C} k=11 d={d}: F(2,3) pair max err {worst3:.2e} rms {r3:.2e}; direct pair {worst1:.2e} / {r1:.2e}")
+    print(f"C={C} k={k} d={d}: F(2,3) pair max err {worst3:.2e} rms {r3:.2e}; direct pair {worst1:.2e} / {r1:.2e}")
     assert not torch.equal(y3[0], y1[0])  # (the transform-domain kernel really ran)
     assert worst3 <= 1e-5 and r3 <= max(3.0 * r1, 1e-6)
-    for i in (5, 13):
+    for i in (5, 16):
         one = _pair(lib, 3, x[i:i + 1].clone(), w1, b1, w2, b2, lengths[i:i + 1], k, d)
         assert torch.equal(one[0, :, :lengths[i]], y3[i, :, :lengths[i]])
     acc0 = torch.rand(len(lengths), C, ld, device=DEV)
