@@ -92,11 +92,14 @@ def _load():
     L.dissc_hubert_workspace_bytes.argtypes = [vp, i32, i32]
     L.dissc_hubert_workspace_bytes.restype = ctypes.c_size_t
     L.dissc_hubert_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, ctypes.c_size_t, vp]
+    L.dissc_kmeans_assign.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     L.dissc_mfma_peak.argtypes = [i32, ctypes.POINTER(ctypes.c_float)]
     L.dissc_erf_check.argtypes = [vp, vp, i32, vp]
     L.dissc_set_option.argtypes = [ctypes.c_char_p, i32]
     L.dissc_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     L.dissc_conv_bench.argtypes = [i32] * 9 + [ctypes.POINTER(ctypes.c_float)]
+    L.dissc_conv1d_s2.argtypes = [vp, vp, vp, vp, vp] + [i32] * 9 + [vp]
+    L.dissc_conv_s2_bench.argtypes = [i32] * 5 + [ctypes.POINTER(ctypes.c_float)]
     L.dissc_pair_bench.argtypes = [i32] * 8 + [ctypes.POINTER(ctypes.c_float)]
     L.dissc_respair1d.argtypes = [vp] * 8 + [i32] * 6 + [ctypes.c_float, i32, ctypes.c_float, i32, vp]
     L.dissc_wav_postprocess.argtypes = [vp, vp, i32, i32, vp]

@@ -275,6 +275,22 @@ int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, c
 bool resblock_bf3_pairs(int C);  // run the block as three pair launches (wide halos, little LDS)
 void resblock_bf3_set_pairs(int v);
 
+// HuBERT's stride-2, k = 3 feature convs in polyphase Toom-Cook form (conv_s2tc.hip)
+struct DevS2tc {
+  float* wpack = nullptr;  // packed A fragments of the point and direct waves (make_s2tc)
+  float* bias = nullptr;   // [M] or nullptr
+  int CIN = 0, M = 0, act = 0;
+};
+extern int g_enc_tc;      // "enc_tc" option (read at dissc_hubert_create)
+extern int g_s2tc_xmode;  // "s2tc_xmode" option
+extern int g_s2tc_dbg;
+bool s2tc_supported(int Cout, int Cin, int KS, int stride);
+int make_s2tc(const float* w, const float* bias, int Cout, int Cin, DevS2tc& dc);
+void free_s2tc(DevS2tc& dc);
+double s2tc_executed_macs_per_out(int Cout, int Cin);
+int run_s2tc(const DevS2tc& dc, const float* x, float* out, const int32_t* lengths_in, const int32_t* lengths_out,
+             int len_default, int olen_default, int B, int ldx, int ldo, int Lmax_out, hipStream_t stream);
+
 // misc kernels (gen_misc.hip)
 void launch_embed_concat(const int64_t* code, const float* f0, const int64_t* spkr,
                          const float* dict_w, const float* spkr_w, const int32_t* lengths, int B,

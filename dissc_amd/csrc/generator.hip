@@ -850,6 +850,9 @@ int dissc_set_option(const char* key, int value) {
   if (strcmp(key, "multistream") == 0) { g_multistream = value; return DISSC_OK; }
   if (strcmp(key, "attn_fused") == 0) { g_attn_fused = value; return DISSC_OK; }
   if (strcmp(key, "hubert_split") == 0) { g_hubert_split = value; return DISSC_OK; }
+  if (strcmp(key, "enc_tc") == 0) { g_enc_tc = value; return DISSC_OK; }
+  if (strcmp(key, "s2tc_xmode") == 0) { g_s2tc_xmode = value; return DISSC_OK; }
+  if (strcmp(key, "s2tc_dbg") == 0) { g_s2tc_dbg = value; return DISSC_OK; }
   if (strcmp(key, "lin_tile") == 0) { g_lin_tile = value; return DISSC_OK; }
   if (strcmp(key, "cpb2") == 0) { g_cpb2 = value; return DISSC_OK; }
   if (strcmp(key, "mfast") == 0) { g_mfast = value; return DISSC_OK; }

@@ -514,26 +514,151 @@ __global__ void __launch_bounds__(256) attn_fused_kernel(const float* __restrict
   }
 }
 
-// units[b][t] = argmin_k (cnorm[k] - 2 * xc[b][k][t]), lowest index on ties
-__global__ void kmeans_argmin_kernel(const float* __restrict__ xc, const float* __restrict__ cnorm,
-                                     const int32_t* __restrict__ lens, int K, int Kld, int ld, int T,
-                                     int64_t* __restrict__ units) {
+// ---- k-means assignment (the quantiser's predict(): reference data/encode.py:21-22 via textless KMeansQuantizer -> sklearn) -----
+// units[t] = the FIRST k minimising  s_k = cnorm[k] - 2 <x_t, c_k>   (sklearn's dense predict: ||c||^2 - 2 x.c, first minimum).
+// The integer step is SPECIFIED to the bit, so that the CPU oracle can restate it exactly (oracle/host_ref.c:
+// oracle_kmeans_assign_f32) and identical inputs give identical indices, exact ties included:
+//     <x, c_k> = the fp32 fma chain  acc = fmaf(x[d], c_k[d], acc)  over d = 0 .. D-1 in order, from acc = 0;
+//     s_k = cnorm[k] - 2 acc (one rounding: 2 acc is exact);  k scanned upwards with a strict '<' from best = +inf, unit 0:
+//     a NaN score never wins, a row of NaNs gets unit 0.
+// An MFMA GEMM cannot promise that (its k-blocking and internal summation order are the hardware's); the products are 0.08 % of
+// the encoder's FLOPs, so they run on the vector ALU: one lane per frame, the centroids staged through LDS 64 dimensions at
+// a time and read back as broadcasts, KQ accumulators per lane, the workgroup's four waves splitting the centroids.
+// x element (t, d) at x[t * st + d * sd]: channels-first features (st = 1, sd = ld: coalesced) or [T][D] rows (st = D, sd = 1).
+constexpr int KM_DC = 64;   // dimensions per LDS chunk
+constexpr int KM_TH = 256;  // 4 waves x 64 frames
+
+template <int KQ>
+__global__ void __launch_bounds__(KM_TH) kmeans_assign_kernel(const float* __restrict__ x, long long x_bstride, long long st,
+                                                              long long sd, const float* __restrict__ centers,
+                                                              const float* __restrict__ cnorm, const int32_t* __restrict__ lens,
+                                                              int T, int K, int D, int64_t* __restrict__ units) {
+  constexpr int KG = 4 * KQ;             // centroids per pass
+  constexpr int LR = KM_DC + 4;          // LDS row stride (16-byte aligned rows)
+  constexpr int NS = (KG * (KM_DC / 4) + KM_TH - 1) / KM_TH;  // float4 staging slots per thread
+  __shared__ __attribute__((aligned(16))) float cs[KG * LR];
+  __shared__ float rs[4][64];
+  __shared__ int rk[4][64];
   const int b = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= T) return;
-  int64_t best = 0;
-  if (t < lens[b]) {
-    float bv = INFINITY;
-    const float* p = xc + (size_t)b * Kld * ld + t;
-    for (int k = 0; k < K; ++k) {
-      const float d = cnorm[k] - 2.f * p[(size_t)k * ld];
-      if (d < bv) {
-        bv = d;
-        best = k;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t = blockIdx.x * 64 + lane;
+  const int tlen = lens ? lens[b] : T;
+  const bool live = t < T && t < tlen;
+  const float* xt = x + (size_t)b * x_bstride + (size_t)(t < T ? t : T - 1) * st;
+  float best = INFINITY;
+  int arg = 0;
+  const int nchunk = (D + KM_DC - 1) / KM_DC;
+  for (int k0 = 0; k0 < K; k0 += KG) {
+    float acc[KQ];
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) acc[j] = 0.f;
+    // chunk of [KG centroids][64 dimensions] -> registers -> LDS, the next chunk's loads in flight behind this one's arithmetic
+    f32x4 sv[NS];
+    auto stage_load = [&](int c) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int e = threadIdx.x + i * KM_TH;
+        const int row = e / (KM_DC / 4), q = e - row * (KM_DC / 4);
+        const int k = k0 + row, d = c * KM_DC + 4 * q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < KG && k < K) {
+          const float* cp = centers + (size_t)k * D + d;
+          if (d + 4 <= D && (D & 3) == 0) {
+            v = *reinterpret_cast<const f32x4*>(cp);
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = d + u < D ? cp[u] : 0.f;
+          }
+        }
+        sv[i] = v;
+      }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int e = threadIdx.x + i * KM_TH;
+        const int row = e / (KM_DC / 4), q = e - row * (KM_DC / 4);
+        if (row < KG) *reinterpret_cast<f32x4*>(cs + row * LR + 4 * q) = sv[i];
+      }
+    };
+    stage_load(0);
+    for (int c = 0; c < nchunk; ++c) {
+      __syncthreads();  // the previous chunk has been read
+      stage_store();
+      __syncthreads();
+      if (c + 1 < nchunk) stage_load(c + 1);
+      const int d0 = c * KM_DC;
+      const float* cw = cs + wave * KQ * LR;
+#pragma unroll 2
+      for (int dd = 0; dd < KM_DC; dd += 4) {
+        float xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = d0 + dd + u < D ? xt[(size_t)(d0 + dd + u) * sd] : 0.f;  // (beyond D: c = 0 too, +0 * +0)
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+          const f32x4 cv = *reinterpret_cast<const f32x4*>(cw + j * LR + dd);  // same address in every lane: a broadcast
+          acc[j] = fmaf(xv[0], cv[0], acc[j]);
+          acc[j] = fmaf(xv[1], cv[1], acc[j]);
+          acc[j] = fmaf(xv[2], cv[2], acc[j]);
+          acc[j] = fmaf(xv[3], cv[3], acc[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+      const int k = k0 + wave * KQ + j;
+      if (k < K) {
+        const float sc = cnorm[k] - 2.f * acc[j];
+        if (sc < best) {
+          best = sc;
+          arg = k;
+        }
       }
     }
   }
-  units[(size_t)b * T + t] = best;
+  // the four waves' candidates, lowest score first, lowest index among equal scores
+  rs[wave][lane] = best;
+  rk[wave][lane] = arg;
+  __syncthreads();
+  if (wave == 0 && t < T) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float s2 = rs[w][lane];
+      const int k2 = rk[w][lane];
+      if (s2 < best || (s2 == best && k2 < arg && s2 < INFINITY)) {
+        best = s2;
+        arg = k2;
+      }
+    }
+    units[(size_t)b * T + t] = live ? arg : 0;
+  }
+}
+
+// cnorm[k] = the fp32 fma chain s = fmaf(c[d], c[d], s) over d in order (same spec as the scores; oracle_kmeans_cnorm_f32)
+__global__ void kmeans_cnorm_kernel(const float* __restrict__ centers, int K, int D, float* __restrict__ cnorm) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int d = 0; d < D; ++d) s = fmaf(centers[(size_t)k * D + d], centers[(size_t)k * D + d], s);
+  cnorm[k] = s;
+}
+
+// x as described above; B utterances (grid y); units [B][T] (0 at and beyond an utterance's length)
+int launch_kmeans_assign(const float* x, long long x_bstride, long long st, long long sd, const float* centers, const float* cnorm,
+                         const int32_t* lens, int B, int T, int K, int D, int64_t* units, hipStream_t stream) {
+  if (B <= 0 || T <= 0 || K <= 0 || D <= 0) {
+    set_error("kmeans_assign: bad shape (B %d, T %d, K %d, D %d)", B, T, K, D);
+    return DISSC_EINVAL;
+  }
+  const int npass = (K + 127) / 128;
+  const int kq = ((K + npass - 1) / npass + 3) / 4;  // centroids per wave and pass
+  const dim3 grid((T + 63) / 64, B), block(KM_TH);
+  if (kq <= 13) hipLaunchKernelGGL(kmeans_assign_kernel<13>, grid, block, 0, stream, x, x_bstride, st, sd, centers, cnorm, lens, T, K, D, units);
+  else if (kq <= 25) hipLaunchKernelGGL(kmeans_assign_kernel<25>, grid, block, 0, stream, x, x_bstride, st, sd, centers, cnorm, lens, T, K, D, units);
+  else hipLaunchKernelGGL(kmeans_assign_kernel<32>, grid, block, 0, stream, x, x_bstride, st, sd, centers, cnorm, lens, T, K, D, units);
+  DISSC_HIP_CHECK(hipGetLastError());
+  return DISSC_OK;
 }
 
 }  // namespace dissc
@@ -552,8 +677,10 @@ struct dissc_hubert {
   float* gn_g = nullptr; // GroupNorm affine
   float* gn_b = nullptr;
   std::vector<DevConv> fconv;  // feature convs 1..6 (stride 2, GELU)
+  std::vector<DevS2tc> ftc;    // the k = 3 ones in polyphase Toom-Cook form ("enc_tc" option; wpack == nullptr: direct)
   float *ln0_g = nullptr, *ln0_b = nullptr;  // feature LayerNorm(512)
-  DevConv proj, pos, kmeans;
+  DevConv proj, pos;
+  float* centers = nullptr;  // [K][768] k-means centroids
   float *eln_g = nullptr, *eln_b = nullptr;  // encoder.layer_norm
   struct Layer {
     DevConv qkv, out, fc1, fc2;
@@ -570,10 +697,11 @@ struct dissc_hubert {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (auto e : ev_join)
       if (e) (void)hipEventDestroy(e);
-    for (float* p : {w0, gn_g, gn_b, ln0_g, ln0_b, eln_g, eln_b, cnorm})
+    for (float* p : {w0, gn_g, gn_b, ln0_g, ln0_b, eln_g, eln_b, cnorm, centers})
       if (p) (void)hipFree(p);
     for (auto& c : fconv) free_conv(c);
-    free_conv(proj); free_conv(pos); free_conv(kmeans);
+    for (auto& c : ftc) free_s2tc(c);
+    free_conv(proj); free_conv(pos);
     for (auto& l : layers) {
       free_conv(l.qkv); free_conv(l.out); free_conv(l.fc1); free_conv(l.fc2);
       for (float* p : {l.ln1_g, l.ln1_b, l.ln2_g, l.ln2_b})
@@ -642,10 +770,16 @@ int dissc_hubert_create(int n_layers, const DisscTensor* weights, size_t n_weigh
   if ((rc = up("feature_extractor.conv_layers.0.2.bias", CF, &m->gn_b))) return fail(rc);
   static const int ks[NCONV] = {10, 3, 3, 3, 3, 2, 2};
   m->fconv.resize(NCONV - 1);
+  m->ftc.resize(NCONV - 1);
   for (int l = 1; l < NCONV; ++l) {
     char name[96];
     snprintf(name, sizeof(name), "feature_extractor.conv_layers.%d.0.weight", l);
     if ((rc = get(name, (size_t)CF * CF * ks[l], &w))) return fail(rc);
+    if (g_enc_tc && s2tc_supported(CF, CF, ks[l], 2)) {  // k = 3: polyphase Toom-Cook form (conv_s2tc.hip)
+      if ((rc = make_s2tc(w, nullptr, CF, CF, m->ftc[l - 1]))) return fail(rc);
+      m->ftc[l - 1].act = 1;
+      continue;
+    }
     if ((rc = make_conv(w, nullptr, CF, CF, ks[l], 1, m->fconv[l - 1], 1, 2, 0))) return fail(rc);
     m->fconv[l - 1].act = 1;
   }
@@ -696,11 +830,11 @@ int dissc_hubert_create(int n_layers, const DisscTensor* weights, size_t n_weigh
   }
   if (centers && n_centers > 0) {
     m->K = n_centers;
-    if ((rc = make_conv(centers, nullptr, n_centers, D, 1, 1, m->kmeans, 1, 1, 0))) return fail(rc);
+    if ((rc = upload(std::vector<float>(centers, centers + (size_t)n_centers * D), &m->centers))) return fail(rc);
     std::vector<float> cn(n_centers);
-    for (int k = 0; k < n_centers; ++k) {
+    for (int k = 0; k < n_centers; ++k) {  // the fma chain of the assignment's specification (kmeans_assign_kernel)
       float s = 0.f;
-      for (int d = 0; d < D; ++d) s += centers[(size_t)k * D + d] * centers[(size_t)k * D + d];
+      for (int d = 0; d < D; ++d) s = fmaf(centers[(size_t)k * D + d], centers[(size_t)k * D + d], s);
       cn[k] = s;
     }
     if ((rc = upload(cn, &m->cnorm))) return fail(rc);
@@ -710,6 +844,31 @@ int dissc_hubert_create(int n_layers, const DisscTensor* weights, size_t n_weigh
 }
 
 void dissc_hubert_destroy(dissc_hubert_t m) { delete m; }
+
+// The quantiser's predict() on its own (the call dissc_hubert_forward makes on its own features): dense [T][D] rows.
+int dissc_kmeans_assign(const float* dense, const float* centers, const float* cnorm, int T, int K, int D, int64_t* units,
+                        void* stream_) {
+  if (!dense || !centers || !units || T <= 0 || K <= 0 || D <= 0) {
+    set_error("dissc_kmeans_assign: bad argument");
+    return DISSC_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream_;
+  float* cn = nullptr;
+  if (!cnorm) {  // (test convenience; allocates and synchronises)
+    DISSC_HIP_CHECK(hipMalloc((void**)&cn, (size_t)K * 4));
+    hipLaunchKernelGGL(kmeans_cnorm_kernel, dim3((K + 63) / 64), dim3(64), 0, st, centers, K, D, cn);
+  }
+  int rc = launch_kmeans_assign(dense, 0, D, 1, centers, cnorm ? cnorm : cn, nullptr, 1, T, K, D, units, st);
+  if (cn) {
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(cn);
+    if (!rc && e != hipSuccess) {
+      set_error("dissc_kmeans_assign: %s", hipGetErrorString(e));
+      rc = DISSC_EHIP;
+    }
+  }
+  return rc;
+}
 
 // workspace carve-up (floats unless noted)
 struct HubertWs {
@@ -721,7 +880,6 @@ struct HubertWs {
   float* qkv;        // [B][2304][ldT]
   float* ffn;        // [B][3072][ldT]
   float* S;          // [B][H][T][ldS]
-  float* xc;         // [B][Kpad][ldT]
   size_t bytes;
 };
 
@@ -750,7 +908,6 @@ static HubertWs carve(const dissc_hubert* m, int B, int Nmax, void* base_) {
   w.ffn = (float*)take((size_t)B * m->F * ldT * 4);
   const bool need_s = !(g_attn_fused && m->D / m->H == 64);  // the fused attention keeps S on chip
   w.S = (float*)take(need_s ? (size_t)B * m->H * (size_t)(T > 0 ? T : 1) * ldT * 4 : 256);
-  w.xc = (float*)take((size_t)B * rup(m->K > 0 ? m->K : 1, 128) * ldT * 4);
   w.bytes = (size_t)(p - p0) + 256;
   return w;
 }
@@ -883,8 +1040,12 @@ static int hubert_forward_part(dissc_hubert_t m, const float* wav, const int32_t
     ConvIO io;
     io.lengths_in = w.lens + (size_t)(l - 1) * B;
     io.lengths_out = w.lens + (size_t)l * B;
-    if ((rc = run_conv_ex(m->fconv[l - 1], w.f[cur], w.f[cur ^ 1], nullptr, io, B, 512, ld_in, ld_out, n_out,
-                          1.0f, EPI_STORE, st)))
+    if (m->ftc[l - 1].wpack) {
+      if ((rc = run_s2tc(m->ftc[l - 1], w.f[cur], w.f[cur ^ 1], io.lengths_in, io.lengths_out, n_in, n_out, B, ld_in, ld_out,
+                         n_out, st)))
+        return rc;
+    } else if ((rc = run_conv_ex(m->fconv[l - 1], w.f[cur], w.f[cur ^ 1], nullptr, io, B, 512, ld_in, ld_out, n_out,
+                                 1.0f, EPI_STORE, st)))
       return rc;
     cur ^= 1;
     ld_in = ld_out;
@@ -944,9 +1105,8 @@ static int hubert_forward_part(dissc_hubert_t m, const float* wav, const int32_t
   if (dense_out)  // [B][768][ldT] channels-first
     DISSC_HIP_CHECK(hipMemcpyAsync(dense_out, w.x, (size_t)B * D * ldT * 4, hipMemcpyDeviceToDevice, st));
   if (units_out) {
-    if ((rc = run_conv_ex(m->kmeans, w.x, w.xc, nullptr, ioT, B, D, ldT, ldT, T, 1.0f, EPI_STORE, st))) return rc;
-    hipLaunchKernelGGL(kmeans_argmin_kernel, dim3((T + 127) / 128, B), dim3(128), 0, st, w.xc, m->cnorm, lensT,
-                       m->K, m->K, ldT, T, units_out);
+    if ((rc = launch_kmeans_assign(w.x, (long long)D * ldT, 1, ldT, m->centers, m->cnorm, lensT, B, T, m->K, D, units_out, st)))
+      return rc;
   }
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;

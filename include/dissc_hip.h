@@ -125,6 +125,16 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
                            const int32_t* lengths, int B, int Cin, int Cout, int k, int stride,
                            int ldx, int ldo, int Lmax, float in_slope, void* stream);
 
+/* Stride-2 VALID conv (HuBERT's feature convs; reference data/encode.py:21-22,32 via fairseq ConvFeatureExtractionModel):
+ * x f32 [B,Cin,ldx] -> y f32 [B,Cout,ldo] with (len - k) / 2 + 1 outputs per utterance, no padding; w HOST [Cout,Cin,k];
+ * act 1 = exact-erf GELU on the output.  form 0 = the direct implicit GEMM, 1 = the polyphase Toom-Cook form (k = 3 only:
+ * F(7,2) on the even samples + a 1-tap GEMM on the odd ones, 15 instead of 21 products per 7 outputs; conv_s2tc.hip).
+ * lengths_in: device int32 [B] or NULL (= Lmax_in everywhere).  Synchronous; test / gate entry, weights packed per call. */
+int dissc_conv1d_s2(const float* x, const float* w_host, const float* bias_host, float* y, const int32_t* lengths_in, int B,
+                    int Cin, int Cout, int k, int ldx, int ldo, int Lmax_in, int act, int form, void* stream);
+/* Diagnostics: average ms of `iters` launches of one C -> C, k = 3, stride 2 conv + GELU on B rows of L input samples. */
+int dissc_conv_s2_bench(int B, int C, int L, int form, int iters, float* ms_out);
+
 /* Tuning hook (process-wide; set before the handles are created; also reachable through the
  * environment variable DISSC_OPTIONS="key=value,key=value" read by the Python binding):
  *   multistream (1)      generator: the ResBlocks of a stage run as concurrent chains on HIP streams (two side
@@ -172,6 +182,10 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
  *                        2 = dissc_conv1d uses it too (tests)
  *   wino_sv (1)          conv_wino.hip, C >= 128: the 12 waves of a workgroup share the input transform (one barrier per
  *                        8 channels) instead of every wave forming its own tile; bit-identical, faster (0 = private tiles)
+ *   enc_tc (0)           read at dissc_hubert_create: 1 = the k = 3, stride-2 feature convs (conv1..conv4) run in polyphase
+ *                        Toom-Cook form (conv_s2tc.hip: 15 / 7 instead of 3 MFMA products per output; opt-in: its gate failed --
+ *                        6 % faster per launch, 2.35x the direct form's rounding error); 0 = direct implicit GEMM (default).
+ *                        s2tc_xmode (0): 0 = row tiles pinned to XCDs, 1 = the row tiles of a time tile share an XCD
  *   attn_fused (1)       HuBERT attention as one fused kernel (0: batched GEMM -> softmax -> batched GEMM)
  *   hubert_split (1)     dissc_hubert_forward runs a batch of >= 16 utterances as 2-4 parts on streams of their own, which
  *                        fill the partly filled last workgroup rounds of each other's launches (0 never, 1 unless the
@@ -280,6 +294,16 @@ size_t dissc_hubert_workspace_bytes(dissc_hubert_t m, int B, int Nmax);
 int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_samples, int B, int Nmax,
                          float* dense_out, int64_t* units_out, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* The quantiser's predict() on its own -- the integer step of the path (reference data/encode.py:21-22: textless
+ * KMeansQuantizer -> sklearn predict), the very launch dissc_hubert_forward makes on its own features:
+ *   units[t] = the FIRST k minimising  cnorm[k] - 2 <dense[t], centers[k]>,
+ * every dot product ONE fp32 fma chain acc = fmaf(x[d], c[d], acc) over d = 0..D-1 from 0, k scanned upwards with a strict '<'
+ * from +inf (a NaN score never wins; a row of NaNs gets unit 0) -- specified to the bit, so that identical inputs give identical
+ * indices on any implementation (oracle/host_ref.c: oracle_kmeans_assign_f32), exact ties included.
+ * dense f32 [T,D] rows, centers f32 [K,D], cnorm f32 [K] (NULL = computed here as the chain fmaf(c[d], c[d], s); then the call
+ * allocates and synchronises), units int64 [T]: device pointers. */
+int dissc_kmeans_assign(const float* dense, const float* centers, const float* cnorm, int T, int K, int D, int64_t* units,
+                        void* stream);
 
 /* Diagnostics: sustained fp32 v_mfma_f32_16x16x4_f32 rate (TFLOP/s) of this GPU at its
  * real clocks -- the practical ceiling the conv kernels are compared with. */

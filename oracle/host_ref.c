@@ -5,8 +5,13 @@
  *   oracle_len_carryover    <- len_carryover_correction, reference infer.py:158-172
  *   oracle_wav_postprocess  <- generate() int16 cast + librosa.util.normalize,
  *                              reference sr/inference.py:73-75,206
- *   oracle_kmeans_assign    <- argmin_k ||x-c_k||^2 (sklearn KMeans.predict semantics,
+ *   oracle_kmeans_assign    <- argmin_k ||x-c_k||^2 in float64 (sklearn KMeans.predict semantics,
  *                              lowest index on ties); third-party, see oracle/hubert_ref.py
+ *   oracle_kmeans_assign_f32 / oracle_kmeans_cnorm_f32
+ *                           <- the SAME step in the fp32 arithmetic the device specifies to the bit
+ *                              (dissc_amd/csrc/hubert.hip kmeans_assign_kernel): the expression sklearn's
+ *                              dense predict evaluates, ||c||^2 - 2 x.c, each dot product one fma chain
+ *                              in index order, first minimum wins, NaN never wins
  * Pinned by tests/test_oracle_golden.py against tests/golden/pred.npz (reference outputs). */
 #include <math.h>
 #include <stdint.h>
@@ -72,6 +77,34 @@ void oracle_kmeans_assign(const float* x, int T, int D, const float* centers, in
       }
       if (d < best) {
         best = d;
+        arg = k;
+      }
+    }
+    units[t] = arg;
+  }
+}
+
+/* cnorm[k] = fma chain s = fmaf(c[d], c[d], s), d = 0..D-1 */
+void oracle_kmeans_cnorm_f32(const float* centers, int K, int D, float* cnorm) {
+  for (int k = 0; k < K; ++k) {
+    float s = 0.0f;
+    for (int j = 0; j < D; ++j) s = fmaf(centers[(long)k * D + j], centers[(long)k * D + j], s);
+    cnorm[k] = s;
+  }
+}
+
+/* units[t] = first k minimising cnorm[k] - 2 * chain(x_t, c_k); x [T][D], centers [K][D] */
+void oracle_kmeans_assign_f32(const float* x, int T, int D, const float* centers, const float* cnorm, int K,
+                              int64_t* units) {
+  for (int t = 0; t < T; ++t) {
+    float best = INFINITY;
+    int64_t arg = 0;
+    for (int k = 0; k < K; ++k) {
+      float acc = 0.0f;
+      for (int j = 0; j < D; ++j) acc = fmaf(x[(long)t * D + j], centers[(long)k * D + j], acc);
+      const float s = cnorm[k] - 2.0f * acc;
+      if (s < best) {
+        best = s;
         arg = k;
       }
     }

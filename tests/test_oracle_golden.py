@@ -229,6 +229,59 @@ def test_c_oracle_postprocess_and_kmeans(coracle, hgold):
     np.testing.assert_array_equal(units, hgold["n16000/units"])  # == sklearn KMeans.predict
 
 
+def kmeans_f32(coracle, dense, centers, cnorm=None):
+    """oracle_kmeans_assign_f32 (the bit-exact specification of the device's integer step) through ctypes"""
+    import ctypes
+    dense = np.ascontiguousarray(dense, dtype=np.float32)
+    centers = np.ascontiguousarray(centers, dtype=np.float32)
+    K, D = centers.shape
+    if cnorm is None:
+        cnorm = np.zeros(K, np.float32)
+        coracle.oracle_kmeans_cnorm_f32(centers.ctypes.data_as(ctypes.c_void_p), K, D, cnorm.ctypes.data_as(ctypes.c_void_p))
+    units = np.full(len(dense), -1, np.int64)
+    coracle.oracle_kmeans_assign_f32(dense.ctypes.data_as(ctypes.c_void_p), len(dense), D, centers.ctypes.data_as(ctypes.c_void_p),
+                                     cnorm.ctypes.data_as(ctypes.c_void_p), K, units.ctypes.data_as(ctypes.c_void_p))
+    return units
+
+
+def kmeans_tie_cases(seed=0, K=100, D=768):
+    """(dense [T,D], centers [K,D], expected or None): exact ties by construction -- duplicated centroids (identical scores
+    bit for bit), centroid pairs that differ only where x is exactly 0 (same dot-product chain, same norm), a NaN row, an Inf row"""
+    rs = np.random.RandomState(seed)
+    c = rs.standard_normal((K, D)).astype(np.float32)
+    x = rs.standard_normal((40, D)).astype(np.float32)
+    c[17] = c[5]                    # duplicates: 5 must win whenever either is the minimum
+    c[K - 1] = c[60]
+    c[31] = c[30]
+    c[31, :8] = -c[30, :8]          # differs from 30 only on dims 0..7 -> tie for every x with x[:8] == 0
+    x[:, :8] = 0.0
+    for t, k in enumerate((5, 17, 60, K - 1, 30, 31)):   # frames sitting ON a member of each tied pair
+        x[t] = c[k]
+        x[t, :8] = 0.0
+    x[20] = np.nan
+    x[21] = np.inf
+    x[22] = 0.0
+    return x, c
+
+
+def test_c_oracle_kmeans_f32_is_sklearn_on_the_goldens_and_breaks_ties_low(coracle, hgold):
+    centers = synth.synth_kmeans_centers().numpy()
+    for n in (400, 719, 4000, 16000, 32000):
+        np.testing.assert_array_equal(kmeans_f32(coracle, hgold[f"n{n}/dense"], centers), hgold[f"n{n}/units"])  # sklearn predict
+    x, c = kmeans_tie_cases()
+    u = kmeans_f32(coracle, x, c)
+    assert u[0] == 5 and u[1] == 5 and u[2] == 60 and u[3] == 60 and u[4] == 30 and u[5] == 30, u[:6]
+    assert not np.isin(u, (17, 99, 31)).any()       # the higher member of a tied pair never wins
+    assert u[20] == 0                               # NaN row: nothing beats +inf
+    # float64 argmin agrees wherever it is not an exact tie (the f32 chain and float64 can only differ at rounding-level margins)
+    import ctypes
+    u64 = np.zeros(len(x), np.int64)
+    xs, cs = np.ascontiguousarray(x[:20]), np.ascontiguousarray(c)
+    coracle.oracle_kmeans_assign(xs.ctypes.data_as(ctypes.c_void_p), 20, 768, cs.ctypes.data_as(ctypes.c_void_p), 100,
+                                 u64.ctypes.data_as(ctypes.c_void_p))
+    np.testing.assert_array_equal(u[:20], u64[:20])
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
 def test_golden_fixtures_regenerate_bit_identically(tmp_path):
     """tests/golden/make_golden.py must still run against the reference and reproduce the committed
