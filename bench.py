@@ -55,7 +55,7 @@ def host_cpu_info():
 
 PARITY_TOL_RMS = 1e-4   # north_star / BASELINE.md 4.5: RMS(gpu - cpu) <= 1e-4 ...
 PARITY_TOL_REL = 1e-3   # ... and <= 1e-3 of the reference waveform's RMS
-SCHEMA = 4              # bench line layout version (round number of the last change of workloads / fields)
+SCHEMA = 5              # bench line layout version (round number of the last change of workloads / fields)
 
 
 def parity_vs(ref_waves, y_host):
@@ -72,11 +72,13 @@ def parity_vs(ref_waves, y_host):
                        "utterance, the waveforms the cpu_baseline leg produced while being timed"}
 
 
-def cpu_baseline(synth, sd, code, f0, spkr, budget_s=14.0, max_utts=400, keep=8):
+def cpu_baseline(synth, sd, code, f0, spkr, budget_s=9.0, max_utts=400, keep=8, node_leg=True):
     """The CPU oracle (kind='port': plain-PyTorch restatement pinned to the reference,
     tests/test_oracle_golden.py) timed the way the reference runs: B=1 per utterance on the host
     cores.  Bounded sample of the same workload: thread count picked by a probe on a full 10 s
-    utterance, then 3 warm-ups and >= 5 timed utterances; the value is 10 s / median time."""
+    utterance, then 3 warm-ups and >= 5 timed utterances; the value is 10 s / median time.
+    `node` (BASELINE.md 4.3 "the node's own host cores"): the same stream run P = floor(physical / threads) times at once on
+    disjoint cores (cpu_baseline_node) -- the reference's own deployment shape (Pool(8), sr/inference.py:351-354)."""
     from oracle import generator_ref as gr
     w = gr.fold_state_dict(sd)
     phys, logical, model = host_cpu_info()
@@ -103,11 +105,96 @@ def cpu_baseline(synth, sd, code, f0, spkr, budget_s=14.0, max_utts=400, keep=8)
             waves.append(wav)
     sec = code.shape[1] * 320 / 16000.0
     med = float(np.median(times))
-    return {"value": round(sec / med, 2), "unit": "audio-sec/sec", "cores": threads, "kind": "port",
+    node = None
+    if node_leg:
+        try:
+            node = cpu_baseline_node(threads, code.shape[0], code.shape[1])
+        except Exception as e:  # noqa: BLE001
+            node = {"error": f"{type(e).__name__}: {e}"}
+    return {"value": round(sec / med, 2), "unit": "audio-sec/sec", "cores": threads, "kind": "port", "node": node,
             "physical_cores": phys, "logical_cpus": logical, "cpu_model": model,
             "sample": f"{len(times)} x {sec:g} s utterances, B=1 each (reference style), torch CPU fp32, {threads} threads "
                       f"(best of a probe on a full utterance), 3 warm-ups, median of {len(times)} "
                       f"(mean rate {sec * len(times) / sum(times):.2f}), {sum(times):.1f} s of CPU work"}, waves
+
+
+def _physical_core_sets(threads):
+    """Disjoint sets of `threads` logical CPUs, ONE per physical core, neighbours in (socket, core) order -- the cores this
+    process may run on, cut into floor(physical / threads) groups."""
+    import subprocess
+    avail = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    first = {}
+    try:
+        rows = subprocess.run(["lscpu", "-p=CPU,CORE,SOCKET"], capture_output=True, text=True, timeout=20).stdout
+        for ln in rows.splitlines():
+            if ln.startswith("#") or not ln.strip():
+                continue
+            cpu, core, sock = (ln.split(",") + ["0", "0"])[:3]
+            if int(cpu) in avail:
+                first.setdefault((int(sock), int(core)), int(cpu))
+    except Exception:
+        pass
+    cpus = [first[k] for k in sorted(first)] or sorted(avail)
+    return [cpus[i:i + threads] for i in range(0, len(cpus) - threads + 1, threads)]
+
+
+def cpu_node_worker(argv):
+    """`python bench.py --cpu-node-worker T0 DURATION THREADS B T cpu,cpu,...`: one B=1 oracle stream pinned to its own cores
+    (a worker of cpu_baseline's whole-host leg; the reference's deployment is a Pool(8) of such workers, sr/inference.py:351-354).
+    Prints one JSON line: utterances finished inside [T0, T0 + DURATION)."""
+    t0, dur, threads, B, T = float(argv[0]), float(argv[1]), int(argv[2]), int(argv[3]), int(argv[4])
+    cpus = [int(c) for c in argv[5].split(",")]
+    if hasattr(os, "sched_setaffinity"):
+        os.sched_setaffinity(0, cpus)
+    torch.set_num_threads(threads)
+    import synthdata as synth
+    from oracle import generator_ref as gr
+    w = gr.fold_state_dict(synth.synth_generator_state_dict(seed=0))
+    code, f0, spkr, _ = synth.synth_generator_inputs(B, T, seed=1234)
+    code, f0, spkr = torch.from_numpy(code), torch.from_numpy(f0), torch.from_numpy(spkr)
+    one = lambda b: gr.code_generator(w, synth.VCTK_CONFIG, code[b:b + 1], f0[b:b + 1], spkr[b:b + 1])
+    one(0)
+    one(1 % B)
+    ready = time.time()
+    while time.time() < t0:
+        time.sleep(0.001)
+    n, ends = 0, []
+    while time.time() < t0 + dur:
+        one(n % B)
+        n += 1
+        ends.append(time.time() - t0)
+    done = sum(1 for e in ends if e <= dur)
+    print(json.dumps({"done": done, "late_start_s": max(0.0, ready - t0), "last_end": ends[-1] if ends else 0.0}), flush=True)
+
+
+def cpu_baseline_node(threads, B, T, duration=5.0, lead=9.0):
+    """Whole-host figure next to the single-stream one: P = floor(physical cores / threads) concurrent B=1 oracle workers on
+    disjoint core sets (fresh processes, `threads` threads each, same utterances), all measuring the same `duration` seconds of
+    wall time; aggregate audio-sec/sec = finished utterances x utterance length / duration."""
+    import subprocess
+    sets = _physical_core_sets(threads)
+    if len(sets) < 2:
+        return {"skipped": f"{len(sets)} core set(s) of {threads} threads on this host"}
+    t0 = time.time() + lead  # the workers import torch, fold the weights and warm up before T0
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-node-worker", repr(t0), str(duration), str(threads),
+                               str(B), str(T), ",".join(map(str, cs))], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                              env=dict(os.environ, OMP_NUM_THREADS=str(threads), CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+             for cs in sets]
+    res = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=lead + duration + 60)
+            res.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception as e:  # noqa: BLE001
+            pr.kill()
+            res.append({"done": 0, "error": f"{type(e).__name__}: {e}"})
+    sec = T * 320 / 16000.0
+    done = sum(r.get("done", 0) for r in res)
+    return {"value": round(done * sec / duration, 2), "unit": "audio-sec/sec", "workers": len(sets), "threads_per_worker": threads,
+            "cores": len(sets) * threads, "utterances": done, "window_s": duration,
+            "late_workers": sum(1 for r in res if r.get("late_start_s", 0) > 0 or "error" in r),
+            "sample": f"{len(sets)} concurrent B=1 oracle processes x {threads} threads on disjoint physical cores "
+                      f"(sched_setaffinity), {done} x {sec:g} s utterances finished in a common {duration:g} s window"}
 
 
 class _FakeGenerator:
@@ -484,6 +571,8 @@ def hbm_traffic(B, T):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-node-worker":
+        return cpu_node_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -641,6 +730,8 @@ def main():
             "value": round(value, 1), "unit": "audio-sec/sec", "n_gpus": n_gpus,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "backend": backend if dist is not None else None,
+            "rccl_ranks_seen": (dist.get_world_size() if dist is not None else 1),  # what the initialised process group reports
             "data": "synthetic (seeded codes/f0/speakers, seeded random weights in the reference checkpoint layout)",
             "config": {"workload": "HiFi-GAN generator only (sr/inference.py generate()), "
                                    f"B={B} x T={T} frames (10 s @16 kHz) per GPU, VCTK hubert100_lut config",
@@ -704,6 +795,20 @@ def main():
                     parity_failed = f"fp32 path: rms {pr['rms']:.3e} (tol {PARITY_TOL_RMS}), rel {pr['rel']:.3e} (tol {PARITY_TOL_REL})"
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        elif not a.no_cpu_baseline and not fake:
+            # N > 1: no CPU timing (rank 0, N = 1 only), but rank 0's timed batch is still checked against the oracle in the same run
+            try:
+                from oracle import generator_ref as gr
+                wf = gr.fold_state_dict(sd)
+                torch.set_num_threads(min(16, os.cpu_count() or 1))
+                tc, tf, ts = torch.from_numpy(code), torch.from_numpy(f0), torch.from_numpy(spkr)
+                ref_waves = [gr.code_generator(wf, synth.VCTK_CONFIG, tc[b:b + 1], tf[b:b + 1], ts[b:b + 1]) for b in range(2)]
+                out["parity"] = parity_vs(ref_waves, y_head)
+                pr = out["parity"]
+                if not (pr["rms"] <= PARITY_TOL_RMS and pr["rel"] <= PARITY_TOL_REL):
+                    parity_failed = f"fp32 path, rank 0 of {n_gpus}: rms {pr['rms']:.3e}, rel {pr['rel']:.3e}"
+            except Exception as e:  # noqa: BLE001
+                out["parity"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
         if parity_failed:
             print("bench.py: PARITY FAILED -- " + parity_failed, file=sys.stderr, flush=True)

@@ -93,6 +93,24 @@ def track_f0(wav, ns, frames, args):
     return [[float(v) for v in f0_per_unit(t, int(T)).astype(np.float32)] for t, T in zip(tracks, frames)]
 
 
+def partial_fingerprint(args):
+    """What a `<out_file>.partial` left by a dead run must agree on before its lines are reused: the input directory, the
+    model / quantiser / vocabulary, the F0 mode and the checkpoint files (name, size, mtime).  A leftover from a run with another
+    --base_dir (same file names), another quantiser or another --f0 mode would otherwise be spliced into the new manifest."""
+    ck = os.path.abspath(args.checkpoint_dir) if args.checkpoint_dir else None
+    ck_files = []
+    if ck and os.path.isdir(ck):
+        for fn in sorted(os.listdir(ck)):
+            st = os.stat(os.path.join(ck, fn))
+            ck_files.append([fn, st.st_size, int(st.st_mtime)])
+    return {"base_dir": os.path.abspath(args.base_dir), "model_name": args.model_name, "quantizer_name": args.quantizer_name,
+            "vocab_size": int(args.vocab_size), "f0": args.f0, "checkpoint_dir": ck, "checkpoint_files": ck_files}
+
+
+def partial_header(args):
+    return (json.dumps({"dissc_encode_partial": 1, "fingerprint": partial_fingerprint(args)}) + "\n").encode()
+
+
 def main(argv=None):
     tm = _Timing()
     parser = argparse.ArgumentParser()
@@ -137,27 +155,54 @@ def main(argv=None):
     # reference's per-line 'a+' does).  A run that died leaves the .partial behind: the next run over the same
     # directory resumes from it (files whose line is already there are not encoded again).
     partial = str(args.out_file) + '.partial'
+    commit = partial + '.commit'  # exists while the ordered lines are being appended to out_file: {"out_size_before": N}
+    if os.path.exists(commit):
+        # the previous run died INSIDE the final append: undo the torn append, so that the rerun cannot duplicate lines
+        try:
+            before = int(json.load(open(commit))["out_size_before"])
+            if os.path.exists(args.out_file) and os.path.getsize(args.out_file) > before:
+                with open(args.out_file, 'r+b') as fo:
+                    fo.truncate(before)
+                print(f"{args.out_file}: rolled back an interrupted append to {before} bytes")
+        except (ValueError, KeyError, OSError) as e:
+            print(f"ignoring unreadable {commit}: {e}")
+        os.remove(commit)
     where = {}  # file -> (offset, length) of its line in .partial
+    header = partial_header(args)
+    from dissc_amd import lib as _lib
     if os.path.exists(partial):
         good = 0
         with open(partial, 'rb') as fi:
-            while True:
-                off, raw = fi.tell(), fi.readline()
-                if not raw:
-                    break
-                try:
-                    name = json.loads(raw)["audio"] if raw.endswith(b"\n") else None
-                except ValueError:
-                    name = None
-                if name is None:  # a torn last line: cut it off
-                    break
-                if name in lengths:
-                    where[name] = (off, len(raw))
-                good = off + len(raw)
-        with open(partial, 'r+b') as fo:
-            fo.truncate(good)
+            first = fi.readline()
+            if first != header:
+                print(f"discarding {partial}: it was written by a run with a different configuration (or an older version)")
+            else:
+                good = len(first)
+                while True:
+                    off, raw = fi.tell(), fi.readline()
+                    if not raw:
+                        break
+                    try:
+                        d = json.loads(raw) if raw.endswith(b"\n") else None
+                        name = d["audio"] if d is not None else None
+                    except (ValueError, KeyError, TypeError):
+                        name = None
+                    if name is None:  # a torn last line: cut it off
+                        break
+                    # (a line whose unit count does not fit this file's sample count is not this file's: encode it again)
+                    if name in lengths and len(d.get("units", ())) == _lib.dissc_hubert_frames(int(lengths[name])):
+                        where[name] = (off, len(raw))
+                    good = off + len(raw)
+        if good == 0:
+            os.remove(partial)
+        else:
+            with open(partial, 'r+b') as fo:
+                fo.truncate(good)
         if where:
             print(f"resuming from {partial}: {len(where)} of {len(lengths)} files already encoded")
+    if not os.path.exists(partial):
+        with open(partial, 'wb') as fo:
+            fo.write(header)
     order = [f for f in order if f not in where]
     tm.add('scan_headers')
     i = 0
@@ -189,13 +234,24 @@ def main(argv=None):
                 fo.write(raw)
         tm.add('json_lines')
     if where:
+        # appended like the reference's per-line 'a+' -- but a crash inside this phase must not leave half an append that the
+        # rerun would repeat: the size before the append is recorded first (see `commit` above)
+        before = os.path.getsize(args.out_file) if os.path.exists(args.out_file) else 0
+        with open(commit, 'w') as fc:
+            json.dump({"out_size_before": before}, fc)
+            fc.flush()
+            os.fsync(fc.fileno())
         with open(args.out_file, 'ab') as fo, open(partial, 'rb') as fi:
             for f in files:
                 if f in where:
                     fi.seek(where[f][0])
                     fo.write(fi.read(where[f][1]))
+            fo.flush()
+            os.fsync(fo.fileno())
     if os.path.exists(partial):
         os.remove(partial)
+    if os.path.exists(commit):
+        os.remove(commit)
     tm.add('ordered_manifest')
     tm.dump(files=len(where))
 

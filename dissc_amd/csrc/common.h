@@ -9,9 +9,85 @@
 
 #include "../../include/dissc_hip.h"
 
+// 1 (-DDISSC_EXPERIMENTAL=1, `DISSC_EXPERIMENTAL=1 python -c "import __graft_entry__ as g; g.build()"`): the library also carries the
+// kernels whose gates FAILED -- kept as tested opt-ins for the record, not shipped by default (conv_s2tc.hip, respair_wino.hip, the
+// k = 3 instances of the F(2,3) pair kernels, hipGraph replay).  dissc_get_option("experimental") reads it back.
+#ifndef DISSC_EXPERIMENTAL
+#define DISSC_EXPERIMENTAL 0
+#endif
+
 namespace dissc {
 
 void set_error(const char* fmt, ...);
+
+// ---- tuning options -----------------------------------------------------------------------------------------------------------
+// ONE struct.  `g_defaults` is what dissc_set_option writes: the defaults of handles created LATER.  Every handle (generator,
+// HuBERT, predictor, trainer) takes a SNAPSHOT when it is created and every entry point that works on a handle runs under an
+// OptScope of that snapshot, so a forward never reads process-wide state ("re-entrant per handle, no global state"):
+// two handles created under different options keep their own behaviour whatever is set in between.  Code without a handle (the
+// stand-alone test / bench entries) sees the defaults.  X(field, default, "key of dissc_set_option").
+#define DISSC_OPTION_LIST(X) \
+  X(multistream, 1, "multistream") \
+  X(stream_prio, 1, "stream_prio") \
+  X(par_ups, 1, "par_ups") \
+  X(graphs, 0, "graphs") \
+  X(graph_frames, 2048, "graph_frames") \
+  X(pair_dma, 1, "pair_dma") \
+  X(precision, 0, "precision") \
+  X(use_mfma32, 1, "mfma32") \
+  X(ragged_enum, 1, "ragged_enum") \
+  X(pos48, 1, "pos48") \
+  X(lin_tile, 2, "lin_tile") \
+  X(cpb2, 0, "cpb2") \
+  X(lin_dma, 1, "lin_dma") \
+  X(conv_pad_lds, 0, "conv_pad_lds") \
+  X(c64_wide, 1, "c64_wide") \
+  X(conv2_dma, 1, "conv2_dma") \
+  X(mfast, 0, "mfast") \
+  X(small_grid, 1, "small_grid") \
+  X(enc_tc, 0, "enc_tc") \
+  X(s2tc_xmode, 0, "s2tc_xmode") \
+  X(s2tc_dbg, 0, "s2tc_dbg") \
+  X(wino_min_c, 64, "wino_min_c") \
+  X(wino_c64_kmin, 3, "wino_c64_kmin") \
+  X(wino_small, 96, "wino_small") \
+  X(wino_dbg, 0, "wino_dbg") \
+  X(wino_cpr, 32, "wino_cpr") \
+  X(wino_sv, 1, "wino_sv") \
+  X(wino8_dbg, 0, "wino8_dbg") \
+  X(wino8_c64_wide, 3, "wino8_c64_wide") \
+  X(wino8_mask, 0770770771, "wino8_mask") \
+  X(wino8_r4_mask, 0770770010, "wino8_r4_mask") \
+  X(wino8_r4, 1, "wino8_r4") \
+  X(wino8, 1, "wino8") \
+  X(wino, 1, "wino") \
+  X(attn_fused, 1, "attn_fused") \
+  X(hubert_split, 1, "hubert_split") \
+  X(bf3_variant, 0, "fused_variant") \
+  X(bf3_pairs, -1, "bf3_pairs") \
+  X(pair_lds_mode, 1, "pair_lds") \
+  X(pair_pad_lds, 0, "pair_pad_lds") \
+  X(pair_max_c, 32, "pair_max_c") \
+  X(pair_f23, 3, "pair_f23") \
+  X(pair_wino, 0, "pair_wino") \
+  X(pairw_chv, 2, "pairw_chv")
+struct Options {
+#define DISSC_OPT_FIELD(f, d, k) int f = d;
+  DISSC_OPTION_LIST(DISSC_OPT_FIELD)
+#undef DISSC_OPT_FIELD
+  int cfg_for_bm[5] = {6, 5, 7, 1, 0};  // conv_mfma.hip: index log2(BM / 16) -> tile shape id ("conv_cfg_bm{16..256}")
+  int cfg32_for_bm[4] = {3, 2, 1, 0};   // conv_mfma32.hip: BM class 32, 64, 128, 256 -> tile shape id ("conv32_cfg_bm{32..256}")
+};
+extern Options g_defaults;
+extern thread_local const Options* t_opts;  // the snapshot of the handle this thread is working for, or nullptr
+inline const Options& opts() { return t_opts ? *t_opts : g_defaults; }
+struct OptScope {
+  const Options* prev;
+  explicit OptScope(const Options* o) : prev(t_opts) { t_opts = o; }
+  ~OptScope() { t_opts = prev; }
+  OptScope(const OptScope&) = delete;
+  OptScope& operator=(const OptScope&) = delete;
+};
 
 #define DISSC_HIP_CHECK(expr)                                                       \
   do {                                                                              \
@@ -24,6 +100,21 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One-time-per-DEVICE guard for hipFuncSetAttribute(MaxDynamicSharedMemorySize): the attribute is per device, and a process may
+// hold handles on several GPUs (a process-wide flag would set it on the first device only).  Usage:
+//   static DeviceOnce once;  if (once.first()) { hipFuncSetAttribute(...); }
+struct DeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    bool& d = done[dev & 63];
+    const bool f = !d;
+    d = true;
+    return f;
+  }
+};
 
 #ifdef __HIPCC__
 // erf to < 1 ulp without a branch (HuBERT's exact-erf GELU sits in VALU-bound epilogues, and a wave with lanes on both sides
@@ -121,29 +212,16 @@ int conv32_tile_bn(int M);
 int conv32_cfg(int M);
 int conv32_pick_cfg(int M, int B, int Lmax_out);  // per-launch choice (steps down on small grids)
 int conv32_cfg_bn(int cfg);
-extern int g_small_grid;
 void conv32_set_cfg(int bm_class, int cfg);
 void pack_conv_weights32(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
                          int& Mpad, int& nchunk, int groups);
-extern int g_attn_fused;
-extern int g_hubert_split;
-extern int g_lin_tile;
-extern int g_cpb2;
-extern int g_conv2_dma;
-extern int g_c64_wide;
-extern int g_pos48;       // tuning: 48-row groups on the 16x16x4 kernel
-extern int g_lin_dma;     // tuning: LDS-DMA staging of the 1x1 convs
-extern int g_mfast;       // tuning: 0 disables the M-fastest block order
 // split-bf16 ("precision" = 1) form of the same conv (conv_bf3.hip); groups == 1 only
 void pack_conv_weights_bf3(const float* w, int Cout, int Cin, int KS, std::vector<float>& packed,
                            int& Mpad, int& nchunk);
 int launch_conv_bf3(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream);
 int conv_bf3_tile_bn(int M);
-extern int g_precision;   // "precision" option: 0 = fp32 (default); 1 = split-bf16 generator (read at create)
-extern thread_local int g_conv_prec;   // precision make_conv packs for: g_precision inside dissc_gen_create, else 0
+extern thread_local int g_conv_prec;   // precision make_conv packs for: opts().precision inside dissc_gen_create, else 0
                           // (predictors and HuBERT feed integer decisions and always stay fp32)
-extern int g_use_mfma32;  // tuning: 0 forces the 16x16x4 kernel everywhere
-extern int g_ragged_enum; // "ragged_enum" option: conv_mfma32_kernel enumerates only the tiles that exist on ragged batches
 
 // Host-side weight packing.  w: [Cout][Cin][KS] (Conv1d layout).  Returns the packed
 // buffer (Mpad/16 * nchunk * KS * 64 float4) and Mpad (M rounded up to 16).
@@ -197,15 +275,8 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
                 int epi, float mrf_div, hipStream_t stream, float out_slope = 0.f, int dma_in = 0);
 
 // Toom-Cook F(4,3) form of the wide ResBlock convs (conv_wino.hip)
-extern int g_wino;        // "wino" option (read at dissc_gen_create): 1 = C >= wino_min_c ResBlock convs use it
-extern int g_wino_min_c;
-extern int g_wino_dbg;
-extern int g_wino_cpr;
-extern int g_wino_sv;
-extern int g_wino_small;
 bool wino_supported(int Cout, int Cin, int KS, int dil);
 bool wino_wanted(int C, int KS);
-extern int g_wino_c64_kmin;
 int make_wino(const float* w, const float* bias, int C, int KS, int dil, DevConv& dc);
 double wino_executed_macs_per_t(int C, int KS);
 int run_wino(const DevConv& dc, const float* x, float* out, const float* res, float* acc, const int32_t* lengths,
@@ -213,14 +284,8 @@ int run_wino(const DevConv& dc, const float* x, float* out, const float* res, fl
              hipStream_t stream);
 
 // Toom-Cook F(6,3) form on 8-wave workgroups (conv_wino8.hip): the k = 7 / 11 ResBlock convs of the C >= 64 stages
-extern int g_wino8;      // "wino8" option (read at dissc_gen_create)
-extern int g_wino8_dbg;
-extern int g_wino8_c64_wide;
-extern int g_wino8_mask;
 bool wino8_supported(int Cout, int Cin, int KS, int dil);
 bool wino8_wanted(int C, int KS, int dil);
-extern int g_wino8_r4;   // "wino8_r4" option: the eight points as F(5,4) (4-tap sub-filters) where wino8_r4_mask says so
-extern int g_wino8_r4_mask;
 bool wino8_r4_supported(int C, int KS, int dil);
 int wino8_taps(int C, int KS, int dil);  // 3 or 4: the generator's policy for a wino8 layer
 int make_wino8(const float* w, const float* bias, int C, int KS, int dil, DevConv& dc, int R = 3);  // sets dc.wino = 2, dc.wr = R
@@ -239,13 +304,10 @@ struct DevPairW {
   int form = 0;  // 0: respair_wino_kernel (F(4,3), Y exchanged through LDS); 1: respair32_f23_kernel (F(2,3), register-only)
 };
 // register-only F(2,3) pairs of the 32-channel stage, k = 11 (respair_f23.hip)
-extern int g_pair_f23;   // "pair_f23" option (read at dissc_gen_create)
 bool pair_f23_supported(int C, int KS, int dil);
 int pack_pair_f23(const float* w, float** dev, int C, int KS);
 int launch_pair_f23(const DevPairW& pw, const float* x, float* out, float* acc, const int32_t* lengths, int len_default,
                     int len_mul, int B, int Lmax, int ld, float slope, int epi, float mrf_div, hipStream_t stream);
-extern int g_pair_wino;  // "pair_wino" option (read at dissc_gen_create)
-extern int g_pairw_chv;  // "pairw_chv" option
 bool pairw_supported(int C, int KS, int dil);
 bool pairw_wanted(int C, int KS, int dil);  // the generator's policy ("pair_wino" option)
 int make_pairw(const float* w1, const float* b1, const float* w2, const float* b2, int C, int KS, int dil, DevPairW& pw);
@@ -254,10 +316,6 @@ int launch_respair_wino(const DevPairW& pw, const float* x, float* out, float* a
                         int len_mul, int B, int Lmax, int ld, float slope, int epi, float mrf_div, hipStream_t stream);
 
 // one residual pair y = x + conv_1(lrelu(conv_d(lrelu(x)))) per launch, exact fp32 (respair.hip)
-extern int g_pair_pad_lds;
-extern int g_conv_pad_lds;
-extern int g_pair_lds_mode;
-extern int g_pair_max_c;  // "pair_max_c" option: widest stage run this way (0 = off)
 bool respair_supported(int C, int KS, int dil);
 int launch_respair(const DevConv& c1, const DevConv& c2, const float* x, float* out, float* acc,
                    const int32_t* lengths, int len_default, int len_mul, int B, int Lmax, int ld, float slope,
@@ -265,7 +323,6 @@ int launch_respair(const DevConv& c1, const DevConv& c2, const float* x, float* 
 
 // the same block in split-bf16 arithmetic ("precision" = 1 only; resblock_bf3.hip)
 bool resblock_bf3_supported(int C, int KS, const int* dil);
-void resblock_bf3_set_variant(int v);
 void pack_resblock_bf3(int C, int KS, const float* const* w6, std::vector<float>& packed);
 // residual pairs [m0, m1) of the block; epi = EPI_STORE writes x_k to `acc` (a partial block)
 int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, const float* bias,
@@ -273,7 +330,6 @@ int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, c
                         int B, int Lmax, int ld, float slope, int epi, float mrf_div, int m0, int m1,
                         hipStream_t stream);
 bool resblock_bf3_pairs(int C);  // run the block as three pair launches (wide halos, little LDS)
-void resblock_bf3_set_pairs(int v);
 
 // HuBERT's stride-2, k = 3 feature convs in polyphase Toom-Cook form (conv_s2tc.hip)
 struct DevS2tc {
@@ -281,9 +337,6 @@ struct DevS2tc {
   float* bias = nullptr;   // [M] or nullptr
   int CIN = 0, M = 0, act = 0;
 };
-extern int g_enc_tc;      // "enc_tc" option (read at dissc_hubert_create)
-extern int g_s2tc_xmode;  // "s2tc_xmode" option
-extern int g_s2tc_dbg;
 bool s2tc_supported(int Cout, int Cin, int KS, int stride);
 int make_s2tc(const float* w, const float* bias, int Cout, int Cin, DevS2tc& dc);
 void free_s2tc(DevS2tc& dc);

@@ -230,11 +230,10 @@ static int launch_bf3_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   dim3 grid((Lmax_out + BN - 1) / BN, a.mt_per_group, B);
   size_t lds = (size_t)2 * 4 * a.XW * 16;
   if (lds < (size_t)WM * WN * 8 * CW * sizeof(float)) lds = (size_t)WM * WN * 8 * CW * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;  // per device (common.h)
+  if (attr_once.first()) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<MI, NI, WM, WN>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
   }
   hipLaunchKernelGGL((conv_bf3_kernel<MI, NI, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
@@ -248,13 +247,13 @@ int launch_conv_bf3(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream) 
     return DISSC_EINVAL;
   }
   const int cls = bf3_class(a.M);
-  if (cls >= 2 && g_small_grid) {
+  if (cls >= 2 && opts().small_grid) {
     // small grids (short or single utterances): 64 x 128 tiles instead of the 128-accumulator ones,
     // same MFMA sequence per output element, bit-identical result (cf. conv32_pick_cfg)
     const TileBf3& t = kBf3[cls];
     const int bm = 32 * t.MI * t.WM, bn = 32 * t.NI * t.WN;
     const long long nwg = (long long)((Lmax_out + bn - 1) / bn) * ((a.M + bm - 1) / bm) * B;
-    if (nwg < 256LL * g_small_grid) return launch_bf3_t<1, 2, 2, 2>(a, B, Lmax_out, stream);
+    if (nwg < 256LL * opts().small_grid) return launch_bf3_t<1, 2, 2, 2>(a, B, Lmax_out, stream);
   }
   switch (cls) {
     case 0: return launch_bf3_t<1, 2, 1, 4>(a, B, Lmax_out, stream);

@@ -6,11 +6,8 @@
 
 namespace dissc {
 
-int g_use_mfma32 = 1;
-int g_ragged_enum = 1;  // "ragged_enum" option (conv_mfma32.hip)
-int g_pos48 = 1;
-int g_precision = 0;
-thread_local int g_conv_prec = 0;  // (per thread: handles may be built concurrently) what make_conv packs for; dissc_gen_create raises it to g_precision for its own layers
+// option "ragged_enum" (Options::ragged_enum, default 1): "ragged_enum" option (conv_mfma32.hip)
+thread_local int g_conv_prec = 0;  // (per thread: handles may be built concurrently) what make_conv packs for; dissc_gen_create raises it to opts().precision for its own layers
 
 int upload(const std::vector<float>& h, float** d) {
   DISSC_HIP_CHECK(hipMalloc((void**)d, h.size() * sizeof(float)));
@@ -26,7 +23,7 @@ int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int 
   const int Mg = Cout / groups, Cg = Cin / groups;
   // 64-cycle MFMAs wherever a 32-row tile is not mostly padding; 48 rows per group (HuBERT's positional conv) are three
   // 16-row tiles of the 16x16x4 kernel instead of two 32-row tiles of which a quarter is padding ("pos48" option)
-  dc.m32 = (g_use_mfma32 && Mg >= 32 && !(g_pos48 && Mg == 48 && groups > 1)) ? 1 : 0;
+  dc.m32 = (opts().use_mfma32 && Mg >= 32 && !(opts().pos48 && Mg == 48 && groups > 1)) ? 1 : 0;
   // split-bf16 only where conv_mfma32.hip has an instance for it
   const bool lin_big = (KS == 1 && Mg >= 256 && (Cg + KC - 1) / KC >= 8);
   dc.prec = (g_conv_prec == 1 && dc.m32 && stride == 1 && groups == 1 && (KS - 1) * dil <= MAX_TAP_SPAN && !lin_big)

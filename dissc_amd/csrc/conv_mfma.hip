@@ -303,10 +303,9 @@ static const TileCfg kCfgs[] = {
     {3, 4, 1, 4},  // 10: 48 x 256 (pick_bm(48) only)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
-static int g_cfg_for_bm[5] = {6, 5, 7, 1, 0};  // index log2(BM/16) -> cfg id (tunable)
 
 void conv_set_cfg(int bm_class, int cfg) {
-  if (bm_class >= 0 && bm_class < 5 && cfg >= 0 && cfg < kNumCfgs) g_cfg_for_bm[bm_class] = cfg;
+  if (bm_class >= 0 && bm_class < 5 && cfg >= 0 && cfg < kNumCfgs) g_defaults.cfg_for_bm[bm_class] = cfg;
 }
 
 int conv_cfg(int M) {
@@ -314,7 +313,7 @@ int conv_cfg(int M) {
   if (bm == 48) return 10;
   int cls = 0;
   while ((16 << cls) < bm) ++cls;
-  int cfg = g_cfg_for_bm[cls];
+  int cfg = opts().cfg_for_bm[cls];
   if (16 * kCfgs[cfg].MI * kCfgs[cfg].WM > bm) cfg = 4 - cls;  // override must divide the padded M
   return cfg;
 }
@@ -379,12 +378,11 @@ static int launch_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   size_t lds_f = (size_t)2 * KC * CPB * a.XW;
   if (lds_f < (size_t)NW * 16 * CW) lds_f = (size_t)NW * 16 * CW;
   const size_t lds = lds_f * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;  // per device (common.h)
+  if (attr_once.first()) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv_mfma_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
   }
   hipLaunchKernelGGL((conv_mfma_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>), grid, dim3(64 * WM * WN), lds,
                      stream, a);

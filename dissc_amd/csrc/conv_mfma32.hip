@@ -301,17 +301,16 @@ static const TileCfg32 kCfgs32[] = {
     {1, 1, 2, 2},  // 10:  64 x 64   (small grids only, see conv32_pick_cfg)
     {1, 1, 1, 4},  // 11:  32 x 128  (likewise)
 };
-int g_lin_tile = 2;  // "lin_tile" option: channels per barrier / 16 of the 1x1 (linear) convs (2 or 4)
-int g_cpb2 = 0;  // "cpb2" option: kernels with KS <= this stage 32 channels per barrier
-int g_lin_dma = 1;  // "lin_dma" option: 1x1 convs stage their window with global_load_lds (1: 64, 2: 32 channels per barrier)
-int g_conv_pad_lds = 0;  // "conv_pad_lds" option (diagnostics): extra LDS bytes per workgroup
-int g_c64_wide = 1;  // "c64_wide" option: 64 x 256 tile (64 x 64 wave tiles) for the DMA-staged second convs of the C = 64 stage
-int g_conv2_dma = 1;  // "conv2_dma" option: stride-2 valid convs stage their window with global_load_lds
-int g_mfast = 0;  // measured neutral on HuBERT linears (weights are L2/MALL resident either way)
-static int g_cfg32_for_bm[4] = {3, 2, 1, 0};  // BM class 32, 64, 128, 256 -> cfg id
+// option "lin_tile" (Options::lin_tile, default 2): "lin_tile" option: channels per barrier / 16 of the 1x1 (linear) convs (2 or 4)
+// option "cpb2" (Options::cpb2, default 0): "cpb2" option: kernels with KS <= this stage 32 channels per barrier
+// option "lin_dma" (Options::lin_dma, default 1): "lin_dma" option: 1x1 convs stage their window with global_load_lds (1: 64, 2: 32 channels per barrier)
+// option "conv_pad_lds" (Options::conv_pad_lds, default 0): "conv_pad_lds" option (diagnostics): extra LDS bytes per workgroup
+// option "c64_wide" (Options::c64_wide, default 1): "c64_wide" option: 64 x 256 tile (64 x 64 wave tiles) for the DMA-staged second convs of the C = 64 stage
+// option "conv2_dma" (Options::conv2_dma, default 1): "conv2_dma" option: stride-2 valid convs stage their window with global_load_lds
+// option "mfast" (Options::mfast, default 0): measured neutral on HuBERT linears (weights are L2/MALL resident either way)
 
 void conv32_set_cfg(int bm_class, int cfg) {
-  if (bm_class >= 0 && bm_class < 4 && cfg >= 0 && cfg < 8) g_cfg32_for_bm[bm_class] = cfg;
+  if (bm_class >= 0 && bm_class < 4 && cfg >= 0 && cfg < 8) g_defaults.cfg32_for_bm[bm_class] = cfg;
 }
 
 static int bm32_of(int M) { return M >= 256 ? 256 : (M >= 128 ? 128 : (M >= 64 ? 64 : 32)); }
@@ -320,7 +319,7 @@ int conv32_cfg(int M) {
   const int bm = bm32_of(M);
   int cls = 0;
   while ((32 << cls) < bm) ++cls;
-  int cfg = g_cfg32_for_bm[cls];
+  int cfg = opts().cfg32_for_bm[cls];
   if (32 * kCfgs32[cfg].MI * kCfgs32[cfg].WM > bm) cfg = 3 - cls;
   if (cfg == 4 && cls != 0) cfg = 3 - cls;
   return cfg;
@@ -339,10 +338,10 @@ int conv32_cfg_bn(int cfg) { return 32 * kCfgs32[cfg].NI * kCfgs32[cfg].WN; }
 // launch steps down to smaller tiles.  Every output element still sees the same sequence of
 // 32x32x2 MFMAs over (chunk, tap, k), so the result is bit-identical for every tile shape and an
 // utterance's samples stay independent of the batch it runs in.
-int g_small_grid = 1;  // "small_grid" option: workgroups per CU below which a launch steps down (0 = never)
+// option "small_grid" (Options::small_grid, default 1): "small_grid" option: workgroups per CU below which a launch steps down (0 = never)
 int conv32_pick_cfg(int M, int B, int Lmax_out) {
   const int base = conv32_cfg(M);
-  if (!g_small_grid) return base;
+  if (!opts().small_grid) return base;
   static const int kSteps[4][3] = {{3, 11, -1}, {2, 10, -1}, {1, 2, 10}, {0, 2, 10}};  // by BM class
   int cls = 0;
   while ((32 << cls) < bm32_of(M)) ++cls;
@@ -353,7 +352,7 @@ int conv32_pick_cfg(int M, int B, int Lmax_out) {
     const TileCfg32& c = kCfgs32[pick];
     const int bm = 32 * c.MI * c.WM, bn = 32 * c.NI * c.WN;
     const long long nwg = (long long)((Lmax_out + bn - 1) / bn) * ((M + bm - 1) / bm) * B;
-    if (nwg >= 256LL * g_small_grid) break;
+    if (nwg >= 256LL * opts().small_grid) break;
   }
   return pick;
 }
@@ -394,18 +393,17 @@ static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   dim3 grid(((a.epi == EPI_STORE_ACT ? a.ldo : Lmax_out) + BN - 1) / BN, a.mt_per_group * a.groups, B);
   // Many M tiles (HuBERT's 768..3072-row linears): let blockIdx.x walk them, so that the blocks an
   // XCD receives (id % 8) share a few M tiles and their weight slices stay L2-resident.
-  a.mfast = (a.mt_per_group * a.groups >= 3 && g_mfast) ? 1 : 0;
+  a.mfast = (a.mt_per_group * a.groups >= 3 && opts().mfast) ? 1 : 0;
   if (a.mfast) grid = dim3(grid.y, grid.x, grid.z);
-  a.ragged_enum = (g_ragged_enum && (a.lengths || a.lengths_out) && a.epi != EPI_STORE_ACT && B > 1) ? 1 : 0;
+  a.ragged_enum = (opts().ragged_enum && (a.lengths || a.lengths_out) && a.epi != EPI_STORE_ACT && B > 1) ? 1 : 0;
   size_t lds_f = (size_t)2 * KC * CPB * a.XW;
   if (lds_f < (size_t)NW * 8 * CW) lds_f = (size_t)NW * 8 * CW;
-  const size_t lds = lds_f * sizeof(float) + (size_t)g_conv_pad_lds;  // (+ diagnostics: occupancy experiments)
-  static bool attr_done = false;
-  if (!attr_done) {
+  const size_t lds = lds_f * sizeof(float) + (size_t)opts().conv_pad_lds;  // (+ diagnostics: occupancy experiments)
+  static DeviceOnce attr_once;  // per device (common.h)
+  if (attr_once.first()) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB, DMA>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
   }
   hipLaunchKernelGGL((conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB, DMA>), grid, dim3(64 * WM * WN), lds,
                      stream, a);
@@ -419,7 +417,7 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
   if (stride == 2 && span <= MAX_TAP_SPAN && a.up == 1) {
     // valid (unpadded) convs on an already-activated input: raw LDS-DMA window, nothing to mask -- every output column
     // below the utterance's output length reads inputs below its input length
-    if (cfg == 0 && g_conv2_dma && a.slope == 1.0f && a.pad_left == 0 && a.groups == 1 && a.KS <= 9 && a.dil == 1 &&
+    if (cfg == 0 && opts().conv2_dma && a.slope == 1.0f && a.pad_left == 0 && a.groups == 1 && a.KS <= 9 && a.dil == 1 &&
         a.CIN % KC == 0 && a.ldx >= 4 && a.ldx % 4 == 0)
       return launch32_t<2, 2, 4, 1, 2, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);
     if (cfg == 0) return launch32_t<2, 2, 4, 1, 2, MAX_TAP_SPAN>(a, B, Lmax_out, stream);
@@ -437,16 +435,16 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
   }
   if (span == 0 && bm32_of(a.M) == 256 && a.nchunk >= 8) {  // 1x1 convs: 64 channels per barrier
     // (the tile must stay the default 256 x 64: a.XW was sized for its BN)
-    const bool dma = g_lin_dma && a.slope == 1.0f && a.pad_left == 0 && a.up == 1 && a.groups == 1 &&
+    const bool dma = opts().lin_dma && a.slope == 1.0f && a.pad_left == 0 && a.up == 1 && a.groups == 1 &&
                      a.CIN % (2 * KC) == 0 && a.ldx >= 4 && a.ldx % 4 == 0;
     // without staging registers 64 channels per barrier fit 3 waves per SIMD (measured: 28.84 -> 28.67 ms per encode)
-    if (dma && g_lin_dma == 1 && a.CIN % (4 * KC) == 0) return launch32_t<2, 2, 4, 1, 1, 0, 4, true>(a, B, Lmax_out, stream);
+    if (dma && opts().lin_dma == 1 && a.CIN % (4 * KC) == 0) return launch32_t<2, 2, 4, 1, 1, 0, 4, true>(a, B, Lmax_out, stream);
     if (dma) return launch32_t<2, 2, 4, 1, 1, 0, 2, true>(a, B, Lmax_out, stream);
-    if (g_lin_tile == 4) return launch32_t<2, 2, 4, 1, 1, 0, 4>(a, B, Lmax_out, stream);  // 64 ch / barrier
+    if (opts().lin_tile == 4) return launch32_t<2, 2, 4, 1, 1, 0, 4>(a, B, Lmax_out, stream);  // 64 ch / barrier
     return launch32_t<2, 2, 4, 1, 1, 0, 2>(a, B, Lmax_out, stream);                        // 32 ch / barrier
   }
   if (a.prec == 1) return launch_conv_bf3(a, B, Lmax_out, stream);  // split-bf16 kernels (conv_bf3.hip)
-  if (g_cpb2 && a.KS <= g_cpb2 && a.nchunk >= 4 && a.up == 1) {  // two chunks per barrier for short kernels
+  if (opts().cpb2 && a.KS <= opts().cpb2 && a.nchunk >= 4 && a.up == 1) {  // two chunks per barrier for short kernels
     if (cfg == 0) return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
     if (cfg == 1) return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
     if (cfg == 2) return launch32_t<1, 2, 2, 2, 1, MAX_TAP_SPAN, 2>(a, B, Lmax_out, stream);
@@ -455,7 +453,7 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
     // input in the EPI_STORE_ACT layout (generator: the second conv of a residual pair): raw LDS-DMA windows
     if (cfg == 0) return launch32_t<2, 2, 4, 1, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);
     if (cfg == 1) return launch32_t<2, 2, 2, 2, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);
-    if (cfg == 2 && g_c64_wide) return launch32_t<2, 2, 1, 4, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);  // 64 x 256
+    if (cfg == 2 && opts().c64_wide) return launch32_t<2, 2, 1, 4, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);  // 64 x 256
     if (cfg == 2) return launch32_t<1, 2, 2, 2, 1, MAX_TAP_SPAN, 1, true>(a, B, Lmax_out, stream);
   }
   switch (cfg) {

@@ -45,13 +45,14 @@
 
 namespace dissc {
 
-int g_enc_tc = 0;       // "enc_tc" option (read at dissc_hubert_create): 1 = conv1..conv4 of the feature extractor use this kernel.
+// option "enc_tc" (Options::enc_tc, default 0): "enc_tc" option (read at dissc_hubert_create): 1 = conv1..conv4 of the feature extractor use this kernel.
                         // OFF by default: the round-5 gate (conv1 <= 5.3 ms AND per-layer rms <= 2x the direct form's) failed on both
                         // counts -- 5.95-6.09 ms against the direct kernel's 6.30-6.45 on the same boxes (conv1..4: 11.7 vs 12.4-12.5 ms,
                         // encode 27.48 vs 27.99 ms) and 2.35x the rms error (profiles/r05/s2tc_gate.txt)
-int g_s2tc_xmode = 0;   // "s2tc_xmode" option: 0 = row tiles pinned to XCDs (weights L2-resident), 1 = row tiles of a time tile share an XCD
-int g_s2tc_dbg = 0;     // diagnostics: knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue, 3 staging loads
+// option "s2tc_xmode" (Options::s2tc_xmode, default 0): "s2tc_xmode" option: 0 = row tiles pinned to XCDs (weights L2-resident), 1 = row tiles of a time tile share an XCD
+// option "s2tc_dbg" (Options::s2tc_dbg, default 0): diagnostics: knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue, 3 staging loads
 
+#if DISSC_EXPERIMENTAL  // the round-5 gate failed (header above): built with DISSC_EXPERIMENTAL=1 only; stubs otherwise (below)
 namespace {
 
 constexpr int S2_MO = 7;                 // outputs per unit
@@ -422,13 +423,10 @@ double s2tc_executed_macs_per_out(int Cout, int Cin) { return (double)Cout * Cin
 
 template <int DBG>
 static int launch_s2tc_t(const S2tcArgs& a, long long nwg, hipStream_t stream) {
-  static bool attr_done[64] = {false};  // per device: a process may hold models on several GPUs
-  int dev = 0;
-  DISSC_HIP_CHECK(hipGetDevice(&dev));
-  if (!attr_done[dev & 63]) {
+  static DeviceOnce attr_once;  // per device (common.h)
+  if (attr_once.first()) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2tc_kernel<DBG>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done[dev & 63] = true;
   }
   hipLaunchKernelGGL(conv_s2tc_kernel<DBG>, dim3((unsigned)nwg), dim3(S2_NTH), (size_t)S2_LDS_FLOATS * sizeof(float), stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
@@ -451,7 +449,7 @@ int run_s2tc(const DevS2tc& dc, const float* x, float* out, const int32_t* lengt
   a.nrt = dc.M / 64;
   a.B = B;
   a.dbg = 0;
-  a.xmode = (g_s2tc_xmode == 0 && a.nrt <= 8 && 8 % a.nrt == 0) ? 0 : 1;
+  a.xmode = (opts().s2tc_xmode == 0 && a.nrt <= 8 && 8 % a.nrt == 0) ? 0 : 1;
   const long long ntile = (long long)a.gx * B;
   long long nwg;
   if (a.xmode == 0) {
@@ -460,7 +458,7 @@ int run_s2tc(const DevS2tc& dc, const float* x, float* out, const int32_t* lengt
   } else {
     nwg = 8LL * a.nrt * ((ntile + 7) / 8);
   }
-  switch (g_s2tc_dbg) {
+  switch (opts().s2tc_dbg) {
     case 0: return launch_s2tc_t<0>(a, nwg, stream);
     case 1: return launch_s2tc_t<1>(a, nwg, stream);
     case 2: return launch_s2tc_t<2>(a, nwg, stream);
@@ -474,9 +472,23 @@ int run_s2tc(const DevS2tc& dc, const float* x, float* out, const int32_t* lengt
     case 45: return launch_s2tc_t<45>(a, nwg, stream);
     case 61: return launch_s2tc_t<61>(a, nwg, stream);
     case 9: return launch_s2tc_t<9>(a, nwg, stream);
-    default: set_error("run_s2tc: no instance for s2tc_dbg = %d", g_s2tc_dbg); return DISSC_EINVAL;
+    default: set_error("run_s2tc: no instance for s2tc_dbg = %d", opts().s2tc_dbg); return DISSC_EINVAL;
   }
 }
+
+#else  // !DISSC_EXPERIMENTAL: the entry points stay (include/dissc_hip.h declares them), the kernel is not in this build
+bool s2tc_supported(int, int, int, int) { return false; }
+int make_s2tc(const float*, const float*, int, int, DevS2tc&) {
+  set_error("the polyphase Toom-Cook feature convs (conv_s2tc.hip) are only in DISSC_EXPERIMENTAL=1 builds");
+  return DISSC_EINVAL;
+}
+void free_s2tc(DevS2tc&) {}
+double s2tc_executed_macs_per_out(int Cout, int Cin) { return (double)Cout * Cin * 3.0; }
+int run_s2tc(const DevS2tc&, const float*, float*, const int32_t*, const int32_t*, int, int, int, int, int, int, hipStream_t) {
+  set_error("run_s2tc: only in DISSC_EXPERIMENTAL=1 builds");
+  return DISSC_EINVAL;
+}
+#endif  // DISSC_EXPERIMENTAL
 
 __global__ void s2_out_lengths_kernel(const int32_t* __restrict__ lin, int B, int k, int32_t* __restrict__ lout) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;

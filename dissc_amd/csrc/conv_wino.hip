@@ -38,13 +38,13 @@
 
 namespace dissc {
 
-int g_wino = 1;          // "wino" option: 1 = wide ResBlock convs through conv_wino_kernel (read at dissc_gen_create);
+// option "wino" (Options::wino, default 1): "wino" option: 1 = wide ResBlock convs through conv_wino_kernel (read at dissc_gen_create);
                          // 2 = the stand-alone dissc_conv1d entry uses it too (tests)
-int g_wino_min_c = 64;   // "wino_min_c" option: narrowest stage that uses it
-int g_wino_c64_kmin = 3;   // "wino_c64_kmin" option: smallest kernel size that uses it in a 64-channel stage (in the generator k = 3 /
+// option "wino_min_c" (Options::wino_min_c, default 64): "wino_min_c" option: narrowest stage that uses it
+// option "wino_c64_kmin" (Options::wino_c64_kmin, default 3): "wino_c64_kmin" option: smallest kernel size that uses it in a 64-channel stage (in the generator k = 3 /
                          // 7 gain 2 % per forward there; in isolation they are break-even against the DMA-staged direct pair)
-int g_wino_small = 96;   // "wino_small" option: launches with fewer 64 x 64-tile workgroups than this use 32 x 32 wave tiles
-int g_wino_dbg = 0;      // "wino_dbg" option (diagnostics): knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue, 3 staging
+// option "wino_small" (Options::wino_small, default 96): "wino_small" option: launches with fewer 64 x 64-tile workgroups than this use 32 x 32 wave tiles
+// option "wino_dbg" (Options::wino_dbg, default 0): "wino_dbg" option (diagnostics): knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue, 3 staging
 
 struct WinoArgs {
   const float* x;
@@ -612,8 +612,8 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
 // ---------------------------------------------------------------------------------------------
 // the generator's policy (per ResBlock): which (C, k) run in the transform domain
 bool wino_wanted(int C, int KS) {
-  if (!g_wino || C < g_wino_min_c) return false;
-  if (C < 128 && KS < g_wino_c64_kmin) return false;
+  if (!opts().wino || C < opts().wino_min_c) return false;
+  if (C < 128 && KS < opts().wino_c64_kmin) return false;
   return wino_supported(C, C, KS, 1);
 }
 
@@ -680,11 +680,10 @@ static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
   size_t lds_f = (size_t)2 * CPR * D * RL + 12 * 8 * 112;
   const size_t epi_f = (size_t)6 * 32 * (32 * TW + 4) + ((DISSC_WINO_EPI2 && D != 1 && D % 4 != 0) ? (size_t)32 * (4 * D * NTU + 4) : 0);
   if (lds_f < epi_f) lds_f = epi_f;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;  // per device (common.h)
+  if (attr_once.first()) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, DIL, CPR, RH, TW, SHV>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
   }
   WinoArgs aa = a;
   aa.gx = (Lmax + OT - 1) / OT;
@@ -701,8 +700,8 @@ static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
   return DISSC_OK;
 }
 
-int g_wino_cpr = 32;  // "wino_cpr" option: channels per barrier round (16 or 32)
-int g_wino_sv = 1;    // "wino_sv" option: shared transform in the row-half form (C >= 128)
+// option "wino_cpr" (Options::wino_cpr, default 32): "wino_cpr" option: channels per barrier round (16 or 32)
+// option "wino_sv" (Options::wino_sv, default 1): "wino_sv" option: shared transform in the row-half form (C >= 128)
 template <int NS, int DIL>
 static int launch_wino_t(const WinoArgs& a, int B, int Lmax, hipStream_t stream) {
   // Small grids (a short or single utterance: the reference's one-at-a-time mode) step down to 32 x 32 wave tiles: four
@@ -712,7 +711,7 @@ static int launch_wino_t(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
   const bool c64 = a.C % 128 != 0;
   const int ot = 4 * D * (64 / D) * (c64 ? 2 : 1);
   const long long nwg = (long long)((Lmax + ot - 1) / ot) * (c64 ? a.C / 64 : a.C / 128) * B;
-  const bool small = g_small_grid && nwg < (long long)g_wino_small;
+  const bool small = opts().small_grid && nwg < (long long)opts().wino_small;
   if (a.C == 32) return launch_wino_c<NS, DIL, 16, 1, 1>(a, B, Lmax, stream);  // diagnostics only (dissc_respair1d mode 2)
   if (c64) {
     if (small) return launch_wino_c<NS, DIL, 16, 1, 1>(a, B, Lmax, stream);  // 32 rows x 64 columns
@@ -720,8 +719,8 @@ static int launch_wino_t(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
   }
   if (small) return launch_wino_c<NS, DIL, 16, 2, 1>(a, B, Lmax, stream);    // 64 rows x 32 columns
   // (k = 11, d = 5 with 32 channels per round needs more registers than three waves per SIMD leave: 16 there)
-  const bool r32 = g_wino_cpr == 32 && a.nchunk % 2 == 0 && !(NS == 4 && DIL == 5);
-  if (g_wino_sv) {
+  const bool r32 = opts().wino_cpr == 32 && a.nchunk % 2 == 0 && !(NS == 4 && DIL == 5);
+  if (opts().wino_sv) {
     // (with 32 channels per round the k = 7 / 11 instances spill a few registers; k = 3 has room)
     if (NS == 1 && r32) return launch_wino_c<NS, DIL, 32, 2, 2, 1>(a, B, Lmax, stream);
     return launch_wino_c<NS, DIL, 16, 2, 2, 1>(a, B, Lmax, stream);
@@ -739,7 +738,7 @@ int run_wino(const DevConv& dc, const float* x, float* out, const float* res, fl
   a.C = dc.M; a.nchunk = dc.nchunk; a.pad = (dc.KS - 1) * dc.dil / 2;
   a.ldx = ldx; a.ldo = ldo;
   a.x_bstride = (long long)dc.M * ldx; a.o_bstride = (long long)dc.M * ldo;
-  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = g_wino_dbg;
+  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = opts().wino_dbg;
   // the window staging, the residual / accumulator reads and the stores are 16-byte accesses
   auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
   if (ldx < 4 || ldx % 4 || ldo % 4 || misaligned(x) || misaligned(out) || misaligned(res) || misaligned(acc)) {

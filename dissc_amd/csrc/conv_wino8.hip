@@ -35,15 +35,15 @@
 
 namespace dissc {
 
-int g_wino8 = 1;      // "wino8" option (read at dissc_gen_create): 1 (default) = the k = 7 / 11 ResBlock convs the "wino8_mask" names use
+// option "wino8" (Options::wino8, default 1): "wino8" option (read at dissc_gen_create): 1 (default) = the k = 7 / 11 ResBlock convs the "wino8_mask" names use
                       // this kernel instead of conv_wino's F(4,3) form; 0 = none; 2 = the stand-alone dissc_conv1d entry uses it too
                       // (tests).  Per launch it is 3-17 % faster than the F(4,3) form on 26 of the 36 (C, k, d, epilogue) shapes of the
                       // generator (tools/wino8_gate.py) and 4-9 % slower on the d = 1 shapes of the 128-channel stage (864 workgroups
                       // = 3.4 rounds of 256 CUs where the F(4,3) tiles make exactly 5.0): the default mask leaves that stage alone.
                       // Whole forward, same box, two runs each: 35.17 / 35.27 -> 34.84 / 34.91 ms (1.0 %), executed-FLOP utilisation
                       // 0.62 -> 0.60 (11 % fewer products on those layers in 1 % less time), in-run parity rms 5.5e-7 -> 6.5e-7.
-int g_wino8_dbg = 0;  // diagnostics: knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue
-int g_wino8_c64_wide = 3;  // "wino8_c64_wide" option, C = 64 instances: 1 = 64 x 128 tiles (768 outputs), 0 = 64 x 64, 2 = 64 x 64 built for TWO
+// option "wino8_dbg" (Options::wino8_dbg, default 0): diagnostics: knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue
+// option "wino8_c64_wide" (Options::wino8_c64_wide, default 3): "wino8_c64_wide" option, C = 64 instances: 1 = 64 x 128 tiles (768 outputs), 0 = 64 x 64, 2 = 64 x 64 built for TWO
                            // workgroups per CU (<= 128 registers, <= 80 KB LDS: their phases overlap; +3-9 % on k = 11, mixed on
                            // k = 7 as F(6,3), +2-8 % on k = 7 as F(5,4)), 3 (default) = 1 for k = 7 as F(6,3), 2 otherwise (run_wino8)
 
@@ -544,6 +544,7 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
 // host side
 // ---------------------------------------------------------------------------------------------
 bool wino8_supported(int Cout, int Cin, int KS, int dil) {
+  if (KS == 3 && !DISSC_EXPERIMENTAL && !(Cout == 64 && dil == 1)) return false;  // (see run_wino8)
   return Cout == Cin && (Cout == 64 || Cout == 128 || Cout == 256 || Cout == 512) && (KS == 3 || KS == 7 || KS == 11) &&
          (dil == 1 || dil == 3 || dil == 5);
 }
@@ -556,22 +557,22 @@ static int w8_shape_bit(int C, int KS, int dil) {
   const int cls = C >= 256 ? 2 : C >= 128 ? 1 : 0;
   return 9 * cls + 3 * (KS == 11 ? 2 : KS == 7 ? 1 : 0) + (dil == 1 ? 0 : dil == 3 ? 1 : 2);
 }
-int g_wino8_mask = 0770770771;  // "wino8_mask" option: the shapes that run on conv_wino8_kernel (the others stay on conv_wino's F(4,3)) --
+// option "wino8_mask" (Options::wino8_mask, default 0770770771): "wino8_mask" option: the shapes that run on conv_wino8_kernel (the others stay on conv_wino's F(4,3)) --
                                 // default: every k = 7 / 11 shape, and k = 3, d = 1 at C = 64 (as F(6,3) on the two-per-CU tiles: 4 of the
                                 // 6 launches of that chain, forward 33.47 -> 33.16 ms; the other k = 3 shapes measured neutral)
 bool wino8_wanted(int C, int KS, int dil) {
-  if (!g_wino8 || !g_wino || C < g_wino_min_c || !wino8_supported(C, C, KS, dil)) return false;
-  return (g_wino8_mask >> w8_shape_bit(C, KS, dil)) & 1;
+  if (!opts().wino8 || !opts().wino || C < opts().wino_min_c || !wino8_supported(C, C, KS, dil)) return false;
+  return (opts().wino8_mask >> w8_shape_bit(C, KS, dil)) & 1;
 }
 
-int g_wino8_r4 = 1;        // "wino8_r4" option (read at dissc_gen_create): 1 = the layers "wino8_r4_mask" names run the eight points as
+// option "wino8_r4" (Options::wino8_r4, default 1): "wino8_r4" option (read at dissc_gen_create): 1 = the layers "wino8_r4_mask" names run the eight points as
                            // F(5,4) (k = 7: 2 sub-filters of 4 taps, k = 11: 3) instead of F(6,3); 2 = dissc_conv1d too (tests); 0 = never
-int g_wino8_r4_mask = 0770770010;  // "wino8_r4_mask" option, same bit layout as wino8_mask (k = 3 bits ignored) -- default: every k = 7 / 11
+// option "wino8_r4_mask" (Options::wino8_r4_mask, default 0770770010): "wino8_r4_mask" option, same bit layout as wino8_mask (k = 3 bits ignored) -- default: every k = 7 / 11
                                    // shape of the C >= 128 stages, and k = 7, d = 1 at C = 64 (the rest of that stage is faster as F(6,3))
 bool wino8_r4_supported(int C, int KS, int dil) { return wino8_supported(C, C, KS, dil) && (KS == 7 || KS == 11); }
 int wino8_taps(int C, int KS, int dil) {  // taps per sub-filter the generator's policy picks for a wino8 layer
-  if (!g_wino8_r4 || !wino8_r4_supported(C, KS, dil)) return 3;
-  return ((g_wino8_r4_mask >> w8_shape_bit(C, KS, dil)) & 1) ? 4 : 3;
+  if (!opts().wino8_r4 || !wino8_r4_supported(C, KS, dil)) return 3;
+  return ((opts().wino8_r4_mask >> w8_shape_bit(C, KS, dil)) & 1) ? 4 : 3;
 }
 
 // w: [C][C][KS] -> U[p][co][ci][j] = sum_i G[p][i] w[co][ci][j + NS i], packed in A-fragment order (make_wino's, 8 points);
@@ -622,11 +623,10 @@ double wino8_executed_macs_per_t(int C, int KS, int R) { return (double)C * C * 
 template <int NS, int DIL, int MI, int NI, int WPS = 2, int R = 3>
 static int launch_wino8_t(const Wino8Args& a, int B, int Lmax, hipStream_t stream) {
   using G = Wino8Geo<NS, DIL, MI, NI, WPS, R>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;  // per device (common.h)
+  if (attr_once.first()) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<NS, DIL, MI, NI, WPS, R>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
   }
   Wino8Args aa = a;
   aa.gx = (Lmax + G::OT - 1) / G::OT;
@@ -652,7 +652,7 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
   a.C = dc.M; a.nchunk = dc.nchunk; a.pad = (dc.KS - 1) * dc.dil / 2;
   a.ldx = ldx; a.ldo = ldo;
   a.x_bstride = (long long)dc.M * ldx; a.o_bstride = (long long)dc.M * ldo;
-  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = g_wino8_dbg;
+  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = opts().wino8_dbg;
   a.gx = a.gy = a.B = 0;
   auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
   if (ldx < 4 || ldx % 4 || ldo % 4 || misaligned(x) || misaligned(out) || misaligned(res) || misaligned(acc)) {
@@ -667,7 +667,7 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
   const int ns = (dc.KS + R - 1) / R;
   // C = 64 (measured per shape, tools/wino8_c64.py): k = 7 as F(6,3) on 64 x 128 tiles, everything else -- k = 11, and k = 7 as
   // F(5,4) -- on 64 x 64 tiles built for two workgroups per CU (4 = the round's earlier policy: k = 7 wide in both forms)
-  const int c64_mode = g_wino8_c64_wide == 3 ? ((dc.KS == 7 && R == 3) ? 1 : 2) : g_wino8_c64_wide == 4 ? (dc.KS == 7 ? 1 : 2) : g_wino8_c64_wide;
+  const int c64_mode = opts().wino8_c64_wide == 3 ? ((dc.KS == 7 && R == 3) ? 1 : 2) : opts().wino8_c64_wide == 4 ? (dc.KS == 7 ? 1 : 2) : opts().wino8_c64_wide;
   // wave tile = workgroup tile: 128 rows x 64 columns for C >= 128, 64 x 128 ("wino8_c64_wide", default) or 64 x 64 for C = 64
 #define DISSC_W8(R_, NS_, D_)                                                                        \
   if (R == R_ && ns == NS_ && dc.dil == D_)                                                          \
@@ -675,7 +675,16 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
                        : (c64_mode == 1 ? launch_wino8_t<NS_, D_, 2, 4, 2, R_>(a, B, Lmax, stream)  \
                           : c64_mode == 2 ? launch_wino8_t<NS_, D_, 2, 2, 4, R_>(a, B, Lmax, stream) \
                                           : launch_wino8_t<NS_, D_, 2, 2, 2, R_>(a, B, Lmax, stream));
-  DISSC_W8(3, 1, 1) DISSC_W8(3, 1, 3) DISSC_W8(3, 1, 5) DISSC_W8(3, 3, 1) DISSC_W8(3, 3, 3) DISSC_W8(3, 3, 5)
+#if DISSC_EXPERIMENTAL  // k = 3 through this kernel: only the C = 64, d = 1 shape on two-per-CU tiles is a default (wino8_mask); the rest
+  DISSC_W8(3, 1, 1) DISSC_W8(3, 1, 3) DISSC_W8(3, 1, 5)  // measured neutral and is only in DISSC_EXPERIMENTAL=1 builds
+#else
+  if (R == 3 && ns == 1 && dc.dil == 1 && dc.M == 64 && c64_mode == 2) return launch_wino8_t<1, 1, 2, 2, 4, 3>(a, B, Lmax, stream);
+  if (R == 3 && ns == 1) {
+    set_error("run_wino8: k = 3 with C = %d, dilation %d, tile mode %d is only in DISSC_EXPERIMENTAL=1 builds", dc.M, dc.dil, c64_mode);
+    return DISSC_EINVAL;
+  }
+#endif
+  DISSC_W8(3, 3, 1) DISSC_W8(3, 3, 3) DISSC_W8(3, 3, 5)
   DISSC_W8(3, 4, 1) DISSC_W8(3, 4, 3) DISSC_W8(3, 4, 5)
   DISSC_W8(4, 2, 1) DISSC_W8(4, 2, 3) DISSC_W8(4, 2, 5) DISSC_W8(4, 3, 1) DISSC_W8(4, 3, 3) DISSC_W8(4, 3, 5)
 #undef DISSC_W8

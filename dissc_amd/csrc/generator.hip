@@ -29,20 +29,22 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+Options g_defaults;
+thread_local const Options* t_opts = nullptr;
+
 }  // namespace dissc
 
 using namespace dissc;
 
-static int g_stream_prio = 1;  // "stream_prio" option: prioritise the longer ResBlock chains
-static int g_graphs = 0;          // "graphs" option: replay small forwards from a captured hipGraph.  OFF by default:
+// option "stream_prio" (Options::stream_prio, default 1): "stream_prio" option: prioritise the longer ResBlock chains
+// option "graphs" (Options::graphs, default 0): "graphs" option: replay small forwards from a captured hipGraph.  OFF by default:
                                   // measured on ROCm 7.2 / MI355X, hipGraphLaunch of the ~85-node three-branch graph costs
                                   // 1.3-1.8 ms MORE per forward than the plain three-stream launches (tools/graph_ab.py)
-static int g_graph_frames = 2048;  // "graph_frames" option: largest B * Tmax that is graphed
-static int g_graph_hits = 0, g_graph_captures = 0;  // diagnostics (dissc_get_option)
-static unsigned g_opt_epoch = 0;   // bumped by every dissc_set_option: captured graphs of older epochs are dropped
-static int g_pair_dma = 1;  // "pair_dma" option: wide residual pairs hand their intermediate over in the EPI_STORE_ACT layout
-static int g_multistream = 1;  // "multistream" option: concurrent ResBlock chains (read at create)
-static int g_par_ups = 1;      // "par_ups" option: ConvTranspose phase groups on concurrent streams
+// option "graph_frames" (Options::graph_frames, default 2048): "graph_frames" option: largest B * Tmax that is graphed
+[[maybe_unused]] static int g_graph_hits = 0, g_graph_captures = 0;  // diagnostics (dissc_get_option)
+// option "pair_dma" (Options::pair_dma, default 1): "pair_dma" option: wide residual pairs hand their intermediate over in the EPI_STORE_ACT layout
+// option "multistream" (Options::multistream, default 1): "multistream" option: concurrent ResBlock chains (read at create)
+// option "par_ups" (Options::par_ups, default 1): "par_ups" option: ConvTranspose phase groups on concurrent streams
 
 // The side streams of the concurrent ResBlock chains are shared by every generator handle of a
 // device (created on first use, kept for the life of the process): HIP multiplexes streams onto a
@@ -66,6 +68,7 @@ static hipStream_t shared_aux_stream(int chain, int prio) {
 }
 
 struct dissc_gen {
+  Options opt;  // this handle's snapshot of the tuning options (common.h): every entry point that works on the handle runs under it
   DisscGenConfig cfg;
   int hop = 1;
   DevConv conv_pre;
@@ -90,7 +93,6 @@ struct dissc_gen {
   struct GraphEntry {
     const void *code, *f0, *spkr, *lengths, *out, *ws;
     int B, T;
-    unsigned epoch;
     hipGraphExec_t exec;
     unsigned long long stamp;
   };
@@ -149,7 +151,7 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
     set_error("dissc_gen_create_ex: precision %d (use -1 = process option, 0 = fp32, 1 = split-bf16)", precision);
     return DISSC_EINVAL;
   }
-  const int prec = precision < 0 ? g_precision : precision;  // this handle's arithmetic, fixed from here on
+  const int prec = precision < 0 ? g_defaults.precision : precision;  // this handle's arithmetic, fixed from here on
   if (!cfg || !weights || !out) {
     set_error("dissc_gen_create: null argument");
     return DISSC_EINVAL;
@@ -185,6 +187,9 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
   };
 
   dissc_gen* g = new dissc_gen();
+  g->opt = g_defaults;          // frozen here: later dissc_set_option calls do not reach this handle
+  g->opt.precision = prec;
+  OptScope opt_scope(&g->opt);
   g->cfg = *cfg;
   struct PrecScope {  // only the generator's layers may be packed for split-bf16
     explicit PrecScope(int p) { g_conv_prec = p; }
@@ -271,7 +276,7 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
           return fail(rc);
         // the whole pair as one transform-domain launch (respair_wino.hip): C = 32, k = 7 / 11 and C = 64, k = 3
         // (C = 64: only a chain's FIRST pair -- the later ones update x_k in place, which a fused pair cannot)
-        if (prec == 0 && g_wino && pairw_wanted(ch, rk, d) && (ch > 32 ? (wino && m == 0) : ch <= g_pair_max_c) &&
+        if (prec == 0 && opts().wino && pairw_wanted(ch, rk, d) && (ch > 32 ? (wino && m == 0) : ch <= opts().pair_max_c) &&
             (rc = make_pairw(w1c, b1c, w, b, ch, rk, d, g->pw[idx])))
           return fail(rc);
         if (bf3) {
@@ -304,7 +309,7 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
     if ((rc = upload(std::vector<float>(w, w + (size_t)cfg->num_speakers * E), &g->spkr_w)))
       return fail(rc);
   }
-  if (g_multistream && nk > 1) {
+  if (opts().multistream && nk > 1) {
     if (hipEventCreateWithFlags(&g->ev_x, hipEventDisableTiming) != hipSuccess) return fail(DISSC_EHIP);
     for (int j = 0; j < nk; ++j) {
       if (hipEventCreateWithFlags(&g->ev_fin[j], hipEventDisableTiming) != hipSuccess) return fail(DISSC_EHIP);
@@ -313,7 +318,7 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent, hi = most urgent (numerically lower)
       int prio = lo;
-      if (g_stream_prio && nk > 1) prio = lo + (hi - lo) * j / (nk - 1);
+      if (opts().stream_prio && nk > 1) prio = lo + (hi - lo) * j / (nk - 1);
       if (j > 0 && !(g->aux[j] = shared_aux_stream(j, prio))) return fail(DISSC_EHIP);
     }
   }
@@ -337,6 +342,7 @@ static size_t gen_buf_floats(const dissc_gen* g, int B, int Tmax) {
 
 size_t dissc_gen_workspace_bytes(dissc_gen_t g, int B, int Tmax) {
   if (!g || B <= 0 || Tmax <= 0) return 0;
+  OptScope opt_scope(&g->opt);
   return (size_t)(2 + 2 * g->cfg.num_kernels) * gen_buf_floats(g, B, Tmax) * sizeof(float) + 256;
 }
 
@@ -393,6 +399,7 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
     set_error("dissc_gen_forward: null argument");
     return DISSC_EINVAL;
   }
+  OptScope opt_scope(&g->opt);  // the forward reads this handle's options only
   if (B <= 0 || Tmax <= 0) {
     set_error("dissc_gen_forward: B=%d Tmax=%d", B, Tmax);
     return DISSC_EINVAL;
@@ -407,12 +414,15 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
     return DISSC_ENOMEM;
   }
   hipStream_t stream = (hipStream_t)stream_;
-  if (!g_graphs || g->graph_failures >= 2 || (long long)B * Tmax > g_graph_frames)
+#if !DISSC_EXPERIMENTAL  // hipGraph replay failed its gate (slower than plain launches on ROCm 7.2): DISSC_EXPERIMENTAL=1 builds only
+  return gen_forward_body(g, code, f0, spkr, lengths, B, Tmax, wav_out, workspace, stream);
+#else
+  if (!opts().graphs || g->graph_failures >= 2 || (long long)B * Tmax > opts().graph_frames)
     return gen_forward_body(g, code, f0, spkr, lengths, B, Tmax, wav_out, workspace, stream);
   // ---- small forward: replay (or first capture) its hipGraph ----
   for (auto& e : g->graphs)
     if (e.code == code && e.f0 == f0 && e.spkr == spkr && e.lengths == lengths && e.out == wav_out && e.ws == workspace &&
-        e.B == B && e.T == Tmax && e.epoch == g_opt_epoch) {
+        e.B == B && e.T == Tmax) {
       e.stamp = ++g->graph_clock;
       ++g_graph_hits;
       DISSC_HIP_CHECK(hipGraphLaunch(e.exec, stream));
@@ -439,14 +449,7 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
     ++g->graph_failures;
     return gen_forward_body(g, code, f0, spkr, lengths, B, Tmax, wav_out, workspace, stream);
   }
-  // keep the eight most recently used graphs (and none of an older option epoch)
-  for (size_t i = 0; i < g->graphs.size();)
-    if (g->graphs[i].epoch != g_opt_epoch) {
-      (void)hipGraphExecDestroy(g->graphs[i].exec);
-      g->graphs.erase(g->graphs.begin() + i);
-    } else {
-      ++i;
-    }
+  // keep the eight most recently used graphs (the handle's options are frozen: a captured graph never goes stale)
   if (g->graphs.size() >= 8) {
     size_t old = 0;
     for (size_t i = 1; i < g->graphs.size(); ++i)
@@ -455,9 +458,10 @@ int dissc_gen_forward(dissc_gen_t g, const int64_t* code, const float* f0, const
     g->graphs.erase(g->graphs.begin() + old);
   }
   ++g_graph_captures;
-  g->graphs.push_back({code, f0, spkr, lengths, wav_out, workspace, B, Tmax, g_opt_epoch, exec, ++g->graph_clock});
+  g->graphs.push_back({code, f0, spkr, lengths, wav_out, workspace, B, Tmax, exec, ++g->graph_clock});
   DISSC_HIP_CHECK(hipGraphLaunch(exec, stream));
   return DISSC_OK;
+#endif
 }
 
 static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0, const int64_t* spkr,
@@ -498,7 +502,7 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
     // (phase groups write disjoint output phases: with side streams they run concurrently, which
     // fills the CUs better than two or three small grids one after the other)
     const int ngrp = (int)g->ups[i].size();
-    const bool par_ups = multi && g_par_ups && ngrp > 1 && ngrp <= nk;
+    const bool par_ups = multi && opts().par_ups && ngrp > 1 && ngrp <= nk;
     if (par_ups) DISSC_HIP_CHECK(hipEventRecord(g->ev_x, stream));  // ACC is complete
     for (int gi = 0; gi < ngrp; ++gi) {
       hipStream_t sg = (par_ups && gi > 0) ? g->aux[gi] : stream;
@@ -599,7 +603,7 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
         }
         // wide stages: the first conv stores lrelu(t) with zero tails (EPI_STORE_ACT) so that the second one -- the only
         // reader of t -- stages its windows by LDS-DMA: no staging registers, no masks, one more wave per SIMD
-        const bool dma2 = g_pair_dma && g->rb1[idx].m32 && g->rb2[idx].m32 && !g->rb1[idx].prec && !g->rb2[idx].prec &&
+        const bool dma2 = opts().pair_dma && g->rb1[idx].m32 && g->rb2[idx].m32 && !g->rb1[idx].prec && !g->rb2[idx].prec &&
                           ch % KC == 0;
         const int ldt = dma2 ? (int)round_up((size_t)L + ZERO_TAIL, 4) : ld;
         if ((rc = run_conv(g->rb1[idx], xin, TMPc, nullptr, nullptr, lengths, L, mul, B, ch, ld, ldt,
@@ -657,9 +661,9 @@ int dissc_conv1d(const float* x, const float* w_host, const float* bias_host, fl
     return DISSC_EINVAL;
   }
   DevConv dc;
-  const bool use8 = g_wino8 >= 2 && wino8_supported(Cout, Cin, k, dilation);  // "wino8" = 2: the stand-alone entry uses it (tests)
-  if (use8 || (g_wino >= 2 && wino_supported(Cout, Cin, k, dilation))) {  // "wino" = 2: likewise for the F(4,3) form
-    const int taps = g_wino8_r4 >= 2 && wino8_r4_supported(Cout, k, dilation) ? 4 : 3;  // "wino8_r4" = 2: F(5,4) (tests)
+  const bool use8 = opts().wino8 >= 2 && wino8_supported(Cout, Cin, k, dilation);  // "wino8" = 2: the stand-alone entry uses it (tests)
+  if (use8 || (opts().wino >= 2 && wino_supported(Cout, Cin, k, dilation))) {  // "wino" = 2: likewise for the F(4,3) form
+    const int taps = opts().wino8_r4 >= 2 && wino8_r4_supported(Cout, k, dilation) ? 4 : 3;  // "wino8_r4" = 2: F(5,4) (tests)
     int rc = use8 ? make_wino8(w_host, bias_host, Cout, k, dilation, dc, taps) : make_wino(w_host, bias_host, Cout, k, dilation, dc);
     if (rc) return rc;
     rc = (use8 ? run_wino8 : run_wino)(dc, x, y, nullptr, nullptr, lengths, Lmax, 1, B, ldx, ldo, Lmax, in_slope, EPI_STORE, 1.f,
@@ -815,26 +819,21 @@ int dissc_conv_transpose1d(const float* x, const float* w_host, const float* bia
   return rc;
 }
 
+// The DEFAULTS (what handles created later start from), whatever handle the calling thread may be working for
 int dissc_get_option(const char* key, int* value) {
   if (!key || !value) return DISSC_EINVAL;
-  if (strcmp(key, "precision") == 0) { *value = g_precision; return DISSC_OK; }
-  if (strcmp(key, "multistream") == 0) { *value = g_multistream; return DISSC_OK; }
-  if (strcmp(key, "graphs") == 0) { *value = g_graphs; return DISSC_OK; }
   if (strcmp(key, "graph_hits") == 0) { *value = g_graph_hits; return DISSC_OK; }
   if (strcmp(key, "graph_captures") == 0) { *value = g_graph_captures; return DISSC_OK; }
-  if (strcmp(key, "stream_prio") == 0) { *value = g_stream_prio; return DISSC_OK; }
-  if (strcmp(key, "par_ups") == 0) { *value = g_par_ups; return DISSC_OK; }
-  if (strcmp(key, "pair_max_c") == 0) { *value = g_pair_max_c; return DISSC_OK; }
-  if (strcmp(key, "wino") == 0) { *value = g_wino; return DISSC_OK; }
-  set_error("dissc_get_option: '%s' cannot be read back", key);
+  if (strcmp(key, "experimental") == 0) { *value = DISSC_EXPERIMENTAL; return DISSC_OK; }
+#define DISSC_OPT_GET(f, d, k) if (strcmp(key, k) == 0) { *value = g_defaults.f; return DISSC_OK; }
+  DISSC_OPTION_LIST(DISSC_OPT_GET)
+#undef DISSC_OPT_GET
+  set_error("dissc_get_option: unknown key %s", key);
   return DISSC_EINVAL;
 }
 
 int dissc_set_option(const char* key, int value) {
   if (!key) return DISSC_EINVAL;
-  ++g_opt_epoch;
-  if (strcmp(key, "graphs") == 0) { g_graphs = value; return DISSC_OK; }
-  if (strcmp(key, "graph_frames") == 0) { g_graph_frames = value; return DISSC_OK; }
   if (strncmp(key, "conv_cfg_bm", 11) == 0) {  // "conv_cfg_bm16|32|64|128|256" -> tile config id
     const int bm = atoi(key + 11);
     int cls = 0;
@@ -842,40 +841,6 @@ int dissc_set_option(const char* key, int value) {
     conv_set_cfg(cls, value);
     return DISSC_OK;
   }
-  if (strcmp(key, "precision") == 0) { g_precision = value; return DISSC_OK; }
-  if (strcmp(key, "par_ups") == 0) { g_par_ups = value; return DISSC_OK; }
-  if (strcmp(key, "small_grid") == 0) { g_small_grid = value; return DISSC_OK; }
-  if (strcmp(key, "bf3_pairs") == 0) { resblock_bf3_set_pairs(value); return DISSC_OK; }
-  if (strcmp(key, "stream_prio") == 0) { g_stream_prio = value; return DISSC_OK; }
-  if (strcmp(key, "multistream") == 0) { g_multistream = value; return DISSC_OK; }
-  if (strcmp(key, "attn_fused") == 0) { g_attn_fused = value; return DISSC_OK; }
-  if (strcmp(key, "hubert_split") == 0) { g_hubert_split = value; return DISSC_OK; }
-  if (strcmp(key, "enc_tc") == 0) { g_enc_tc = value; return DISSC_OK; }
-  if (strcmp(key, "s2tc_xmode") == 0) { g_s2tc_xmode = value; return DISSC_OK; }
-  if (strcmp(key, "s2tc_dbg") == 0) { g_s2tc_dbg = value; return DISSC_OK; }
-  if (strcmp(key, "lin_tile") == 0) { g_lin_tile = value; return DISSC_OK; }
-  if (strcmp(key, "cpb2") == 0) { g_cpb2 = value; return DISSC_OK; }
-  if (strcmp(key, "mfast") == 0) { g_mfast = value; return DISSC_OK; }
-  if (strcmp(key, "ragged_enum") == 0) { g_ragged_enum = value; return DISSC_OK; }
-  if (strcmp(key, "lin_dma") == 0) { g_lin_dma = value; return DISSC_OK; }
-  if (strcmp(key, "pos48") == 0) { g_pos48 = value; return DISSC_OK; }
-  if (strcmp(key, "pair_dma") == 0) { g_pair_dma = value; return DISSC_OK; }
-  if (strcmp(key, "wino") == 0) { g_wino = value; return DISSC_OK; }
-  if (strcmp(key, "wino_min_c") == 0) { g_wino_min_c = value; return DISSC_OK; }
-  if (strcmp(key, "wino_dbg") == 0) { g_wino_dbg = value; return DISSC_OK; }
-  if (strcmp(key, "wino8") == 0) { g_wino8 = value; return DISSC_OK; }
-  if (strcmp(key, "wino8_dbg") == 0) { g_wino8_dbg = value; return DISSC_OK; }
-  if (strcmp(key, "wino8_c64_wide") == 0) { g_wino8_c64_wide = value; return DISSC_OK; }
-  if (strcmp(key, "wino8_mask") == 0) { g_wino8_mask = value; return DISSC_OK; }
-  if (strcmp(key, "wino8_r4") == 0) { g_wino8_r4 = value; return DISSC_OK; }
-  if (strcmp(key, "wino8_r4_mask") == 0) { g_wino8_r4_mask = value; return DISSC_OK; }
-  if (strcmp(key, "wino_cpr") == 0) { g_wino_cpr = value; return DISSC_OK; }
-  if (strcmp(key, "wino_sv") == 0) { g_wino_sv = value; return DISSC_OK; }
-  if (strcmp(key, "wino_small") == 0) { g_wino_small = value; return DISSC_OK; }
-  if (strcmp(key, "wino_c64_kmin") == 0) { g_wino_c64_kmin = value; return DISSC_OK; }
-  if (strcmp(key, "c64_wide") == 0) { g_c64_wide = value; return DISSC_OK; }
-  if (strcmp(key, "conv2_dma") == 0) { g_conv2_dma = value; return DISSC_OK; }
-  if (strcmp(key, "mfma32") == 0) { g_use_mfma32 = value; return DISSC_OK; }
   if (strncmp(key, "conv32_cfg_bm", 13) == 0) {
     const int bm = atoi(key + 13);
     int cls = 0;
@@ -883,14 +848,10 @@ int dissc_set_option(const char* key, int value) {
     conv32_set_cfg(cls, value);
     return DISSC_OK;
   }
-  if (strcmp(key, "pair_max_c") == 0) { g_pair_max_c = value; return DISSC_OK; }
-  if (strcmp(key, "pair_wino") == 0) { g_pair_wino = value; return DISSC_OK; }
-  if (strcmp(key, "pair_f23") == 0) { g_pair_f23 = value; return DISSC_OK; }
-  if (strcmp(key, "pairw_chv") == 0) { g_pairw_chv = value == 2 ? 2 : 1; return DISSC_OK; }
-  if (strcmp(key, "pair_pad_lds") == 0) { g_pair_pad_lds = value; return DISSC_OK; }
-  if (strcmp(key, "conv_pad_lds") == 0) { g_conv_pad_lds = value; return DISSC_OK; }
-  if (strcmp(key, "pair_lds") == 0) { g_pair_lds_mode = value; return DISSC_OK; }
-  if (strcmp(key, "fused_variant") == 0) { resblock_bf3_set_variant(value); return DISSC_OK; }
+  if (strcmp(key, "pairw_chv") == 0) value = value == 2 ? 2 : 1;
+#define DISSC_OPT_SET(f, d, k) if (strcmp(key, k) == 0) { g_defaults.f = value; return DISSC_OK; }
+  DISSC_OPTION_LIST(DISSC_OPT_SET)
+#undef DISSC_OPT_SET
   set_error("dissc_set_option: unknown key %s", key);
   return DISSC_EINVAL;
 }
@@ -909,7 +870,7 @@ int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int e
     v = ((s >> 8) / 16777216.0f - 0.5f) * 0.05f;
   }
   DevConv dc;
-  g_conv_prec = g_precision;  // diagnostics follow the "precision" option like the generator does
+  g_conv_prec = opts().precision;  // diagnostics follow the "precision" option like the generator does
   const bool w8 = (flags & 4) && wino8_supported(Cout, Cin, k, dilation);
   const bool wino = w8 || ((flags & 2) && wino_supported(Cout, Cin, k, dilation));
   int rc = w8 ? make_wino8(w.data(), bias.data(), Cout, k, dilation, dc, (flags & 8) && wino8_r4_supported(Cout, k, dilation) ? 4 : 3)

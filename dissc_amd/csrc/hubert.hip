@@ -666,12 +666,13 @@ int launch_kmeans_assign(const float* x, long long x_bstride, long long st, long
 using namespace dissc;
 
 namespace dissc {
-int g_attn_fused = 1;  // "attn_fused" option: 0 = S=QK^T -> softmax -> PV through HBM (3 kernels)
-int g_hubert_split = 1;  // "hubert_split" option: batches of >= 16 utterances run as 2-4 parts on streams of their own (0 never, 1
+// option "attn_fused" (Options::attn_fused, default 1): "attn_fused" option: 0 = S=QK^T -> softmax -> PV through HBM (3 kernels)
+// option "hubert_split" (Options::hubert_split, default 1): "hubert_split" option: batches of >= 16 utterances run as 2-4 parts on streams of their own (0 never, 1
                          // unless the batch fills whole workgroup rounds by itself, N >= 2: always N parts)
 }
 
 struct dissc_hubert {
+  Options opt;  // this handle's snapshot of the tuning options (common.h)
   int n_layers = 6, H = 12, D = 768, F = 3072, CF = 512, K = 0;
   float* w0 = nullptr;   // conv0 [512][10]
   float* gn_g = nullptr; // GroupNorm affine
@@ -736,6 +737,8 @@ int dissc_hubert_create(int n_layers, const DisscTensor* weights, size_t n_weigh
   std::map<std::string, const DisscTensor*> by;
   for (size_t i = 0; i < n_weights; ++i) by[weights[i].name] = &weights[i];
   dissc_hubert* m = new dissc_hubert();
+  m->opt = g_defaults;  // frozen here
+  OptScope opt_scope(&m->opt);
   m->n_layers = n_layers;
   int rc = DISSC_OK;
   auto fail = [&](int code) {
@@ -775,7 +778,7 @@ int dissc_hubert_create(int n_layers, const DisscTensor* weights, size_t n_weigh
     char name[96];
     snprintf(name, sizeof(name), "feature_extractor.conv_layers.%d.0.weight", l);
     if ((rc = get(name, (size_t)CF * CF * ks[l], &w))) return fail(rc);
-    if (g_enc_tc && s2tc_supported(CF, CF, ks[l], 2)) {  // k = 3: polyphase Toom-Cook form (conv_s2tc.hip)
+    if (opts().enc_tc && s2tc_supported(CF, CF, ks[l], 2)) {  // k = 3: polyphase Toom-Cook form (conv_s2tc.hip)
       if ((rc = make_s2tc(w, nullptr, CF, CF, m->ftc[l - 1]))) return fail(rc);
       m->ftc[l - 1].act = 1;
       continue;
@@ -906,7 +909,7 @@ static HubertWs carve(const dissc_hubert* m, int B, int Nmax, void* base_) {
   w.t1 = (float*)take((size_t)B * m->D * ldT * 4);
   w.qkv = (float*)take((size_t)B * 3 * m->D * ldT * 4);
   w.ffn = (float*)take((size_t)B * m->F * ldT * 4);
-  const bool need_s = !(g_attn_fused && m->D / m->H == 64);  // the fused attention keeps S on chip
+  const bool need_s = !(opts().attn_fused && m->D / m->H == 64);  // the fused attention keeps S on chip
   w.S = (float*)take(need_s ? (size_t)B * m->H * (size_t)(T > 0 ? T : 1) * ldT * 4 : 256);
   w.bytes = (size_t)(p - p0) + 256;
   return w;
@@ -916,6 +919,7 @@ constexpr int HUBERT_SPLIT_MIN_B = 16;
 
 size_t dissc_hubert_workspace_bytes(dissc_hubert_t m, int B, int Nmax) {
   if (!m || B <= 0 || Nmax <= 0) return 0;
+  OptScope opt_scope(&m->opt);
   size_t whole = carve(m, B, Nmax, nullptr).bytes;
   if (B >= HUBERT_SPLIT_MIN_B)  // the parts of a split batch side by side (whatever the option says when the forward runs)
     for (int np = 2; np <= dissc_hubert::MAX_PARTS; ++np) {
@@ -935,6 +939,7 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
     set_error("dissc_hubert_forward: bad argument");
     return DISSC_EINVAL;
   }
+  OptScope opt_scope(&m->opt);  // the forward reads this handle's options only
   if (ws_bytes < dissc_hubert_workspace_bytes(m, B, Nmax)) {
     set_error("dissc_hubert_forward: workspace %zu < %zu bytes", ws_bytes,
               dissc_hubert_workspace_bytes(m, B, Nmax));
@@ -944,8 +949,8 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
   // "hubert_split": 0 never, 2 always, 1 (default) unless the whole batch already fills whole rounds: with rows of T frames
   // the linears launch B ceil(T / 64) column tiles per M tile, and when that is a multiple of the CU count (32 x 10 s: 8 x 32 =
   // 256) every round is full and splitting only costs (28.0 -> 28.9 ms).  The lengths live on the device, so the rows decide.
-  bool split = g_hubert_split != 0 && B >= HUBERT_SPLIT_MIN_B;
-  if (split && g_hubert_split == 1) {
+  bool split = opts().hubert_split != 0 && B >= HUBERT_SPLIT_MIN_B;
+  if (split && opts().hubert_split == 1) {
     static int n_cu_of[64] = {0};  // per device (a process may hold models on several GPUs)
     int dev = 0;
     DISSC_HIP_CHECK(hipGetDevice(&dev));
@@ -965,7 +970,7 @@ int dissc_hubert_forward(dissc_hubert_t m, const float* wav, const int32_t* n_sa
   // fill each other's tails: ragged 32.0 -> 30.2 ms per 320 s, the lucky shape 28.0 -> 28.8 (tools/encode_ragged.py).
   // Utterances are independent (per-utterance GroupNorm statistics, masked attention), so the units do not change.
   // parts of >= 8 utterances, at most 4 (32 ragged utterances of 8-12 s: 32.0 ms whole, 31.0 / 30.6 / 30.2 in 2 / 3 / 4 parts)
-  int nparts = g_hubert_split >= 2 ? g_hubert_split : B / 8;
+  int nparts = opts().hubert_split >= 2 ? opts().hubert_split : B / 8;
   if (nparts < 2) nparts = 2;
   if (nparts > dissc_hubert::MAX_PARTS) nparts = dissc_hubert::MAX_PARTS;
   if (!m->ev_fork) DISSC_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
@@ -1068,7 +1073,7 @@ static int hubert_forward_part(dissc_hubert_t m, const float* wav, const int32_t
   for (int i = 0; i < m->n_layers; ++i) {
     auto& L = m->layers[i];
     if ((rc = run_conv_ex(L.qkv, w.x, w.qkv, nullptr, ioT, B, D, ldT, ldT, T, 1.0f, EPI_STORE, st))) return rc;
-    if (g_attn_fused && hd == 64) {
+    if (opts().attn_fused && hd == 64) {
       hipLaunchKernelGGL(attn_fused_kernel, dim3((T + AT_Q - 1) / AT_Q, H, B), dim3(256), 0, st, w.qkv, lensT, D,
                          hd, ldT, w.t1);
     } else {

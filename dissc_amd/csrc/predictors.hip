@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(SEQ_NT) expand_kernel(const int64_t* __restric
 using namespace dissc;
 
 struct dissc_pred {
+  Options opt;  // this handle's snapshot of the tuning options (common.h)
   int kind = 0;  // 0 len, 1 pitch "new", 2 pitch "base"
   int E = 32, C = 128;
   int n_tok_rows = 0, n_spk_rows = 0, pe_len = 0;
@@ -238,6 +239,8 @@ int dissc_pred_create(int kind, const DisscTensor* weights, size_t n_weights, di
     return n;
   };
   dissc_pred* p = new dissc_pred();
+  p->opt = g_defaults;  // frozen here
+  OptScope opt_scope(&p->opt);
   p->kind = kind;
   int rc = DISSC_OK;
   auto fail = [&](int code) {
@@ -383,6 +386,7 @@ int dissc_len_forward(dissc_pred_t p, const int64_t* seq, const int64_t* spk, co
     set_error("dissc_len_forward: bad argument");
     return DISSC_EINVAL;
   }
+  OptScope opt_scope(&p->opt);
   hipStream_t stream = (hipStream_t)stream_;
   float *h, *spare;
   int ld;
@@ -413,6 +417,7 @@ int dissc_pitch_forward(dissc_pred_t p, const int64_t* seq, const int64_t* spk,
     set_error("dissc_pitch_forward: bad argument");
     return DISSC_EINVAL;
   }
+  OptScope opt_scope(&p->opt);
   if (p->kind == 1 && Tmax > p->pe_len) {
     // the reference fails the same way: PositionalEncoding max_len (model/pitch_predictor.py:7,37)
     set_error("dissc_pitch_forward: %d frames exceed the positional encoding (%d)", Tmax, p->pe_len);

@@ -342,15 +342,13 @@ static inline float bf16_to_f32_host(uint16_t h) {
   return f;
 }
 
-static int g_bf3_variant = 0;  // "fused_variant" in precision mode: 0 = 512-column window, 1 = 1024
-void resblock_bf3_set_variant(int v) { g_bf3_variant = v; }
+// option "fused_variant" (Options::bf3_variant, default 0): "fused_variant" in precision mode: 0 = 512-column window, 1 = 1024
 
-static int g_bf3_pairs = -1;  // "bf3_pairs": -1 = by channel count (below), 0 = whole blocks, 1 = always pairs
-void resblock_bf3_set_pairs(int v) { g_bf3_pairs = v; }
+// option "bf3_pairs" (Options::bf3_pairs, default -1): "bf3_pairs": -1 = by channel count (below), 0 = whole blocks, 1 = always pairs
 // One launch per residual pair instead of per block?  With 64 channels the LDS holds 256-column
 // windows only, and the 120-column halo of a whole 11-tap block would be recomputed ~2x; a pair's
 // halo is 10-30 columns, at the price of two more read+write passes of x_k per block.
-bool resblock_bf3_pairs(int C) { return g_bf3_pairs < 0 ? C >= 64 : g_bf3_pairs != 0; }
+bool resblock_bf3_pairs(int C) { return opts().bf3_pairs < 0 ? C >= 64 : opts().bf3_pairs != 0; }
 
 bool resblock_bf3_supported(int C, int KS, const int* dil) {
   if (C != 16 && C != 32 && C != 64) return false;
@@ -400,11 +398,10 @@ static int launch_bf3(ResblockBf3Args a, int B, int Lmax, hipStream_t stream) {
   a.H4 = (H + 3) & ~3;
   a.BN = COLS - 2 * a.H4;
   const size_t lds = (size_t)4 * (C / 8) * XW * 16;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;  // per device (common.h)
+  if (attr_once.first()) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bf3_kernel<C, KS, NW, NI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
   }
   dim3 grid((Lmax + a.BN - 1) / a.BN, B);
   hipLaunchKernelGGL((resblock_bf3_kernel<C, KS, NW, NI>), grid, dim3(64 * NW), lds, stream, a);
@@ -436,7 +433,7 @@ int launch_resblock_bf3(int C, const float* x, float* acc, const float* wpack, c
     if (KS == 7) return launch_bf3<32, 7, 8, 4>(a, B, Lmax, stream);
     return launch_bf3<32, 11, 8, 4>(a, B, Lmax, stream);
   }
-  if (g_bf3_variant == 1) {  // 1024-column windows: less halo recompute, but one workgroup per CU
+  if (opts().bf3_variant == 1) {  // 1024-column windows: less halo recompute, but one workgroup per CU
     if (KS == 3) return launch_bf3<16, 3, 8, 8>(a, B, Lmax, stream);
     if (KS == 7) return launch_bf3<16, 7, 8, 8>(a, B, Lmax, stream);
     return launch_bf3<16, 11, 8, 8>(a, B, Lmax, stream);

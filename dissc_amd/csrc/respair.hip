@@ -441,10 +441,10 @@ template <int KS, int DIL>
 static int launch_pair32(const PairArgs& a, int B, int Lmax, hipStream_t stream) {
   constexpr int NI = 2, SLOTS = 32 * NI * 4, WOUT = (SLOTS - (KS - 1)) & ~3;
   dim3 grid((Lmax + WOUT - 1) / WOUT, B);
-  if (g_pair_lds_mode == 0)
-    hipLaunchKernelGGL((respair32_kernel<KS, DIL, NI, 0>), grid, dim3(256), (size_t)g_pair_pad_lds, stream, a);
+  if (opts().pair_lds_mode == 0)
+    hipLaunchKernelGGL((respair32_kernel<KS, DIL, NI, 0>), grid, dim3(256), (size_t)opts().pair_pad_lds, stream, a);
   else
-    hipLaunchKernelGGL((respair32_kernel<KS, DIL, NI, 1>), grid, dim3(256), (size_t)g_pair_pad_lds, stream, a);
+    hipLaunchKernelGGL((respair32_kernel<KS, DIL, NI, 1>), grid, dim3(256), (size_t)opts().pair_pad_lds, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
@@ -453,17 +453,17 @@ template <int KS, int DIL>
 static int launch_pair16(const PairArgs& a, int B, int Lmax, hipStream_t stream) {
   constexpr int NI = 4, SLOTS = 16 * NI * 4, WOUT = (SLOTS - (KS - 1)) & ~3;
   dim3 grid((Lmax + WOUT - 1) / WOUT, B);
-  hipLaunchKernelGGL((respair16_kernel<KS, DIL, NI>), grid, dim3(256), (size_t)g_pair_pad_lds, stream, a);
+  hipLaunchKernelGGL((respair16_kernel<KS, DIL, NI>), grid, dim3(256), (size_t)opts().pair_pad_lds, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
 
-int g_pair_lds_mode = 1;  // "pair_lds" option: LDS layout of respair32 (see LM)
-int g_pair_pad_lds = 0;  // diagnostics: extra dynamic LDS bytes per workgroup (lowers occupancy)
-int g_pair_max_c = 32;  // "pair_max_c" option: widest stage run as fused residual pairs (0 = off)
+// option "pair_lds" (Options::pair_lds_mode, default 1): "pair_lds" option: LDS layout of respair32 (see LM)
+// option "pair_pad_lds" (Options::pair_pad_lds, default 0): diagnostics: extra dynamic LDS bytes per workgroup (lowers occupancy)
+// option "pair_max_c" (Options::pair_max_c, default 32): "pair_max_c" option: widest stage run as fused residual pairs (0 = off)
 
 bool respair_supported(int C, int KS, int dil) {
-  if (C > g_pair_max_c) return false;
+  if (C > opts().pair_max_c) return false;
   if (C != 16 && C != 32) return false;
   return (KS == 3 || KS == 7 || KS == 11) && (dil == 1 || dil == 3 || dil == 5);
 }

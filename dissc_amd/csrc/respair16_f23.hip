@@ -268,7 +268,10 @@ static int launch_f23_16_t(const PairFArgs& a, int B, int Lmax, hipStream_t stre
 int launch_pair16_f23(const PairFArgs& a, int KS, int dil, int B, int Lmax, hipStream_t stream) {
 #define DISSC_F23(K_, D_) \
   if (KS == K_ && dil == D_) return launch_f23_16_t<K_, D_>(a, B, Lmax, stream);
-  DISSC_F23(11, 1) DISSC_F23(11, 3) DISSC_F23(11, 5) DISSC_F23(3, 1) DISSC_F23(3, 3) DISSC_F23(3, 5)
+  DISSC_F23(11, 1) DISSC_F23(11, 3) DISSC_F23(11, 5)
+#if DISSC_EXPERIMENTAL  // k = 3 through these kernels measured neutral in the forward (NOTES round 4): not in the default build
+  DISSC_F23(3, 1) DISSC_F23(3, 3) DISSC_F23(3, 5)
+#endif
 #undef DISSC_F23
   set_error("launch_pair16_f23: no instance for k = %d, dilation %d", KS, dil);
   return DISSC_EINVAL;

@@ -33,12 +33,13 @@
 
 namespace dissc {
 
-int g_pair_wino = 0;  // "pair_wino" option (read at dissc_gen_create): 0 (default) = not used (respair32 direct / two conv_wino
+// option "pair_wino" (Options::pair_wino, default 0): "pair_wino" option (read at dissc_gen_create): 0 (default) = not used (respair32 direct / two conv_wino
                       // launches); 1 = the shapes pairw_wanted() names run as fused transform-domain pairs, 2 = every shape
                       // with an instance.  Off by default: the gate experiment failed (below) -- per launch the winning
                       // shapes are 6-15 % faster, in the whole forward (three chains overlapping on their streams) that
                       // is 35.36 against 35.42 ms, while the executed-FLOP utilisation falls from 0.619 to 0.602.
 
+#if DISSC_EXPERIMENTAL  // the F(4,3) pair kernel failed its gate (above): built with DISSC_EXPERIMENTAL=1 only
 struct PairWArgs {
   const float* x;     // [B][C][ld] pair input x_k
   float* out;         // EPI_RES: x_k' (may not alias x: neighbouring workgroups still read x's halo)
@@ -568,11 +569,14 @@ __global__ void __launch_bounds__(384 * CHV, 3) respair_wino_kernel(const PairWA
   pass_d(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
 }
 
+#endif  // DISSC_EXPERIMENTAL
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 // shapes that have an instance: a point's weights must fit 64 registers per lane (C^2 NS / 64 <= 64)
 bool pairw_supported(int C, int KS, int dil) {
+  if (!DISSC_EXPERIMENTAL) return false;  // (the kernel is not in this build)
   if (!(dil == 1 || dil == 3 || dil == 5)) return false;
   if (C == 32) return KS == 7 || KS == 11;
   if (C == 64) return KS == 3;
@@ -588,15 +592,16 @@ bool pairw_supported(int C, int KS, int dil) {
 // exchanges 125 + skeleton (staging, barriers, weight loads, launch) 197 us, nothing overlapping -- one workgroup fills
 // the CU and fp32 VALU work shares the MFMA datapath.  "pair_wino" = 2 takes every supported shape (tests).
 bool pairw_wanted(int C, int KS, int dil) {
-  if (g_pair_f23 && pair_f23_supported(C, KS, dil)) return true;  // (make_pairw then builds the register-only F(2,3) form)
-  if (!g_pair_wino || !pairw_supported(C, KS, dil)) return false;
-  if (g_pair_wino >= 2) return true;
+  if (opts().pair_f23 && pair_f23_supported(C, KS, dil)) return true;  // (make_pairw then builds the register-only F(2,3) form)
+  if (!opts().pair_wino || !pairw_supported(C, KS, dil)) return false;
+  if (opts().pair_wino >= 2) return true;
   if (C == 32) return KS == 11 && dil <= 3;
   return C == 64 && KS == 3 && dil == 1;
 }
 
 // w: [C][C][KS] -> U[p][co][ci][j] = sum_i G[p][i] w[co][ci][j + NS i] in the order the kernel's lanes hold them:
 // [point][mi][tap j][8-channel sub-chunk][lane][k-step e] = U_p[32 mi + (lane & 31)][8 ksub + 2 e + (lane >> 5)][j]
+#if DISSC_EXPERIMENTAL
 static int pack_pairw(const float* w, int C, int KS, float** dev) {
   const int NS = (KS + 2) / 3, MI = C / 32, NK = C / 8;
   std::vector<float> packed((size_t)6 * MI * NS * NK * 64 * 4);
@@ -617,9 +622,15 @@ static int pack_pairw(const float* w, int C, int KS, float** dev) {
             }
   return upload(packed, dev);
 }
+#else
+static int pack_pairw(const float*, int, int, float**) {
+  set_error("make_pairw: the F(4,3) pair kernel is only in DISSC_EXPERIMENTAL=1 builds");
+  return DISSC_EINVAL;
+}
+#endif
 
 int make_pairw(const float* w1, const float* b1, const float* w2, const float* b2, int C, int KS, int dil, DevPairW& pw) {
-  pw.form = (g_pair_f23 && pair_f23_supported(C, KS, dil)) ? 1 : 0;
+  pw.form = (opts().pair_f23 && pair_f23_supported(C, KS, dil)) ? 1 : 0;
   if (!pw.form && !pairw_supported(C, KS, dil)) {
     set_error("make_pairw: no instance for C = %d, k = %d, dilation %d", C, KS, dil);
     return DISSC_EINVAL;
@@ -643,17 +654,17 @@ void free_pairw(DevPairW& pw) {
   }
 }
 
-int g_pairw_chv = 2;  // "pairw_chv" option: column halves per workgroup of respair_wino_kernel (2: one 12-wave workgroup per CU;
+// option "pairw_chv" (Options::pairw_chv, default 2): "pairw_chv" option: column halves per workgroup of respair_wino_kernel (2: one 12-wave workgroup per CU;
                       // 1: two 6-wave workgroups with half the tile each -- measured 5-30 % slower, kept for the tests)
 
+#if DISSC_EXPERIMENTAL
 template <int C, int KS, int DIL, int CHV>
 static int launch_pairw_t(PairWArgs a, int B, int Lmax, hipStream_t stream) {
   using G = PairWGeo<C, KS, DIL, CHV>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;  // per device (common.h)
+  if (attr_once.first()) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&respair_wino_kernel<C, KS, DIL, CHV>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
   }
   a.gx = (Lmax + G::OT - 1) / G::OT;
   a.B = B;
@@ -663,6 +674,7 @@ static int launch_pairw_t(PairWArgs a, int B, int Lmax, hipStream_t stream) {
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
+#endif
 
 int launch_respair_wino(const DevPairW& pw, const float* x, float* out, float* acc, const int32_t* lengths, int len_default,
                         int len_mul, int B, int Lmax, int ld, float slope, int epi, float mrf_div, hipStream_t stream) {
@@ -673,18 +685,20 @@ int launch_respair_wino(const DevPairW& pw, const float* x, float* out, float* a
     return DISSC_EINVAL;
   }
   if (pw.form == 1) return launch_pair_f23(pw, x, out, acc, lengths, len_default, len_mul, B, Lmax, ld, slope, epi, mrf_div, stream);
+#if DISSC_EXPERIMENTAL
   PairWArgs a;
   a.x = x; a.out = out; a.acc = acc; a.w1 = pw.w1; a.w2 = pw.w2; a.b1 = pw.b1; a.b2 = pw.b2;
   a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul; a.ld = ld;
-  a.bstride = (long long)pw.C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.gx = 0; a.B = B; a.dbg = g_wino_dbg;
+  a.bstride = (long long)pw.C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.gx = 0; a.B = B; a.dbg = opts().wino_dbg;
 #define DISSC_PAIRW(C_, K_, D_)                                                                       \
   if (pw.C == C_ && pw.KS == K_ && pw.dil == D_)                                                      \
-    return g_pairw_chv == 2 ? launch_pairw_t<C_, K_, D_, 2>(a, B, Lmax, stream) : launch_pairw_t<C_, K_, D_, 1>(a, B, Lmax, stream);
+    return opts().pairw_chv == 2 ? launch_pairw_t<C_, K_, D_, 2>(a, B, Lmax, stream) : launch_pairw_t<C_, K_, D_, 1>(a, B, Lmax, stream);
   DISSC_PAIRW(32, 7, 1) DISSC_PAIRW(32, 7, 3) DISSC_PAIRW(32, 7, 5)
   DISSC_PAIRW(32, 11, 1) DISSC_PAIRW(32, 11, 3) DISSC_PAIRW(32, 11, 5)
   DISSC_PAIRW(64, 3, 1) DISSC_PAIRW(64, 3, 3) DISSC_PAIRW(64, 3, 5)
 #undef DISSC_PAIRW
-  set_error("launch_respair_wino: no instance");
+#endif
+  set_error("launch_respair_wino: no instance%s", DISSC_EXPERIMENTAL ? "" : " (the F(4,3) pair kernel is only in DISSC_EXPERIMENTAL=1 builds)");
   return DISSC_EINVAL;
 }
 

@@ -578,6 +578,7 @@ struct TLayer {
 }  // namespace
 
 struct dissc_trainer {
+  Options opt;  // this handle's snapshot of the tuning options (common.h)
   int kind = 0, E = 32, n_tok = 0, n_spk = 0, pe_len = 0;
   std::vector<TParam> params;      // trainable ones first (flat region [0, n_train))
   std::map<std::string, int> index;
@@ -618,6 +619,8 @@ int dissc_train_create(int kind, const DisscTensor* tensors, size_t n, dissc_tra
     return DISSC_EINVAL;
   }
   dissc_trainer* t = new dissc_trainer();
+  t->opt = g_defaults;  // frozen here
+  OptScope opt_scope(&t->opt);
   t->kind = kind;
   auto fail = [&](int rc) { delete t; return rc; };
   // ---- model description (reference model/len_predictor.py:13-33, model/pitch_predictor.py:52-70,117-143) ----
@@ -818,6 +821,7 @@ int dissc_train_step(dissc_trainer_t t, const int64_t* seq, const int64_t* spk, 
     set_error("dissc_train_step: bad argument");
     return DISSC_EINVAL;
   }
+  OptScope opt_scope(&t->opt);
   if (t->kind != 0 && (!t->id2mean || !t->id2std)) {
     set_error("dissc_train_step: dissc_train_set_pitch_stats first");
     return DISSC_EINVAL;

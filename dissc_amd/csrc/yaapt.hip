@@ -561,11 +561,10 @@ int dissc_yaapt_spectral(dissc_yaapt_t y, const float* wav, const int32_t* n_sam
     a.thresh1 = y->shc_thresh1; a.thresh2 = y->shc_thresh2; a.f0_double = y->f0_double; a.f0_half = y->f0_half;
     a.cand_pitch = cand_pitch; a.cand_merit = cand_merit; a.shc_out = shc_out;
     const size_t lds = ((size_t)SHC_FR * (y->half + y->shc_nb) + (size_t)SHC_FR * y->max_shc) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;  // per device (common.h)
+    if (attr_once.first()) {
       DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&yaapt_shc_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_done = true;
     }
     if (lds > 160 * 1024) {
       set_error("dissc_yaapt_spectral: %zu bytes of LDS needed", lds);

@@ -535,11 +535,10 @@ int dissc_yaapt_spec_track(const DisscYaaptTrackConfig* cfg, const float* energy
   a.wsb = reinterpret_cast<uint8_t*>(a.wsi + (size_t)B * 3 * F);
   const size_t lds = (size_t)4 * F;
   a.back_in_lds = lds <= kLdsBack;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;  // per device (common.h)
+  if (attr_once.first()) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&yaapt_spec_track_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBack));
-    attr_done = true;
   }
   hipLaunchKernelGGL(yaapt_spec_track_kernel, dim3(B), dim3(DP_NT), a.back_in_lds ? lds : 0, (hipStream_t)stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
@@ -569,11 +568,10 @@ int dissc_yaapt_final_track(const DisscYaaptTrackConfig* cfg, const float* tp1, 
   a.wsb = reinterpret_cast<uint8_t*>(a.wsi + (size_t)B * 3 * F);
   const size_t lds = (size_t)8 * F;
   a.back_in_lds = lds <= kLdsBack;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_once;  // per device (common.h)
+  if (attr_once.first()) {
     DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&yaapt_final_track_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBack));
-    attr_done = true;
   }
   hipLaunchKernelGGL(yaapt_final_track_kernel, dim3(B), dim3(DP_NT), a.back_in_lds ? lds : 0, (hipStream_t)stream, a);
   DISSC_HIP_CHECK(hipGetLastError());

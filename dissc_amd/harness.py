@@ -404,6 +404,15 @@ class Exchange:
         if overlap is None:
             overlap = cuda and sink is not None and os.environ.get("DISSC_EXCHANGE_OVERLAP", "1") != "0"
         self.overlap = bool(overlap) and sink is not None
+        # Whether the run is CUT into tapered rounds is part of the round plan, and the plan must be the same on every rank (one
+        # all-gather per round): a rank that passes no sink (rank != 0 with unpack_ranks=(0,)) would plan one round while rank 0
+        # plans four, and the run would hang.  So the ranks agree once: cut if ANY rank delivers overlapped (collectives are
+        # issued from the caller's thread only, here as everywhere).
+        self.plan_cut = self.overlap
+        if dist is not None and self.world > 1:
+            flag = torch.tensor([int(self.overlap)], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            self.plan_cut = bool(int(flag.item()))
         self.result, self.delivered, self.k = {}, 0, 0
         self.error = None
         self._pending = []   # (work, buf, out) of rounds this rank does not deliver: kept until the collective is done
@@ -675,7 +684,10 @@ def overlap_budget(lengths, parts, budget, cap=None):
     2 / (n (n + 1)) of the run's delivery instead of 1 / n.  ``budget`` (the memory bound of a round, or None) caps every
     entry, and so does ``cap`` (length units per overlapped round, OVERLAP_CAP_FLOATS / hop: a run too long for four rounds
     of that size takes more of them, all but the last of the cap's size).  Derived from the global job list: every rank
-    gets the same answer.  Returns ``budget`` itself when the run is too short to cut, else a list for plan_rounds."""
+    gets the same answer.  Returns ``budget`` itself when the run is too short to cut -- or when the caller already gave
+    explicit per-round budgets (a list) --, else a list for plan_rounds."""
+    if isinstance(budget, (list, tuple)):
+        return budget
     share = max((sum(int(lengths[i]) for i in p) for p in parts), default=0)
     n = min(OVERLAP_MAX_ROUNDS, share // OVERLAP_ROUND_FRAMES)
     while n >= 2 and share // (n * (n + 1) // 2) < OVERLAP_MIN_LAST:
@@ -721,7 +733,7 @@ def run_resynthesis(generator, jobs, rank=0, world_size=1, device="cuda:0", dist
         budget = [max(1, int(f) // hop) for f in round_floats]
     else:
         budget = None if round_floats is None else max(1, round_floats // hop)
-    if ex.overlap:
+    if ex.plan_cut:  # (agreed between the ranks: Exchange)
         budget = overlap_budget(lengths, parts, budget, cap=max(1, OVERLAP_CAP_FLOATS // hop))
     rounds = plan_rounds(lengths, parts, budget)
     t_run = time.perf_counter()

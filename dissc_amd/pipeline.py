@@ -200,7 +200,7 @@ class Converter:
         budget = None if round_floats is None else max(1, round_floats // nt)
         ex = harness.Exchange(rank, world_size, self.generator.device, dist, unpack_ranks, own_rows, sink, stats,
                               decode=lambda got: self._decode(got, target_ids), overlap=overlap)
-        if ex.overlap:  # input frames (320 samples) as the length unit of the overlap rule
+        if ex.plan_cut:  # (agreed between the ranks) input frames (320 samples) as the length unit of the overlap rule
             b = harness.overlap_budget([n // 320 for n in n_samples], parts, None,
                                        cap=max(1, harness.OVERLAP_CAP_FLOATS // (320 * nt)))
             if b is not None:  # (a list: the tapered cut)

@@ -135,8 +135,14 @@ int dissc_conv1d_s2(const float* x, const float* w_host, const float* bias_host,
 /* Diagnostics: average ms of `iters` launches of one C -> C, k = 3, stride 2 conv + GELU on B rows of L input samples. */
 int dissc_conv_s2_bench(int B, int C, int L, int form, int iters, float* ms_out);
 
-/* Tuning hook (process-wide; set before the handles are created; also reachable through the
- * environment variable DISSC_OPTIONS="key=value,key=value" read by the Python binding):
+/* Tuning hook: the DEFAULTS of handles created LATER (also reachable through the environment variable
+ * DISSC_OPTIONS="key=value,key=value" read by the Python binding).  Every handle -- generator, HuBERT, predictor, trainer --
+ * takes a snapshot of all options when it is created and never reads the process-wide values again: forwards are
+ * re-entrant per handle, two handles created under different options keep their own behaviour whatever is set in between
+ * (tests/test_gpu_generator.py::test_options_are_frozen_into_the_handle).  The stand-alone entries without a handle
+ * (dissc_conv1d, dissc_respair1d, the *_bench diagnostics) read the defaults at call time.
+ * Options marked [experimental] select kernels whose gates failed; they are only in libraries built with
+ * DISSC_EXPERIMENTAL=1 (dissc_get_option("experimental") == 1) and are refused or ignored otherwise.
  *   multistream (1)      generator: the ResBlocks of a stage run as concurrent chains on HIP streams (two side
  *                        streams per device, shared by all generator handles of the process)
  *   stream_prio (1)      ... and the longer chains get higher HIP stream priority
@@ -169,7 +175,7 @@ int dissc_conv_s2_bench(int B, int C, int L, int form, int iters, float* ms_out)
  *                        built for two workgroups per CU, 3 = 1 for k = 7 as F(6,3) and 2 for everything else (k = 11; k = 7 as F(5,4))
  *   ragged_enum (1)      conv_mfma32_kernel on a ragged batch enumerates only the (time tile, utterance) pairs that exist (the
  *                        empty workgroups all sit at the end of the dispatch order); 0 = tile x utterance grid with early exits
- *   pair_wino (0)        read at dissc_gen_create: 0 = off (default: the whole-forward gain is 0.2 %); 1 = the residual pairs this measured faster for (C = 32, k = 11, d = 1 / 3;
+ *   pair_wino (0)        [experimental] read at dissc_gen_create: 0 = off (default: the whole-forward gain is 0.2 %); 1 = the residual pairs this measured faster for (C = 32, k = 11, d = 1 / 3;
  *                        the first pair of the C = 64, k = 3 chain) run as ONE launch with both convs in the Toom-Cook
  *                        transform domain and the intermediate in LDS (respair_wino.hip); 2 = every shape with an instance
  *                        (C = 32: k = 7 / 11; C = 64: k = 3, first pair of a chain); 0 = none
@@ -182,7 +188,7 @@ int dissc_conv_s2_bench(int B, int C, int L, int form, int iters, float* ms_out)
  *                        2 = dissc_conv1d uses it too (tests)
  *   wino_sv (1)          conv_wino.hip, C >= 128: the 12 waves of a workgroup share the input transform (one barrier per
  *                        8 channels) instead of every wave forming its own tile; bit-identical, faster (0 = private tiles)
- *   enc_tc (0)           read at dissc_hubert_create: 1 = the k = 3, stride-2 feature convs (conv1..conv4) run in polyphase
+ *   enc_tc (0)           [experimental] read at dissc_hubert_create: 1 = the k = 3, stride-2 feature convs (conv1..conv4) run in polyphase
  *                        Toom-Cook form (conv_s2tc.hip: 15 / 7 instead of 3 MFMA products per output; opt-in: its gate failed --
  *                        6 % faster per launch, 2.35x the direct form's rounding error); 0 = direct implicit GEMM (default).
  *                        s2tc_xmode (0): 0 = row tiles pinned to XCDs, 1 = the row tiles of a time tile share an XCD
@@ -193,8 +199,8 @@ int dissc_conv_s2_bench(int B, int C, int L, int form, int iters, float* ms_out)
  *   mfast (0)            M-fastest block order for convs with many M tiles
  * Unknown keys return DISSC_EINVAL. */
 int dissc_set_option(const char* key, int value);
-/* Read back one of: precision, multistream, stream_prio, par_ups, pair_max_c (so that a wrapper can set an option
- * around the creation of one handle and restore it). */
+/* Read back any option's DEFAULT (so that a wrapper can set an option around the creation of one handle and restore it), plus
+ * "experimental" (1: the library was built with DISSC_EXPERIMENTAL=1), "graph_hits", "graph_captures". */
 int dissc_get_option(const char* key, int* value);
 
 /* Diagnostics (not on the product path): average milliseconds of `iters` launches of

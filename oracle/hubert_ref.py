@@ -141,17 +141,23 @@ def unit_flip_allowed(x_ref, centers, eps_l2=None, eps_rel=FEAT_EPS_L2_REL):
     eps_l2 = torch.as_tensor(eps_l2).double().reshape(T)
     cdist = torch.cdist(c, c)                                            # [K,K]
     u = 2.0 ** -24
-    gamma = D * u / (1 - D * u)
+    # Rounding of a length-D fp32 dot product.  The worst-case constant gamma_D = D u is ~10x what any summation order
+    # delivers on real data (errors of alternating sign: they grow like a random walk) and, at scores of O(1e3), made r
+    # dominate the feature term -- a weaker check presented as a stricter one.  Model: the random walk's scale,
+    # sqrt(D) u (never above the worst case) -- on the golden features the measured fp32-vs-fp64 score difference is 1.7 u
+    # at worst, 16x inside it (tests/test_oracle_golden.py::test_score_rounding_model_holds asserts 4x).
+    gamma = min(D * u / (1 - D * u), (D ** 0.5) * u)
     mag = (c * c).sum(1)[None, :] + 2.0 * (x.abs() @ c.abs().t())        # [T,K]
     r = 2.0 * gamma * (mag + mag.gather(1, i[:, None]))                  # both evaluations, both terms
     allowed = gap <= 2.0 * cdist[i] * eps_l2[:, None] + r
     return allowed.numpy(), int((allowed.sum(1) > 1).sum())
 
 
-def check_units(units, units_ref, x_ref, centers, x_dev=None, tag="units"):
+def check_units(units, units_ref, x_ref, centers, x_dev=None, tag="units", max_mismatch_frac=0.02):
     """Assert: every frame where ``units`` differs from the reference's is explained by the feature error (measured when
     ``x_dev`` is given, else the asserted FEAT_EPS_L2_REL bound) -- and the unit chosen instead is one of the explicable
-    ones.  Returns (n_mismatch, n_ambiguous)."""
+    ones -- and no more than ``max_mismatch_frac`` of the frames (+ 1) differ at all (None: unbounded, for constructed ties).
+    Returns (n_mismatch, n_ambiguous)."""
     import numpy as np
     x_ref = torch.as_tensor(x_ref)
     eps = None
@@ -167,6 +173,8 @@ def check_units(units, units_ref, x_ref, centers, x_dev=None, tag="units"):
     print(f"{tag}: {int(mism.sum())} mismatching frames, {n_amb} ambiguous frames of {len(units)}"
           + (f", feature error <= {float(rel.max()):.2e} (l2, relative, per frame)" if x_dev is not None else ""))
     assert ok.all(), f"{tag}: frames {np.nonzero(~ok)[0][:10]} got units {units[~ok][:10]}, reference {units_ref[~ok][:10]}"
+    if max_mismatch_frac is not None:
+        assert int(mism.sum()) <= max_mismatch_frac * len(units) + 1, f"{tag}: {int(mism.sum())} of {len(units)} units differ"
     return int(mism.sum()), n_amb
 
 

@@ -36,6 +36,7 @@ def test_bench_two_ranks_gloo_dry_run():
     assert st["exchange"]["collectives"] == 1 and st["exchange"]["rounds"] == 1
     assert st["exchange"]["sent_bytes_per_rank"] <= 1.2 * st["exchange"]["payload_bytes_this_rank"] + 1024
     assert "all_gather_into_tensor" in j["config"]["collective"]
+    assert j["rccl_ranks_seen"] == 2 and j["backend"] == "gloo"  # what the initialised process group reports
 
 
 def test_bench_gpus_flag_spawns_its_own_ranks():
@@ -73,11 +74,25 @@ def test_cpu_baseline_and_in_run_parity_figure():
     sd = synth.synth_generator_state_dict(seed=0)
     code, f0, spkr, _ = synth.synth_generator_inputs(3, 12, seed=1234)
     out, waves = bench.cpu_baseline(synth, sd, torch.from_numpy(code), torch.from_numpy(f0), torch.from_numpy(spkr),
-                                    budget_s=0.5, max_utts=5)
-    assert out["kind"] == "port" and out["value"] > 0 and len(waves) == 3
+                                    budget_s=0.5, max_utts=5, node_leg=False)
+    assert out["kind"] == "port" and out["value"] > 0 and len(waves) == 3 and out["node"] is None
     y = torch.stack([w.reshape(1, -1) for w in waves])
     p = bench.parity_vs(waves, y)
     assert p["rms"] == 0.0 and p["utts"] == 3 and p["tol_rms"] == 1e-4
     y[1, 0, 5] += 0.5
     p = bench.parity_vs(waves, y)
     assert p["rms"] > 1e-4 and abs(p["max"] - 0.5) < 1e-6
+
+
+def test_cpu_baseline_whole_host_leg():
+    """the `node` figure of cpu_baseline: P concurrent pinned B=1 oracle workers on disjoint physical cores, aggregate rate over a
+    common wall-clock window (the reference's Pool(8), sr/inference.py:351-354)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    sets = bench._physical_core_sets(2)
+    assert all(len(cs) == 2 for cs in sets) and len({c for cs in sets for c in cs}) == 2 * len(sets)  # disjoint
+    if len(sets) < 2:
+        return
+    r = bench.cpu_baseline_node(2, 3, 25, duration=1.5, lead=8.0)
+    assert r["workers"] == len(sets) and r["cores"] == 2 * len(sets) and r["utterances"] >= r["workers"]
+    assert abs(r["value"] - r["utterances"] * 0.5 / 1.5) < 0.01 and r["late_workers"] == 0, r

@@ -212,15 +212,36 @@ def test_encode_cli_roundtrip(gpu, golden_dir, tmp_path):
         hr.check_units(np.array(d["units"]), units.numpy(), dense, centers, tag=d["audio"])
     # a run that died leaves <out_file>.partial: the next run resumes from it (the finished file is not encoded again --
     # its line comes back verbatim, a torn last line is dropped) and the manifest keeps the listdir order
+    import argparse
     first = lines[0]
     marked = dict(first, durations=[7] * 99)
-    with open(f"{td}/out/enc2.txt.partial", "w") as f:
-        f.write(json.dumps(marked) + "\n" + '{"units": [1, 2')
+    ns = argparse.Namespace(base_dir=f"{td}/wav", model_name="hubert-base-ls960", quantizer_name="kmeans", vocab_size=100,
+                            f0="yaapt", checkpoint_dir=f"{td}/ckpt")
+    with open(f"{td}/out/enc2.txt.partial", "wb") as f:
+        f.write(cli.partial_header(ns) + (json.dumps(marked) + "\n" + '{"units": [1, 2').encode())
     cli.main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/out/enc2.txt", "--checkpoint_dir", f"{td}/ckpt"])
     again = [json.loads(x) for x in open(f"{td}/out/enc2.txt").read().strip().split("\n")]
     assert [d["audio"] for d in again] == [d["audio"] for d in lines]
     assert again[0] == marked and again[1] == lines[1]
     assert not os.path.exists(f"{td}/out/enc2.txt.partial")
+    # a leftover from a run with ANOTHER configuration (here: --f0 zeros) or whose line does not fit the file (wrong
+    # unit count) is not spliced in; and an append that was interrupted is rolled back instead of repeated
+    stale = dict(first, durations=[9] * 99)
+    with open(f"{td}/out/enc3.txt.partial", "wb") as f:
+        f.write(cli.partial_header(argparse.Namespace(**dict(vars(ns), f0="zeros"))) + (json.dumps(stale) + "\n").encode())
+    cli.main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/out/enc3.txt", "--checkpoint_dir", f"{td}/ckpt"])
+    assert [json.loads(x) for x in open(f"{td}/out/enc3.txt").read().strip().split("\n")] == lines
+    short = dict(first, units=first["units"][:50])
+    with open(f"{td}/out/enc4.txt.partial", "wb") as f:
+        f.write(cli.partial_header(ns) + (json.dumps(short) + "\n").encode())
+    with open(f"{td}/out/enc4.txt", "w") as f:
+        f.write("kept\n" + json.dumps(first)[:40])      # a torn append of a dead run ...
+    with open(f"{td}/out/enc4.txt.partial.commit", "w") as f:
+        json.dump({"out_size_before": 5}, f)             # ... which began at byte 5
+    cli.main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/out/enc4.txt", "--checkpoint_dir", f"{td}/ckpt"])
+    got = open(f"{td}/out/enc4.txt").read().strip().split("\n")
+    assert got[0] == "kept" and [json.loads(x) for x in got[1:]] == lines
+    assert not os.path.exists(f"{td}/out/enc4.txt.partial.commit")
 
 
 def test_in_memory_converter_equals_file_pipeline(gpu, golden_dir, tmp_path):

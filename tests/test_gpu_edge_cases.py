@@ -47,21 +47,20 @@ def test_dma_handover_of_wide_residual_pairs_on_a_poisoned_workspace(env):
     code, f0, spkr, _ = synth.synth_generator_inputs(B, T, seed=11)
     kw = dict(code=torch.from_numpy(code).cuda(), f0=torch.from_numpy(f0).cuda(), spkr=torch.from_numpy(spkr).cuda())
     lens = torch.tensor([70, 64, 33, 1, 17], dtype=torch.int32).cuda()
-    try:
-        assert lib.dissc_set_option(b"wino", 0) == 0
-        g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
-        g.load_state_dict(synth.synth_generator_state_dict(seed=0))
-        g.eval().remove_weight_norm()
-        g(**kw, lengths=lens)  # builds the native handle (every conv direct) and sizes the workspace
-    finally:
-        lib.dissc_set_option(b"wino", 1)
     outs = {}
-    for v in (0, 1):
-        assert lib.dissc_set_option(b"pair_dma", v) == 0
+    for v in (0, 1):  # a handle snapshots the options when it is created: one generator per setting
+        try:
+            assert lib.dissc_set_option(b"wino", 0) == 0 and lib.dissc_set_option(b"pair_dma", v) == 0
+            g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
+            g.load_state_dict(synth.synth_generator_state_dict(seed=0))
+            g.eval().remove_weight_norm()
+            g(**kw, lengths=lens)  # builds the native handle (every conv direct) and sizes the workspace
+        finally:
+            lib.dissc_set_option(b"wino", 1)
+            lib.dissc_set_option(b"pair_dma", 1)
         g._ws.view(torch.float32)[: g._ws.numel() // 4].fill_(float("nan"))
         outs[v] = g(**kw, lengths=lens).clone()
         assert torch.isfinite(outs[v]).all(), v
-    assert lib.dissc_set_option(b"pair_dma", 1) == 0
     assert torch.equal(outs[0], outs[1])
     hop = outs[0].shape[-1] // T
     for b, n in enumerate([70, 64, 33, 1, 17]):
@@ -81,29 +80,38 @@ def test_hipgraph_replay_is_bit_identical(env):
     """option "graphs" (off by default: measured slower on ROCm 7.2): a small forward captured into a hipGraph --
     the three ResBlock streams join the capture through their events -- and replayed gives the same bits, also when
     the ragged lengths behind the same pointer change between replays"""
-    g, synth, lib = env["g"], env["synth"], env["lib"]
+    import dissc_amd
+    g0, synth, lib = env["g"], env["synth"], env["lib"]
+    exp = ctypes.c_int(0)
+    assert lib.dissc_get_option(b"experimental", ctypes.byref(exp)) == 0
+    if not exp.value:
+        pytest.skip("hipGraph replay failed its gate (slower than plain launches on ROCm 7.2): DISSC_EXPERIMENTAL=1 builds only")
     code, f0, spkr, _ = synth.synth_generator_inputs(3, 60, seed=7)
     kw = dict(code=torch.from_numpy(code).cuda(), f0=torch.from_numpy(f0).cuda(), spkr=torch.from_numpy(spkr).cuda())
     lens = torch.tensor([60, 41, 13], dtype=torch.int32).cuda()
-    plain = [g(**kw, lengths=lens).clone()]
+    plain = [g0(**kw, lengths=lens).clone()]
     lens.copy_(torch.tensor([22, 60, 5], dtype=torch.int32))
-    plain.append(g(**kw, lengths=lens).clone())
-    hits0, cap0 = ctypes.c_int(), ctypes.c_int()
+    plain.append(g0(**kw, lengths=lens).clone())
+    hits0 = ctypes.c_int()
     lib.dissc_get_option(b"graph_hits", ctypes.byref(hits0))
-    assert lib.dissc_set_option(b"graphs", 1) == 0
-    try:
+    try:  # a handle created under "graphs" = 1
+        assert lib.dissc_set_option(b"graphs", 1) == 0
+        g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
+        g.load_state_dict(synth.synth_generator_state_dict(seed=0))
+        g.eval().remove_weight_norm()
         lens.copy_(torch.tensor([60, 41, 13], dtype=torch.int32))
-        for rep in range(4):
-            y = g(**kw, lengths=lens)
-            assert torch.equal(y, plain[0]), rep
-            del y
-        lens.copy_(torch.tensor([22, 60, 5], dtype=torch.int32))
-        assert torch.equal(g(**kw, lengths=lens), plain[1])
-        hits = ctypes.c_int()
-        lib.dissc_get_option(b"graph_hits", ctypes.byref(hits))
-        assert hits.value > hits0.value  # replays happened (the caching allocator hands the same buffers back)
+        g(**kw, lengths=lens)
     finally:
         assert lib.dissc_set_option(b"graphs", 0) == 0
+    for rep in range(4):
+        y = g(**kw, lengths=lens)
+        assert torch.equal(y, plain[0]), rep
+        del y
+    lens.copy_(torch.tensor([22, 60, 5], dtype=torch.int32))
+    assert torch.equal(g(**kw, lengths=lens), plain[1])
+    hits = ctypes.c_int()
+    lib.dissc_get_option(b"graph_hits", ctypes.byref(hits))
+    assert hits.value > hits0.value  # replays happened (the caching allocator hands the same buffers back)
 
 
 def test_long_utterance_30s(env):

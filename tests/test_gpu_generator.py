@@ -368,13 +368,15 @@ def test_precision_option_leaves_predictors_and_units_exact():
 
 
 def _generator_with(lib, synth, **options):
-    """an instance built under the given creation-time options (restored afterwards)"""
+    """an instance whose native handle is CREATED under the given options (a handle snapshots the options when it is created and
+    never looks at the process-wide defaults again: include/dissc_hip.h); the defaults are restored afterwards"""
     import dissc_amd
     saved = {}
     try:
         for k, v in options.items():
             cur = ctypes.c_int(0)
-            saved[k] = cur.value if lib.dissc_get_option(k.encode(), ctypes.byref(cur)) != 0 else cur.value
+            assert lib.dissc_get_option(k.encode(), ctypes.byref(cur)) == 0, k
+            saved[k] = cur.value
             assert lib.dissc_set_option(k.encode(), v) == 0
         gd = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
         gd.load_state_dict(synth.synth_generator_state_dict(seed=0))
@@ -382,9 +384,8 @@ def _generator_with(lib, synth, **options):
         c1, f1, s1, _ = synth.synth_generator_inputs(1, 3, seed=1)
         gd(code=torch.from_numpy(c1), f0=torch.from_numpy(f1), spkr=torch.from_numpy(s1))  # the native handle is built here
     finally:
-        for k in options:
-            lib.dissc_set_option(k.encode(), {"pair_wino": 0, "pair_f23": 3, "wino": 1, "wino8": 1, "wino8_r4": 1, "wino8_mask": 0o770770771,
-                                                     "wino8_r4_mask": 0o770770010}.get(k, saved.get(k, 0)))
+        for k, v in saved.items():
+            lib.dissc_set_option(k.encode(), v)
     return gd
 
 
@@ -405,15 +406,12 @@ def test_fused_residual_pairs_are_bit_identical_to_separate_launches(env):
     g = _generator_with(lib, synth, pair_f23=0)  # (the default's k = 11 pairs of the 32-channel stage are F(2,3): next test)
     cur = ctypes.c_int(0)
     assert lib.dissc_get_option(b"pair_max_c", ctypes.byref(cur)) == 0 and cur.value >= 16
+    g_sep = _generator_with(lib, synth, pair_f23=0, pair_max_c=0)  # every conv its own launch
     for code, f0, spkr, lengths in _pair_cases(synth):
         kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
                   lengths=torch.from_numpy(lengths))
         y_pair = g(**kw).cpu()
-        try:
-            assert lib.dissc_set_option(b"pair_max_c", 0) == 0
-            y_sep = g(**kw).cpu()
-        finally:
-            lib.dissc_set_option(b"pair_max_c", cur.value)
+        y_sep = g_sep(**kw).cpu()
         assert torch.isfinite(y_pair).all()
         assert torch.equal(y_pair, y_sep)
 
@@ -439,7 +437,7 @@ def test_f23_pairs_agree_with_the_direct_pairs(env):
         assert torch.equal(one, y[0])
 
 
-def test_transform_domain_pairs_agree_with_the_unfused_generator(env):
+def test_transform_domain_pairs_agree_with_the_unfused_generator(env, experimental):
     """respair_wino.hip (opt-in, "pair_wino" = 1: the k = 11, d = 1 / 3 pairs of the 32-channel stage and the first k = 3
     pair of the 64-channel stage as ONE transform-domain launch each; = 2: every shape with an instance) against the
     default instance: same waveform to fp32 rounding, ragged and at the BASELINE size; fewer executed FLOPs are
@@ -535,3 +533,80 @@ def test_eight_point_generators_agree_with_the_f43_generator(env):
             assert rms <= 5e-6 and float(e.abs().max()) <= 1e-4
             one = g8(code=kw["code"][:1], f0=kw["f0"][:1], spkr=kw["spkr"][:1], lengths=kw["lengths"][:1]).cpu()[0]
             assert torch.equal(one, y8[0])
+
+
+def test_generator_random_dispatch_fuzz(env):
+    """Which kernel a layer runs on depends on (B, T, lengths): per-shape form masks, small_grid tile step-downs, two-per-CU
+    tiles, exists-only tile enumeration on ragged batches.  25 seeded cases -- B in [1, 40], T in [1, 700], ragged rows incl.
+    0- and 1-frame utterances, NaN-free poison beyond every length -- of the DEFAULT generator against
+    oracle.generator_ref.code_generator (reference sr/models.py:98-114) at <= 1e-4 RMS / 1e-3 of the reference's RMS on up to
+    three utterances per case, nothing written beyond an utterance, and batch independence: an utterance decoded alone is
+    bit-identical to its row of the batch (tools/wino_fuzz.py one level up)."""
+    g, gr, synth = env["g"], env["gr"], env["synth"]
+    rs = np.random.RandomState(2025)
+    worst = 0.0
+    for case in range(25):
+        B = int(rs.choice([1, 2, 3, 5, 8, 13, 21, 32, 40]))
+        T = int(rs.choice([1, 2, 7, 33, 64, 99, 128, 250, 257, 500, 511, 700]))
+        if B * T > 14000:  # keep a case within ~0.5 s of GPU and a few seconds of oracle
+            B = max(1, 14000 // T)
+        code, f0, spkr, _ = synth.synth_generator_inputs(B, T, seed=4000 + case)
+        mode = case % 3  # 0: uniform, 1: ragged, 2: ragged with empty / one-frame rows
+        lengths = np.full(B, T, np.int32)
+        if mode >= 1:
+            lengths = rs.randint(1, T + 1, size=B).astype(np.int32)
+            lengths[rs.randint(B)] = T
+        if mode == 2 and B >= 3:
+            lengths[rs.randint(B)] = 0
+            lengths[rs.randint(B)] = 1
+            lengths[rs.randint(B)] = T if (lengths == T).sum() == 0 else lengths[rs.randint(B)]
+        code2, f02 = code.copy(), f0.copy()
+        for b in range(B):
+            code2[b, lengths[b]:] = 99
+            f02[b, 0, lengths[b]:] = 1e9
+        tc, tf, ts, tl = torch.from_numpy(code2), torch.from_numpy(f02), torch.from_numpy(spkr), torch.from_numpy(lengths)
+        y = g(code=tc, f0=tf, spkr=ts, lengths=tl if mode else None).cpu()
+        assert tuple(y.shape) == (B, 1, 320 * T) and torch.isfinite(y).all()
+        for b in range(B):
+            assert not y[b, :, 320 * int(lengths[b]):].any(), (case, b)
+        live = [b for b in range(B) if lengths[b] > 0]
+        for b in list(rs.choice(live, size=min(3, len(live)), replace=False)):
+            n = int(lengths[b])
+            ref = gr.code_generator(env["folded"], synth.VCTK_CONFIG, code[b:b + 1, :n], f0[b:b + 1, :, :n], spkr[b:b + 1])
+            e = (y[b:b + 1, :, :320 * n] - ref).numpy()
+            assert _rms(e) <= 1e-4 and _rms(e) <= 1e-3 * max(_rms(ref.numpy()), 1e-3), (case, B, T, b, n, _rms(e))
+            worst = max(worst, _rms(e))
+        for b in list(rs.choice(live, size=min(2, len(live)), replace=False)):
+            n = int(lengths[b])
+            y1 = g(code=tc[b:b + 1, :n], f0=tf[b:b + 1, :, :n], spkr=ts[b:b + 1]).cpu()
+            assert torch.equal(y1[0, :, :320 * n], y[b, :, :320 * n]), (case, B, T, b, n)
+    print(f"generator dispatch fuzz: 25 cases, worst RMS error vs the oracle {worst:.3e}")
+
+
+def test_options_are_frozen_into_the_handle(env):
+    """"re-entrant per handle, no global state".  Two generators created under different options -- every ResBlock
+    conv direct ("wino" = 0, residual pairs as separate launches) and the default transform-domain build -- run INTERLEAVED, with
+    dissc_set_option calls in between (the defaults of handles created later): each one's output is bit-identical to its solo
+    run, and the two really are different code paths (they differ in the last bits)."""
+    lib, synth = env["lib"], env["synth"]
+    g_direct = _generator_with(lib, synth, wino=0, pair_max_c=0, multistream=0)
+    g_default = env["g"]
+    code, f0, spkr, lengths = synth.synth_generator_inputs(5, 90, seed=31, ragged=True)
+    kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr), lengths=torch.from_numpy(lengths))
+    solo_direct, solo_default = g_direct(**kw).cpu(), g_default(**kw).cpu()
+    assert not torch.equal(solo_direct, solo_default) and float((solo_direct - solo_default).abs().max()) <= 1e-4
+    saved = {}
+    try:
+        for i, (k, v) in enumerate([("wino", 0), ("pair_max_c", 0), ("small_grid", 0), ("ragged_enum", 0), ("wino_sv", 0),
+                                    ("wino8", 0), ("multistream", 0), ("pair_f23", 0)]):
+            cur = ctypes.c_int(0)
+            assert lib.dissc_get_option(k.encode(), ctypes.byref(cur)) == 0
+            saved[k] = cur.value
+            assert lib.dissc_set_option(k.encode(), v) == 0   # changes what handles created LATER do -- not these two
+            a, b = (g_direct, g_default) if i % 2 == 0 else (g_default, g_direct)
+            ya, yb = a(**kw).cpu(), b(**kw).cpu()
+            assert torch.equal(ya, solo_direct if a is g_direct else solo_default), k
+            assert torch.equal(yb, solo_direct if b is g_direct else solo_default), k
+    finally:
+        for k, v in saved.items():
+            lib.dissc_set_option(k.encode(), v)

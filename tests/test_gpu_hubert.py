@@ -28,10 +28,10 @@ def env(golden_dir):
                 g=np.load(os.path.join(golden_dir, "hubert.npz")))
 
 
-def _check_units(hr, units, dense_ref, centers, want, tag="", dense_dev=None):
+def _check_units(hr, units, dense_ref, centers, want, tag="", dense_dev=None, max_mismatch_frac=0.02):
     """every frame where ``units`` differs from the reference's must be explained by the (measured) feature error:
     oracle.hubert_ref.check_units -- bound 2 ||c_i - c_j|| ||delta|| + fp32 rounding of the score, no hand-set margin"""
-    mism, amb = hr.check_units(units, want, dense_ref, centers, x_dev=dense_dev, tag=tag)
+    mism, amb = hr.check_units(units, want, dense_ref, centers, x_dev=dense_dev, tag=tag, max_mismatch_frac=max_mismatch_frac)
     return amb, mism
 
 
@@ -117,12 +117,15 @@ def test_split_batch_forward_is_bit_identical(env):
     wav = torch.full((21, max(ns) + 320), float("nan"))
     for i, n in enumerate(ns):
         wav[i, :n] = torch.from_numpy(synth.synth_waveform(n, seed=900 + i))
+    from dissc_amd.hubert import HubertEncoder
     outs = []
     try:
-        for mode in (0, 2, 4, 1):
+        for mode in (0, 2, 4, 1):  # (a handle snapshots the options when it is created: one encoder per mode)
             assert _lib.lib.dissc_set_option(b"hubert_split", mode) == 0
-            o = env["enc"](wav, n_samples=torch.tensor(ns))
+            enc = HubertEncoder(env["sd"], env["centers"], n_layers=6).to("cuda:0")
+            o = enc(wav, n_samples=torch.tensor(ns))
             outs.append((o["units"].cpu(), o["dense"].cpu(), o["frames"].cpu()))
+            del enc
     finally:
         _lib.lib.dissc_set_option(b"hubert_split", 1)
     for u, d, f in outs[1:]:
@@ -153,7 +156,7 @@ def test_units_differ_from_the_oracle_only_at_constructed_near_ties(env):
     u_ref = hr.kmeans_assign(dense_ref, centers).numpy()
     enc = HubertEncoder(env["sd"], centers, n_layers=6).to("cuda:0")
     out = enc(wav)
-    near, mism = _check_units(hr, out["units"][0].cpu().numpy(), dense_ref, centers, u_ref, "constructed ties")
+    near, mism = _check_units(hr, out["units"][0].cpu().numpy(), dense_ref, centers, u_ref, "constructed ties", max_mismatch_frac=None)
     assert near >= 50  # (every frame whose nearest centre is one of a twin pair is a near-tie by construction)
 
 

@@ -59,7 +59,7 @@ def _data(C, k, lengths, ld, seed):
 
 
 @pytest.fixture(params=[1, 2], ids=["two-6-wave-workgroups-per-CU", "one-12-wave-workgroup-per-CU"])
-def chv(request, lib):
+def chv(request, lib, experimental):  # (respair_wino_kernel failed its gate: DISSC_EXPERIMENTAL=1 builds only)
     """both workgroup shapes of the kernel (option "pairw_chv"); "pair_f23" off, so that mode 3 builds THIS kernel's form for
     C = 32, k = 11 too (the default there is the register-only F(2,3) pair, tested below)"""
     assert lib.lib.dissc_set_option(b"pairw_chv", request.param) == 0
@@ -134,6 +134,10 @@ def f23(lib):
 @pytest.mark.parametrize("k", [11, 3])
 @pytest.mark.parametrize("C,d", [(32, 1), (32, 3), (32, 5), (16, 1), (16, 3), (16, 5)])
 def test_register_only_f23_pair_matches_float64_and_the_direct_pair(lib, f23, C, d, k):
+    if k == 3:
+        from conftest import is_experimental_build
+        if not is_experimental_build():
+            pytest.skip("the k = 3 instances measured neutral in the forward: DISSC_EXPERIMENTAL=1 builds only")
     """respair32_f23_kernel / respair16_f23_kernel (k = 11: tiles of 500 / 492 / 468 outputs; k = 3: 508): ragged lengths around
     the tile edges, NaN beyond every utterance, against float64 and the direct pair; batch independence; the MRF modes"""
     lengths = [2000, 1, 7, 255, 467, 468, 469, 491, 492, 493, 499, 500, 501, 507, 508, 509, 1023, 1999, 12]

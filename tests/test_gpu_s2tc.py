@@ -20,7 +20,18 @@ pytestmark = pytest.mark.gpu
 def lib():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    from conftest import is_experimental_build
     from dissc_amd import _lib
+    if not is_experimental_build():
+        # the form's gate failed (conv1 5.95 ms against <= 5.3, rms 2.35x against <= 2x: profiles/r05/s2tc_gate.txt): the default
+        # library does not carry the kernel; what the default build must do is refuse it loudly
+        x = torch.zeros(1, 16, 64, device="cuda:0")
+        w = torch.zeros(64, 16, 3)
+        y = torch.zeros(1, 64, 32, device="cuda:0")
+        rc = _lib.lib.dissc_conv1d_s2(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(w.data_ptr()), None,
+                                      ctypes.c_void_p(y.data_ptr()), None, 1, 16, 64, 3, 64, 32, 64, 0, 1, None)
+        assert rc != 0 and b"DISSC_EXPERIMENTAL" in _lib.lib.dissc_last_error()
+        pytest.skip("conv_s2tc.hip is only in DISSC_EXPERIMENTAL=1 builds (its gate failed)")
     return _lib
 
 

@@ -190,6 +190,55 @@ def test_two_rank_gloo_matches_single_process():
             np.testing.assert_array_equal(np.array(got[r][j], dtype=np.float32), single[j])
 
 
+def _worker_sink_on_rank0(rank, world, port, q):
+    """the default unpack_ranks=(0,) invites `sink=write if rank == 0 else None` -- rank 0 then overlaps (and cuts the
+    run into tapered rounds), the others would plan ONE round: different numbers of all-gathers, a hang.  The cut is agreed."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rs = np.random.RandomState(5)
+    jobs = [dict(code=rs.randint(0, 100, 200), f0=rs.standard_normal(200).astype(np.float32), spkr=1) for _ in range(200)]
+    seen, st = {}, {}
+    n = harness.run_resynthesis(_FakeGenerator(), jobs, rank, world, "cpu", dist, max_batch=16, max_frames=4000,
+                                sink=(lambda w: seen.update({k: v.copy() for k, v in w.items()})) if rank == 0 else None,
+                                stats=st, overlap=(True if rank == 0 else None))
+    assert st["rounds"] >= 2 and st["collectives"] == st["rounds"]  # 20 000 frames per rank: cut on BOTH ranks
+    assert (n == 200 and len(seen) == 200) if rank == 0 else len(seen) == 0
+    q.put((rank, st["rounds"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_round_plan_is_agreed_when_only_rank0_has_a_sink():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sink_on_rank0, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] >= 2
+
+
+def test_explicit_round_budgets_with_overlap():
+    """a LIST of per-round budgets together with overlapped delivery used to raise TypeError in overlap_budget"""
+    jobs = _jobs()
+    single = harness.run_resynthesis(_FakeGenerator(), jobs, 0, 1, "cpu", None, max_batch=4, max_frames=100)
+    seen, st = {}, {}
+    n = harness.run_resynthesis(_FakeGenerator(), jobs, 0, 1, "cpu", None, max_batch=4, max_frames=100,
+                                sink=lambda w: seen.update({k: v.copy() for k, v in w.items()}), round_floats=[400, 300, 100000],
+                                stats=st, overlap=True)
+    assert n == 25 and st["overlap"] and st["rounds"] == 3 and all(np.array_equal(seen[k], single[k]) for k in single)
+    assert harness.overlap_budget([175] * 1024, harness.lpt_shard([175] * 1024, 2), [5000, 100]) == [5000, 100]
+
+
 def test_overlap_budget_rule():
     """a run that fits one round is still cut into <= 4 rounds of >= 8 000 frames per rank when rounds overlap"""
     lengths = [175] * 1024

@@ -179,6 +179,22 @@ def test_hubert_oracle_matches_hf_and_sklearn(hgold, n):
         assert np.abs(cnn.numpy() - hgold[f"n{n}/cnn"]).max() <= 1e-4
 
 
+def test_score_rounding_model_holds(hgold):
+    """oracle.hubert_ref.unit_flip_allowed models the fp32 rounding of a score as sqrt(D) u (|c|^2 + 2 |x|.|c|): the measured
+    fp32-vs-fp64 difference of the scores on the golden features stays far inside it (and far inside the old worst case D u)"""
+    c = synth.synth_kmeans_centers()
+    worst = 0.0
+    for n in (4000, 16000, 32000):
+        x = torch.from_numpy(hgold[f"n{n}/dense"])
+        s32 = (c * c).sum(1)[None, :] - 2.0 * (x @ c.t())
+        s64 = (c.double() ** 2).sum(1)[None, :] - 2.0 * (x.double() @ c.double().t())
+        mag = (c.double() ** 2).sum(1)[None, :] + 2.0 * (x.double().abs() @ c.double().abs().t())
+        worst = max(worst, float(((s32.double() - s64).abs() / mag).max()))
+    u = 2.0 ** -24
+    print(f"score rounding: worst |fl(s) - s| / mag = {worst / u:.2f} u (model sqrt(768) u = {768 ** 0.5:.0f} u, worst case 768 u)")
+    assert worst <= 0.25 * 768 ** 0.5 * u
+
+
 # ------------------------------------------------------------------------------------------
 # the C restatement (oracle/host_ref.c) of the integer host logic
 # ------------------------------------------------------------------------------------------
