@@ -83,9 +83,12 @@ def cpu_baseline(synth, sd, code, f0, spkr, budget_s=9.0, max_utts=400, keep=8, 
     w = gr.fold_state_dict(sd)
     phys, logical, model = host_cpu_info()
     one = lambda b: gr.code_generator(w, synth.VCTK_CONFIG, code[b:b + 1], f0[b:b + 1], spkr[b:b + 1])
-    # oneDNN degrades when oversubscribed: probe the physical and the logical count (and a few below)
+    # oneDNN degrades when oversubscribed: probe the physical and the logical count (and a few below) -- never more threads than
+    # the container's CPU-time quota (the GPU boxes of this pool show 256 logical CPUs and are given 16 cores of CPU time)
+    quota = cgroup_cpu_limit()
+    limit = logical if quota is None else max(1, min(logical, int(quota)))
     best, threads = None, 1
-    for th in sorted({min(logical, c) for c in (8, 16, 32, phys, logical)}):
+    for th in sorted({min(limit, c) for c in (8, 16, 32, phys, logical)}):
         torch.set_num_threads(th)
         one(0)  # warm-up at this thread count
         t = time.perf_counter()
@@ -112,10 +115,26 @@ def cpu_baseline(synth, sd, code, f0, spkr, budget_s=9.0, max_utts=400, keep=8, 
         except Exception as e:  # noqa: BLE001
             node = {"error": f"{type(e).__name__}: {e}"}
     return {"value": round(sec / med, 2), "unit": "audio-sec/sec", "cores": threads, "kind": "port", "node": node,
-            "physical_cores": phys, "logical_cpus": logical, "cpu_model": model,
+            "physical_cores": phys, "logical_cpus": logical, "cpu_model": model, "cgroup_cpu_quota_cores": quota,
             "sample": f"{len(times)} x {sec:g} s utterances, B=1 each (reference style), torch CPU fp32, {threads} threads "
                       f"(best of a probe on a full utterance), 3 warm-ups, median of {len(times)} "
                       f"(mean rate {sec * len(times) / sum(times):.2f}), {sum(times):.1f} s of CPU work"}, waves
+
+
+def cgroup_cpu_limit():
+    """CPU-time quota of this container in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unreadable.  A box
+    can show 256 logical CPUs in its affinity mask and still be throttled to a fraction of them."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
 
 
 def _physical_core_sets(threads):
@@ -167,14 +186,18 @@ def cpu_node_worker(argv):
     print(json.dumps({"done": done, "late_start_s": max(0.0, ready - t0), "last_end": ends[-1] if ends else 0.0}), flush=True)
 
 
-def cpu_baseline_node(threads, B, T, duration=5.0, lead=9.0):
+def cpu_baseline_node(threads, B, T, duration=5.0, lead=12.0):
     """Whole-host figure next to the single-stream one: P = floor(physical cores / threads) concurrent B=1 oracle workers on
     disjoint core sets (fresh processes, `threads` threads each, same utterances), all measuring the same `duration` seconds of
     wall time; aggregate audio-sec/sec = finished utterances x utterance length / duration."""
     import subprocess
     sets = _physical_core_sets(threads)
+    quota = cgroup_cpu_limit()
+    if quota is not None:  # never start more busy threads than the container is given CPU time for
+        sets = sets[:max(0, int(quota) // threads)]
     if len(sets) < 2:
-        return {"skipped": f"{len(sets)} core set(s) of {threads} threads on this host"}
+        return {"skipped": f"{len(sets)} core set(s) of {threads} threads on this host"
+                           + (f" (cgroup CPU quota {quota:g} cores)" if quota is not None else "")}
     t0 = time.time() + lead  # the workers import torch, fold the weights and warm up before T0
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-node-worker", repr(t0), str(duration), str(threads),
                                str(B), str(T), ",".join(map(str, cs))], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
@@ -192,7 +215,8 @@ def cpu_baseline_node(threads, B, T, duration=5.0, lead=9.0):
     done = sum(r.get("done", 0) for r in res)
     return {"value": round(done * sec / duration, 2), "unit": "audio-sec/sec", "workers": len(sets), "threads_per_worker": threads,
             "cores": len(sets) * threads, "utterances": done, "window_s": duration,
-            "late_workers": sum(1 for r in res if r.get("late_start_s", 0) > 0 or "error" in r),
+            "late_workers": sum(1 for r in res if r.get("late_start_s", 0) > 0 or "error" in r), "cgroup_cpu_quota_cores": quota,
+            "per_worker_utterances": [r.get("done", 0) for r in res],
             "sample": f"{len(sets)} concurrent B=1 oracle processes x {threads} threads on disjoint physical cores "
                       f"(sched_setaffinity), {done} x {sec:g} s utterances finished in a common {duration:g} s window"}
 
