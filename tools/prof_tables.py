@@ -79,8 +79,8 @@ def enc_layers():
         out.append(lin(f"L{l} fc1 768->3072 + GELU", 768, 3072))
         out.append(lin(f"L{l} fc2 3072->768 + residual", 3072, 768, 768))
         out.append((f"L{l} LayerNorm", 0, 2 * B * 768 * Tn * f4))
-    out.append(lin("k-means centroid products 768->100", 768, 100))
-    out.append(("k-means argmin", 0, B * 100 * Tn * f4))
+    # round 5: ONE launch, the bit-exact fp32 fma-chain kernel on the vector ALU (products + argmin), reads the features once
+    out.append(("k-means assign 768->100 (fp32 fma chain on the VALU + argmin)", 2.0 * 768 * 100 * Tn * B, B * (768 * f4 + 8) * Tn))
     return out
 
 
