@@ -29,7 +29,6 @@ import wave
 
 import numpy as np
 import torch
-from scipy.io import wavfile
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "data")):
@@ -149,8 +148,8 @@ def main(argv=None):
 
     def write(waves):  # once per round, on the harness's delivery thread while the next round is computed
         for (i, t), w in sorted(waves.items()):
-            wavfile.write(os.path.join(a.output_dir, f"{os.path.splitext(files[i])[0]}_{t}_gen.wav"),
-                          h.sampling_rate, w)
+            formats.write_wav(os.path.join(a.output_dir, f"{os.path.splitext(files[i])[0]}_{t}_gen.wav"),
+                              h.sampling_rate, w)
 
     # DISSC_WRITERS=all (default for N > 1): every rank writes the conversions it produced (it drains its own slice of
     # the gathered buffer); rank0: rank 0 receives and writes every file

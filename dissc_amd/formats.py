@@ -79,3 +79,37 @@ def speaker_id(name, spkr_to_id, what="source"):
     except KeyError:
         raise KeyError(f"{what} speaker {name!r} is not in id_to_spkr ({len(spkr_to_id)} speakers); "
                        "pass --unseen_speaker for speakers outside the training set") from None
+
+
+def write_wav(path, rate, data):
+    """``scipy.io.wavfile.write(path, rate, data)`` for the two sample types this repo writes -- float32 (IEEE-float WAVE:
+    18-byte fmt chunk + fact chunk) and int16 (PCM) --, byte for byte (tests/test_host_logic.py compares the files), without
+    importing scipy.io (0.25-0.6 s of a CLI's start-up; the reference writes through the same scipy call: sr/inference.py:206,250)."""
+    import struct
+
+    import numpy as np
+    data = np.asarray(data)
+    if data.dtype.byteorder == '>':
+        data = data.astype(data.dtype.newbyteorder('<'))
+    if data.dtype == np.float32:
+        tag = 3
+    elif data.dtype == np.int16:
+        tag = 1
+    else:
+        raise ValueError(f"write_wav: unsupported dtype {data.dtype}")
+    channels = 1 if data.ndim == 1 else data.shape[1]
+    bits = data.dtype.itemsize * 8
+    fmt = struct.pack('<HHIIHH', tag, channels, int(rate), int(rate) * (bits // 8) * channels, channels * (bits // 8), bits)
+    if tag != 1:
+        fmt += b'\x00\x00'  # cbSize of a non-PCM format
+    body = b'WAVE' + b'fmt ' + struct.pack('<I', len(fmt)) + fmt
+    if tag != 1:
+        body += b'fact' + struct.pack('<II', 4, data.shape[0])
+    payload = np.ascontiguousarray(data)
+    if len(body) + 8 + payload.nbytes + 4 > 0xFFFFFFFF:
+        raise ValueError("write_wav: data exceeds the WAV size limit")
+    body += b'data' + struct.pack('<I', payload.nbytes)
+    with open(path, 'wb') as f:
+        f.write(b'RIFF' + struct.pack('<I', len(body) + payload.nbytes) + body)
+        f.write(payload.data if payload.size else b'')
+        # (no pad byte: both sample types have an even size)

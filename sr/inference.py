@@ -28,7 +28,6 @@ from pathlib import Path
 
 import numpy as np
 import torch
-from scipy.io import wavfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -58,6 +57,7 @@ def load_gt(path, code_len, pad=None, sampling_rate=16000, code_hop_size=None):
     (sr/dataset.py:225-227; resampy restated, parity unpinned)."""
     if not os.path.isfile(path):
         return None
+    from scipy.io import wavfile  # (only the ground-truth copies read wavs: not on the start-up path of a conversion)
     sr, audio = wavfile.read(path)
     if audio.ndim > 1:
         audio = audio[:, 0]
@@ -239,6 +239,11 @@ def main(argv=None):
     rank, local_rank, world, dist = harness.init_distributed(29512)
     device = torch.device('cuda', local_rank)
     ph.mark('process_group')
+    # The HIP context (+ the first allocation) takes ~0.3 s and needs nothing from the host work below -- config, manifest,
+    # checkpoint load --, so it is created on a helper thread meanwhile and joined before the first tensor goes to the device.
+    import threading
+    hip_up = threading.Thread(target=lambda: torch.zeros(1, device=device), name='dissc-hip-init', daemon=True)
+    hip_up.start()
 
     if os.path.isdir(a.checkpoint_file):
         config_file = os.path.join(a.checkpoint_file, 'config.json')
@@ -248,8 +253,6 @@ def main(argv=None):
         cp_g = a.checkpoint_file
     from dissc_amd import AttrDict, CodeGenerator, formats, harness
     from dissc_amd.generator import wav_postprocess_
-    torch.zeros(1, device=device)  # HIP context + library load, accounted on their own
-    ph.mark('hip_init', device)
     with open(config_file) as f:
         h = AttrDict(json.loads(f.read()))
     if not os.path.isfile(cp_g):
@@ -278,10 +281,12 @@ def main(argv=None):
     print("Loading '{}'".format(cp_g))
     state = torch.load(cp_g, map_location='cpu')
     print("Complete.")
+    ph.mark('manifest_and_checkpoint_load_host')
+    hip_up.join()
+    ph.mark('hip_init_exposed', device)  # what is left of the context creation after the host work above
     generator = CodeGenerator(h).to(device)
     generator.load_state_dict(state['generator'])
     generator.eval()
-    ph.mark('manifest_and_checkpoint_load', device)
     generator.remove_weight_norm()
     generator.prepare()
     ph.mark('fold_and_pack_weights', device)
@@ -292,7 +297,7 @@ def main(argv=None):
 
     def write(waves):  # once per round, on the harness's delivery thread while the next round is computed
         for j, w in sorted(waves.items()):
-            wavfile.write(os.path.join(a.output_dir, jobs[j]['out']), h.sampling_rate, w)
+            formats.write_wav(os.path.join(a.output_dir, jobs[j]['out']), h.sampling_rate, w)
 
     # Who writes (DISSC_WRITERS): "all" (default for N > 1, like the reference's pool workers, which each write their
     # own outputs: sr/inference.py:205-207,249-251 there) -- after the all-gather every rank drains the rows it decoded
@@ -308,8 +313,8 @@ def main(argv=None):
             gt = load_gt(str(audio_path), code_len, a.pad, h.sampling_rate,
                          None if a.eval_mode else int(h.code_hop_size))
             if gt is not None:
-                wavfile.write(os.path.join(a.output_dir, stem + '_gt.wav'), h.sampling_rate,
-                              peak_normalize(gt))
+                formats.write_wav(os.path.join(a.output_dir, stem + '_gt.wav'), h.sampling_rate,
+                                  peak_normalize(gt))
     ph.mark('gt_copies')
     if rank == 0:
         print(f'{len(jobs)} waveforms written to {a.output_dir}')

@@ -132,3 +132,26 @@ def test_parse_speaker_modes_and_unknown_source_speaker():
     assert [(j["spkr"], j["out"]) for j in jobs] == [(0, "p226_001_0_gen.wav")]
     with pytest.raises(NotImplementedError):
         sr.build_jobs(args(), AttrDict({"multispkr": "nope"}), samples, ids, None, None)
+
+
+def test_write_wav_is_scipy_byte_for_byte(tmp_path):
+    """dissc_amd.formats.write_wav (what sr/inference.py and convert.py write their outputs with, without importing scipy.io at
+    start-up) == scipy.io.wavfile.write -- the call the reference writes with (sr/inference.py:206,250) -- byte for byte"""
+    import numpy as np
+    from scipy.io import wavfile
+    from dissc_amd import formats
+    rs = np.random.RandomState(0)
+    cases = [rs.standard_normal(n).astype(np.float32) for n in (0, 1, 2, 3, 31999, 32000)]
+    cases += [(rs.standard_normal(n) * 3000).astype(np.int16) for n in (0, 1, 7, 16000)]
+    cases += [rs.standard_normal((100, 2)).astype(np.float32), np.asarray(rs.standard_normal(50), dtype='>f4')]
+    for i, x in enumerate(cases):
+        a, b = str(tmp_path / f"a{i}.wav"), str(tmp_path / f"b{i}.wav")
+        wavfile.write(a, 16000, x)
+        formats.write_wav(b, 16000, x)
+        assert open(a, "rb").read() == open(b, "rb").read(), (i, x.dtype, x.shape)
+        if x.size:
+            rate, back = wavfile.read(b)
+            assert rate == 16000 and np.array_equal(back, x.astype(x.dtype.newbyteorder('=')))
+    import pytest
+    with pytest.raises(ValueError):
+        formats.write_wav(str(tmp_path / "c.wav"), 16000, np.zeros(4, np.float64))
