@@ -17,8 +17,14 @@ import torch
 
 from test_gpu_pipeline import ROOT, _free_port, _run, _sweep_jobs, _write_models, _write_wavs, models  # noqa: F401
 
+# DISSC_MULTIGPU_REHEARSAL=gloo: run this file's code on a ONE-GPU box with two gloo ranks sharing the device (what the other test
+# files do for the product path) -- a rehearsal of the TESTS themselves, so that their first execution on a multi-GPU box is not
+# also the first execution of their fixtures and assertions.  Timing assertions and RCCL banners are skipped there.
+REHEARSAL = os.environ.get("DISSC_MULTIGPU_REHEARSAL", "") == "gloo"
+BACKEND = "gloo" if REHEARSAL else "nccl"
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL with one GPU per rank)")]
+              pytest.mark.skipif(torch.cuda.device_count() < 2 and not REHEARSAL,
+                                 reason="needs >= 2 GPUs (RCCL with one GPU per rank); DISSC_MULTIGPU_REHEARSAL=gloo rehearses on one")]
 
 
 def _clean_env(**kw):
@@ -26,6 +32,8 @@ def _clean_env(**kw):
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DISSC_FORCE_DIST", "DISSC_DIST_BACKEND", "DISSC_BENCH_BACKEND",
                         "DISSC_WRITERS")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if REHEARSAL:
+        env.update(DISSC_BENCH_BACKEND="gloo", DISSC_DIST_BACKEND="gloo")
     env.update(kw)
     return env
 
@@ -48,10 +56,10 @@ def bench2():
 
 def test_bench_two_gpus_over_rccl(bench2):
     j, log = bench2
-    assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and j["backend"] == "nccl" and j["scaling"] == "weak"
-    assert "nccl" in j["config"]["collective"] and "all_gather_into_tensor" in j["config"]["collective"]
+    assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and j["backend"] == BACKEND and j["scaling"] == "weak"
+    assert BACKEND in j["config"]["collective"] and "all_gather_into_tensor" in j["config"]["collective"]
     assert j["config"]["parallelism"] == "dp2" and j["value"] > 400  # 2 x 200x real time at the very least
-    assert "RCCL version" in log or "NCCL version" in log
+    assert REHEARSAL or "RCCL version" in log or "NCCL version" in log
     st = j["strong"]
     assert st["jobs"] == 1024 and len(st["per_rank_compute_ms"]) == 2 and 1.0 <= st["load_imbalance"] < 1.01
     assert 1 <= st["exchange"]["collectives"] == st["exchange"]["rounds"] <= 4  # ONE all-gather per exchange round
@@ -70,7 +78,7 @@ def test_strong_scaling_model_is_falsifiable_at_two_gpus(bench2):
         pytest.skip("no committed prediction for N = 2 (profiles/rNN/strong_model.json)")
     ratio = st["wall_ms"] / pred["predicted_wall_ms"]
     print(f"strong leg at 2 GPUs: measured {st['wall_ms']:.1f} ms, predicted {pred['predicted_wall_ms']:.1f} ms, ratio {ratio:.3f}")
-    assert 0.85 <= ratio <= 1.15, (st["wall_ms"], pred)
+    assert REHEARSAL or 0.85 <= ratio <= 1.15, (st["wall_ms"], pred)  # (two gloo ranks on ONE GPU say nothing about the model)
 
 
 @pytest.mark.parametrize("writers", ["all", "rank0"])
@@ -88,7 +96,7 @@ def test_sr_inference_two_gpus_rccl_equals_one_process(models, golden_dir, tmp_p
     script = os.path.join(ROOT, "sr", "inference.py")
     _run([sys.executable, script] + args + ["--output_dir", f"{td}/o1"], _clean_env(), td)
     r = _run(_torchrun(2, script, args + ["--output_dir", f"{td}/o2"]), _clean_env(DISSC_WRITERS=writers, NCCL_DEBUG="VERSION"), td)
-    assert "RCCL version" in r.stdout + r.stderr or "NCCL version" in r.stdout + r.stderr
+    assert REHEARSAL or "RCCL version" in r.stdout + r.stderr or "NCCL version" in r.stdout + r.stderr
     files = sorted(os.listdir(f"{td}/o1"))
     assert len(files) == 192 and sorted(os.listdir(f"{td}/o2")) == files
     for fn in files:
@@ -113,7 +121,7 @@ def test_convert_two_gpus_rccl_equals_one_process(models, golden_dir, tmp_path, 
 
 def test_all_visible_gpus_weak_scaling_line():
     """bench.py at N = every visible GPU (what the driver's SCALE run launches): one JSON line, N ranks seen, per-GPU work fixed"""
-    n = torch.cuda.device_count()
+    n = 2 if REHEARSAL else torch.cuda.device_count()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2", "--no-strong"],
                        env=_clean_env(), capture_output=True, text=True, timeout=1800, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
