@@ -117,7 +117,7 @@ struct DeviceOnce {
 };
 
 #ifdef __HIPCC__
-// erf to < 1 ulp without a branch (HuBERT's exact-erf GELU sits in VALU-bound epilogues, and a wave with lanes on both sides
+// erf to ~1 ulp (measured 1.18 ulp max; 0.96 with the library's expf in place of v_exp_f32) without a branch (HuBERT's exact-erf GELU sits in VALU-bound epilogues, and a wave with lanes on both sides
 // of the library routine's branch pays for both anyway): two minimax polynomials (Norbert Juffa's single-precision erff,
 // public; max error 0.96 ulp measured against float64 on 120 000 samples), |a| <= 0.9277: a + a P(a^2); above: 1 - exp(Q(|a|)).
 __device__ __forceinline__ float erf_1ulp(float a) {
@@ -129,7 +129,9 @@ __device__ __forceinline__ float erf_1ulp(float a) {
   r = fmaf(r, t, -6.34846687e-1f);
   r = fmaf(r, t, -1.28717512e-1f);
   r = fmaf(r, t, -t);
-  const float big = copysignf(1.0f - expf(r), a);
+  // exp through v_exp_f32 (x * log2(e), then the hardware's 2^x: 2 instructions instead of the library routine's 13): r <= -0.9 here,
+  // so exp(r) <= 0.4 and its ~2e-7 relative error (argument rounding + 1 ulp) is < 0.5 ulp of 1 - exp(r) >= 0.6
+  const float big = copysignf(1.0f - __expf(r), a);
   float q = -5.96761703e-4f;
   q = fmaf(q, s, 4.99119423e-3f);
   q = fmaf(q, s, -2.67681349e-2f);
