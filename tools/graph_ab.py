@@ -1,9 +1,16 @@
 #!/usr/bin/env python
-"""small-batch generator forwards with and without hipGraph replay: python tools/graph_ab.py"""
+"""small-batch generator forwards with and without hipGraph replay (DISSC_EXPERIMENTAL=1 builds only): python tools/graph_ab.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dissc_amd, synthdata as synth
-g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0"); g.load_state_dict(synth.synth_generator_state_dict(0)); g.eval().remove_weight_norm()
+def make(graphs):  # a handle snapshots the options when it is created (round 5): one generator per setting
+    assert dissc_amd.lib.dissc_set_option(b"graphs", graphs) == 0
+    g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0"); g.load_state_dict(synth.synth_generator_state_dict(0)); g.eval().remove_weight_norm()
+    c, f, s, _ = synth.synth_generator_inputs(1, 3, seed=1)
+    g(code=torch.from_numpy(c), f0=torch.from_numpy(f), spkr=torch.from_numpy(s))  # builds the native handle under the option
+    return g
+gs = {0: make(0), 1: make(1)}
+dissc_amd.lib.dissc_set_option(b"graphs", 0)
 for B, T in [(1, 100), (1, 500), (2, 500), (4, 500), (8, 250)]:
     code, f0, spkr, _ = synth.synth_generator_inputs(B, T, seed=1234)
     kw = dict(code=torch.from_numpy(code).cuda(), f0=torch.from_numpy(f0).cuda(), spkr=torch.from_numpy(spkr).cuda())
@@ -11,7 +18,7 @@ for B, T in [(1, 100), (1, 500), (2, 500), (4, 500), (8, 250)]:
         kw["lengths"] = torch.tensor([T - 7 * i for i in range(B)], dtype=torch.int32).cuda()
     res = {}
     for v in (0, 1, 0, 1):
-        assert dissc_amd.lib.dissc_set_option(b"graphs", v) == 0
+        g = gs[v]
         for _ in range(5): y = g(**kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

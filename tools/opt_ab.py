@@ -18,15 +18,19 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--frames", type=int, default=500)
 ap.add_argument("--iters", type=int, default=10)
 a = ap.parse_args()
-g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
-g.load_state_dict(synth.synth_generator_state_dict(0))
-g.eval().remove_weight_norm()
+def make_generator():
+    g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
+    g.load_state_dict(synth.synth_generator_state_dict(0))
+    return g.eval().remove_weight_norm()
+
+
 code, f0, spkr, _ = synth.synth_generator_inputs(a.batch, a.frames, seed=1234)
 kw = dict(code=torch.from_numpy(code).cuda(), f0=torch.from_numpy(f0).cuda(), spkr=torch.from_numpy(spkr).cuda())
 ref = None
 for rep in range(2):
     for v in a.values:
         assert dissc_amd.lib.dissc_set_option(a.key.encode(), v) == 0
+        g = make_generator()  # a handle snapshots the options when it is created (round 5): one generator per value
         for _ in range(3):
             y = g(**kw)
         torch.cuda.synchronize()
