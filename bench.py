@@ -482,10 +482,14 @@ def strong_leg(synth, g, dev, rank, world, dist, fake=False, reps=3):
                         "payload_bytes_this_rank": 4 * int(stats["payload_floats"])},
            "best_of": reps}
     if world > 1:  # the CLIs' default at N > 1: every rank drains and "writes" the rows it decoded itself
-        w2, a2, _ = run(True)
-        out["own_rows"] = {"what": "same list, every rank delivers the rows it decoded (DISSC_WRITERS=all, the CLIs' default at N > 1)",
+        w2, a2, s2 = run(True)
+        out["own_rows"] = {"what": "same list, every rank delivers the rows it decoded (DISSC_WRITERS=all, the CLIs' default at N > 1); "
+                                   "the round's collective carries the row tables only (DISSC_OWN_ROWS_GATHER=full: whole buffers)",
                            "wall_ms": ms(w2), "value": round(audio_sec / w2, 1),
-                           "exposed_tail_ms": ms(w2 - a2[:, 3].max())}
+                           "exposed_tail_ms": ms(w2 - a2[:, 3].max()),
+                           "exchange": {"collectives": int(s2.get("collectives", 0)), "rounds": int(s2["rounds"]),
+                                        "sent_bytes_per_rank": 4 * int(s2["sent_floats"]),
+                                        "rows_all_ranks": int(s2.get("rows_all_ranks", 0))}}
     emu = os.environ.get("DISSC_STRONG_EMULATE", "")
     if emu and world == 1 and not fake:
         # Every rank's share at N ranks (the LPT partition, the rounds and the batches of the N-rank run) computed in THIS

@@ -151,8 +151,8 @@ def main(argv=None):
             formats.write_wav(os.path.join(a.output_dir, f"{os.path.splitext(files[i])[0]}_{t}_gen.wav"),
                               h.sampling_rate, w)
 
-    # DISSC_WRITERS=all (default for N > 1): every rank writes the conversions it produced (it drains its own slice of
-    # the gathered buffer); rank0: rank 0 receives and writes every file
+    # DISSC_WRITERS=all (default for N > 1): every rank writes the conversions it produced (it drains its own packed
+    # buffer; the round's all-gather then carries the row tables only); rank0: rank 0 receives and writes every file
     own = world > 1 and os.environ.get("DISSC_WRITERS", "all") != "rank0"
     n = conv.run_sharded(n_samples, load, targets, rank, world, dist, f0_stats=f0_stats, sink=write,
                          round_floats=int(a.round_seconds * 16000), own_rows=own)

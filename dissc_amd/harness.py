@@ -15,7 +15,7 @@ resident footprint is bounded by the round and a failure loses one round at most
 run is cut into up to 4 rounds anyway and ``Exchange`` delivers round k (wait for the gather, device-to-host
 copy on a copy stream, unpack, sink) on a worker thread while round k + 1 computes: the serial tail of a run at
 N ranks is the delivery of its last round only.  Who delivers: rank 0 everything, or (``own_rows``) every rank
-the rows it decoded itself.
+the rows it decoded itself (the round's all-gather then carries the row tables only: ``Exchange``).
 
 Everything here is host logic; it runs on CPU tensors with the gloo backend in the tests (there the
 rows are packed with torch copies) and on CUDA tensors over RCCL/xGMI in production.  A non-None ``dist``
@@ -357,14 +357,22 @@ def unpack_waves(gathered, n_cap, copy=False, stats=None, transient=False, ranks
 
 
 def gather_store(store, n_cap, data_cap, rank, world_size, dist=None, unpack_ranks=(0,), stats=None, transient=False,
-                 src_ranks=None):
+                 src_ranks=None, tables_only=False):
     """The single collective of a round, synchronously.  Returns {job_id: samples} on the ranks in ``unpack_ranks``
     (None = every rank), {} elsewhere -- only the consumers pay the device-to-host copy (``src_ranks``: and only for
     the regions those ranks packed).  The collective runs whenever a process group is given (``dist`` not None),
-    also at world_size 1."""
+    also at world_size 1.  ``tables_only`` (own-rows delivery, the caller unpacks its OWN buffer): the collective carries
+    the header + row table of every rank (16 B per row) instead of the samples."""
     buf = store.pack(n_cap, data_cap)
-    _exchange_stats(stats, store, buf, dist)
-    if dist is not None:
+    lean = tables_only and dist is not None
+    _exchange_stats(stats, store, buf, dist, HDR + ENT * n_cap if lean else None)
+    if lean:
+        # own-rows delivery: no rank reads another rank's samples, so only the row TABLES travel (who decoded what, how long)
+        tables = torch.empty(world_size * (HDR + ENT * n_cap), dtype=torch.float32, device=buf.device)
+        dist.all_gather_into_tensor(tables, buf[:HDR + ENT * n_cap].contiguous())
+        _check_tables(tables.view(world_size, -1), n_cap, stats)
+        buf, src_ranks = buf.view(1, -1), None
+    elif dist is not None:
         out = torch.empty(world_size * buf.numel(), dtype=torch.float32, device=buf.device)
         dist.all_gather_into_tensor(out, buf)
         buf = out.view(world_size, -1)
@@ -388,8 +396,11 @@ class Exchange:
     (results returned as a dict) or on the CPU the rounds are delivered synchronously, as before.
 
     Who delivers what: ``unpack_ranks`` (default rank 0; None = every rank) receive EVERY waveform of the round;
-    ``own_rows=True`` instead makes every rank deliver exactly the rows it packed itself (it reads only its own slice
-    of the gathered buffer), which spreads the device-to-host copies and the file writes over the ranks.
+    ``own_rows=True`` instead makes every rank deliver exactly the rows it packed itself, which spreads the
+    device-to-host copies and the file writes over the ranks.  Nobody then reads another rank's samples, so the round's
+    collective carries the row TABLES only (header + 16 B per waveform: every rank still learns what every rank delivered,
+    ``stats['rows_all_ranks']``) and each rank unpacks its own buffer; ``DISSC_OWN_ROWS_GATHER=full`` sends the whole
+    buffers as rounds 4 and earlier did (N x the payload over xGMI and into HBM, read by nobody).
     ``decode`` maps the {job id: samples} of a round to what the sink / the result dict should see.
     Collectives are only ever ISSUED from the caller's thread, in the same order on every rank; the worker only waits."""
 
@@ -399,6 +410,9 @@ class Exchange:
         self.own_rows = bool(own_rows)
         self.delivers = self.own_rows or unpack_ranks is None or self.rank in unpack_ranks
         self.src_ranks = [self.rank] if self.own_rows else None
+        # own_rows: nobody reads another rank's samples, so the round's collective carries the row tables only (16 B per
+        # waveform) unless DISSC_OWN_ROWS_GATHER=full asks for the whole buffers (N x the payload over xGMI, for nothing)
+        self.lean = self.own_rows and dist is not None and os.environ.get("DISSC_OWN_ROWS_GATHER", "tables") != "full"
         self.sink, self.decode, self.stats = sink, decode, stats
         cuda = self.device.type == "cuda"
         if overlap is None:
@@ -430,23 +444,28 @@ class Exchange:
             self._thread.start()
 
     # -- worker ------------------------------------------------------------------------------------------------
-    def _deliver(self, k, work, ev, buf, n_cap):
+    def _deliver(self, k, work, ev, buf, n_cap, tables=None):
         import time
         t0 = time.perf_counter()
         if self.device.type == "cuda":
             with torch.cuda.device(self.device), torch.cuda.stream(self._side):
                 if work is not None:
                     work.wait()               # RCCL: the copy stream waits for the collective; gloo: the host does
-                elif ev is not None:
+                if ev is not None:
                     self._side.wait_event(ev)
                 self._side.synchronize()      # split "waiting for the round" from "moving it"
                 t1 = time.perf_counter()
-                got = unpack_waves(buf, n_cap, stats=self.stats, transient=True, ranks=self.src_ranks, slot=k & 1)
+                if self.lean:
+                    _check_tables(tables.view(self.world, -1), n_cap, self.stats)
+                got = unpack_waves(buf, n_cap, stats=self.stats, transient=True,
+                                   ranks=None if self.lean else self.src_ranks, slot=k & 1)
         else:
             if work is not None:
                 work.wait()
             t1 = time.perf_counter()
-            got = unpack_waves(buf, n_cap, stats=self.stats, transient=True, ranks=self.src_ranks)
+            if self.lean:
+                _check_tables(tables.view(self.world, -1), n_cap, self.stats)
+            got = unpack_waves(buf, n_cap, stats=self.stats, transient=True, ranks=None if self.lean else self.src_ranks)
         t2 = time.perf_counter()
         if self.decode is not None:
             got = self.decode(got)
@@ -465,7 +484,7 @@ class Exchange:
                 return
             try:
                 if self.error is None:
-                    self._deliver(*item[:5])
+                    self._deliver(*item[:5], tables=item[6] if self.lean else None)
             except BaseException as e:  # noqa: BLE001  (handed to the caller's thread by submit / finish)
                 self.error = e
             finally:
@@ -484,7 +503,7 @@ class Exchange:
             # synchronous round (no sink, CPU, or overlap switched off): pack, gather, unpack, deliver
             got = gather_store(store, n_cap, data_cap, self.rank, self.world, self.dist,
                                (self.rank,) if self.delivers else (), self.stats, transient=self.sink is not None,
-                               src_ranks=self.src_ranks)
+                               src_ranks=self.src_ranks, tables_only=self.lean)
             if self.decode is not None:
                 got = self.decode(got)
             if self.sink is not None:
@@ -502,17 +521,22 @@ class Exchange:
             self._raise()
         t1 = time.perf_counter()
         buf = store.pack(n_cap, data_cap)
-        _exchange_stats(self.stats, store, buf, self.dist)
+        tbl = HDR + ENT * n_cap
+        _exchange_stats(self.stats, store, buf, self.dist, tbl if self.lean else None)
         work = ev = out = None
-        if self.dist is not None:
+        if self.lean:
+            out = torch.empty(self.world * tbl, dtype=torch.float32, device=buf.device)
+            work = self.dist.all_gather_into_tensor(out, buf[:tbl], async_op=True)
+            view = buf.view(1, -1)   # this rank's own rows come out of its own buffer
+        elif self.dist is not None:
             out = torch.empty(self.world * buf.numel(), dtype=torch.float32, device=buf.device)
             work = self.dist.all_gather_into_tensor(out, buf, async_op=True)
             view = out.view(self.world, -1)
         else:
             view = buf.view(1, -1)
-            if self.device.type == "cuda":
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
+        if (self.lean or self.dist is None) and self.device.type == "cuda":
+            ev = torch.cuda.Event()   # the copy stream must see the pack (a collective's wait() orders only the collective)
+            ev.record(torch.cuda.current_stream(self.device))
         self.t["submit_wait_s"] += t1 - t0
         self.t["pack_s"] += time.perf_counter() - t1
         if self.delivers:
@@ -547,11 +571,28 @@ class Exchange:
         return self.delivered if self.sink is not None else self.result
 
 
-def _exchange_stats(stats, store, buf, dist):
+def _exchange_stats(stats, store, buf, dist, sent=None):
     if stats is not None:
         stats["payload_floats"] = stats.get("payload_floats", 0) + sum(int(b[1].sum()) for b in store.batches)
-        stats["sent_floats"] = stats.get("sent_floats", 0) + buf.numel()
+        stats["sent_floats"] = stats.get("sent_floats", 0) + (buf.numel() if sent is None else int(sent))
         stats["collectives"] = stats.get("collectives", 0) + (1 if dist is not None else 0)
+
+
+def _check_tables(tables, n_cap, stats=None):
+    """tables: f32 [world, HDR + ENT * n_cap] (any device), the row tables of a tables-only round.  Validates every rank's
+    header and counts what the round delivered over all ranks (``stats['rows_all_ranks']``, ``['floats_all_ranks']``):
+    the accounting the full all-gather gave for free."""
+    t = (tables.cpu() if tables.is_cuda else tables).contiguous().numpy().view(np.int32).reshape(tables.shape[0], 1 + n_cap, 4)
+    rows = used = 0
+    for r in range(t.shape[0]):
+        n, u = int(t[r, 0, 0]), int(t[r, 0, 2:4].copy().view(np.int64)[0])
+        if n < 0 or n > n_cap or u < 0:
+            raise ValueError(f"rank {r}: corrupt exchange header (rows {n}, data floats {u})")
+        rows, used = rows + n, used + u
+    if stats is not None:
+        stats["rows_all_ranks"] = stats.get("rows_all_ranks", 0) + rows
+        stats["floats_all_ranks"] = stats.get("floats_all_ranks", 0) + used
+    return rows, used
 
 
 def gather_waves(local_waves, local_ids, lengths, parts, hop, rank, world_size, device, dist=None,

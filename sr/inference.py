@@ -300,8 +300,8 @@ def main(argv=None):
             formats.write_wav(os.path.join(a.output_dir, jobs[j]['out']), h.sampling_rate, w)
 
     # Who writes (DISSC_WRITERS): "all" (default for N > 1, like the reference's pool workers, which each write their
-    # own outputs: sr/inference.py:205-207,249-251 there) -- after the all-gather every rank drains the rows it decoded
-    # itself, so device-to-host copies and file writes spread over the ranks; "rank0" -- rank 0 receives and writes
+    # own outputs: sr/inference.py:205-207,249-251 there) -- every rank drains the rows it decoded itself (the round's
+    # all-gather then carries the row tables only), so device-to-host copies and file writes spread over the ranks; "rank0" -- rank 0 receives and writes
     # every file.  The files are byte-identical either way.
     own = world > 1 and os.environ.get('DISSC_WRITERS', 'all') != 'rank0'
     run_stats = {} if ph.on else None

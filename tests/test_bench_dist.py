@@ -94,5 +94,7 @@ def test_cpu_baseline_whole_host_leg():
     if len(sets) < 2:
         return
     r = bench.cpu_baseline_node(2, 3, 25, duration=1.5, lead=8.0)
+    if r["late_workers"]:  # a loaded machine: the workers' `import torch` outlasted the lead -- once more with a long one
+        r = bench.cpu_baseline_node(2, 3, 25, duration=1.5, lead=30.0)
     assert r["workers"] == len(sets) and r["cores"] == 2 * len(sets) and r["utterances"] >= r["workers"]
     assert abs(r["value"] - r["utterances"] * 0.5 / 1.5) < 0.01 and r["late_workers"] == 0, r

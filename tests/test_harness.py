@@ -144,6 +144,18 @@ def _worker(rank, world, port, q):
         if own:
             mine = sorted(harness.lpt_shard([len(j["code"]) for j in _jobs()], world)[rank])
             assert sorted(seen2) == mine
+            # own rows: the collective carried the row tables only, and every rank saw all 25 rows accounted for
+            assert st2["rows_all_ranks"] == 25 and st2["sent_floats"] < st2["payload_floats"]
+            for ov in (True, False):   # the whole-buffer gather of rounds <= 4, and the synchronous tables-only round
+                os.environ["DISSC_OWN_ROWS_GATHER"] = "full" if ov else "tables"
+                seen3, st3 = {}, {}
+                harness.run_resynthesis(_FakeGenerator(), _jobs(), rank, world, "cpu", dist, max_batch=4, max_frames=100,
+                                        sink=lambda w: seen3.update({k: v.copy() for k, v in w.items()}), round_floats=400,
+                                        stats=st3, own_rows=True, overlap=ov)
+                os.environ.pop("DISSC_OWN_ROWS_GATHER")
+                assert sorted(seen3) == mine and all(np.array_equal(seen3[k], out[k]) for k in seen3)
+                assert (st3["sent_floats"] > st3["payload_floats"]) == ov and st3["collectives"] == st3["rounds"]
+                assert ov or st3["rows_all_ranks"] == 25
         else:
             assert sorted(seen2) == (sorted(out) if rank == 0 else [])
     q.put((rank, {k: v.tolist() for k, v in out.items()}))
