@@ -131,6 +131,8 @@ def main(argv=None):
         print("WARNING: data/encode.py --f0 zeros writes an all-zero (fully unvoiced) 'f0' track. It is only valid "
               "as input to `infer.py --pred_pitch` (which predicts F0 and never reads it); data/prep_dataset.py "
               "and resynthesis of the source pitch need --f0 yaapt.", file=sys.stderr)
+    from dissc_amd.harness import limit_host_threads
+    limit_host_threads()  # torch's host pool: a few threads, not one per logical CPU (start-up cost, harness.py)
     from dissc_amd.hubert import SpeechEncoder
     encoder = SpeechEncoder.by_name(dense_model_name=args.model_name, quantizer_model_name=args.quantizer_name,
                                     vocab_size=args.vocab_size, deduplicate=False,

@@ -679,6 +679,44 @@ def pin_to_gpu_numa(local_rank, n_local):
         return None
 
 
+def cgroup_cpu_quota():
+    """CPU-time quota of this container in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unreadable."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def limit_host_threads(local_world=1, cap=8):
+    """The CLIs' host work in torch is the weight-norm fold and a few small tensor ops; torch's default intra-op pool is one
+    thread per logical CPU, and STARTING 128 threads under a 16-core CPU quota cost 160 ms of the 210 ms the first fold took
+    (tools/first_op_probe.py, profiles/r05/create_timing.txt).  The pool is capped at min(cap, affinity / ranks on the node,
+    cgroup quota / ranks); OMP_NUM_THREADS or DISSC_HOST_THREADS (0 = leave torch alone) win.  Returns the thread count set, or
+    None when nothing was changed.  Process-wide: for the CLIs (which own their process), not for library users."""
+    env = os.environ.get("DISSC_HOST_THREADS")
+    if env is not None:
+        if int(env) <= 0:
+            return None
+        torch.set_num_threads(int(env))
+        return int(env)
+    if os.environ.get("OMP_NUM_THREADS"):
+        return None
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpu_quota()
+    if quota is not None:
+        avail = min(avail, max(1, int(quota)))
+    n = max(1, min(int(cap), avail // max(1, int(local_world))))
+    torch.set_num_threads(n)
+    return n
+
+
 def init_distributed(default_port, backend_env="DISSC_DIST_BACKEND"):
     """Process-group set-up shared by the CLIs (sr/inference.py, convert.py): one process per GPU from the
     torchrun environment.  Returns (rank, local_rank, world_size, dist-or-None).
@@ -687,10 +725,12 @@ def init_distributed(default_port, backend_env="DISSC_DIST_BACKEND"):
       mode for a box with fewer GPUs than ranks (ranks share devices round-robin, tensors staged through the host).
       Each rank's host threads are pinned to its GPU's NUMA node (``pin_to_gpu_numa``; DISSC_NUMA_PIN=0 = off).
     * WORLD_SIZE == 1: no process group -- unless ``DISSC_FORCE_DIST=1``, which initialises the same backend with
-      one rank so that the collectives of the path run on the one GPU that is there."""
+      one rank so that the collectives of the path run on the one GPU that is there.
+    Also caps torch's host thread pool (``limit_host_threads``)."""
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    limit_host_threads(int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world == 1 and os.environ.get("DISSC_FORCE_DIST", "0") != "1":
         return rank, local_rank, world, None
     import torch.distributed as dist

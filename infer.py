@@ -183,6 +183,8 @@ def main(argv=None):
     args = parser.parse_args(argv)
 
     assert args.pred_len | args.pred_pitch, "Inference must at least convert pitch or rhythm (or both)"
+    from dissc_amd.harness import limit_host_threads
+    limit_host_threads()  # torch's host pool: a few threads, not one per logical CPU (start-up cost, harness.py)
     assert (args.wild_sample & args.pred_len & args.pred_pitch) | (not args.wild_sample), \
         "If we use an unknown speaker we must convert both pitch and rhythm"
     seed_everything(args.seed)

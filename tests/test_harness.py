@@ -296,3 +296,23 @@ def test_numa_cpu_assignment():
     assert harness.numa_cpus_for(0, [-1], ranges) is None                       # unknown topology: leave it alone
     assert harness.numa_cpus_for(1, [0, 0], {0: [[0, 1, 2, 3]]}, allowed={2, 3}) == [3]
     assert harness._parse_cpulist("0-3,8,10-11\n") == [[0, 1, 2, 3], [8], [10, 11]]
+
+
+def test_limit_host_threads_env_rules(monkeypatch):
+    """the CLIs cap torch's host pool (start-up cost of one thread per logical CPU); explicit settings win"""
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+        monkeypatch.setenv("DISSC_HOST_THREADS", "0")
+        assert harness.limit_host_threads() is None and torch.get_num_threads() == before
+        monkeypatch.setenv("DISSC_HOST_THREADS", "3")
+        assert harness.limit_host_threads() == 3 and torch.get_num_threads() == 3
+        monkeypatch.delenv("DISSC_HOST_THREADS")
+        monkeypatch.setenv("OMP_NUM_THREADS", "5")
+        assert harness.limit_host_threads() is None and torch.get_num_threads() == 3
+        monkeypatch.delenv("OMP_NUM_THREADS")
+        n = harness.limit_host_threads(local_world=2, cap=8)
+        assert 1 <= n <= 8 and torch.get_num_threads() == n
+        assert harness.limit_host_threads(local_world=10 ** 6) == 1
+    finally:
+        torch.set_num_threads(before)
