@@ -214,3 +214,27 @@ def test_predictor_and_hubert_limits(env):
     with pytest.raises(ValueError):
         enc(torch.zeros(1, 399))
     assert P.infer_samples([], [], None, None) == []
+
+
+def test_maximum_sizes_index_arithmetic():
+    """Activation buffers beyond 2^31 ELEMENTS (generator: 1 700 x 5 s, 2.2e9 floats per stage buffer; HuBERT: 170 x 10 s,
+    2.8e9 floats out of conv0): rows of the giant batch are bit-identical to the same utterance on its own, tails are zero --
+    an int32 offset anywhere in the kernels or the host planners would show here (tools/max_size_probe.py has the larger sweep)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if torch.cuda.get_device_properties(0).total_memory < 150 * 2 ** 30:
+        pytest.skip("needs ~100 GB of HBM")
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "max_size_probe", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "max_size_probe.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    g = m.make_generator()
+    assert m.gen_case(g, 1700, 250, [0, 3, 849, 1342, 1343, 1699], True)
+    del g
+    torch.cuda.empty_cache()
+    enc = m.make_encoder()
+    assert m.hubert_case(enc, 170, 10.0, rows=(0, 85, 169))
+    del enc
+    torch.cuda.empty_cache()
