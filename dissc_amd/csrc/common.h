@@ -44,6 +44,8 @@ void set_error(const char* fmt, ...);
   X(c64_wide, 1, "c64_wide") \
   X(conv2_dma, 1, "conv2_dma") \
   X(mfast, 0, "mfast") \
+  X(xcd_order, 3, "xcd_order") \
+  X(xcd_mg, 0, "xcd_mg") \
   X(small_grid, 1, "small_grid") \
   X(enc_tc, 0, "enc_tc") \
   X(s2tc_xmode, 0, "s2tc_xmode") \
@@ -181,6 +183,10 @@ struct ConvArgs {
   int nsub_group;       // 16-row subtiles per group in the packed weights / bias arrays
   int act;              // 0 none, 1 exact GELU on (conv + bias) before any residual
   int mfast;            // 1: blockIdx.x walks the M tiles (XCD i keeps M tiles i, i+8, ... of the weights in its L2)
+  int xcd;              // 1: 1-D grid in XCD order -- workgroup id i runs on XCD i % 8 and takes M tile (i / 8) % MT of time tile
+                        //    i % 8 + 8 * ((i / 8) / MT): the M tiles that read one input window follow each other on ONE XCD (one L2)
+  int xcd_ntile, xcd_nb;  // time tiles per utterance / utterances of that enumeration
+  int xcd_mg, xcd_span;   // M tiles per sweep (the weight slabs one sweep keeps L2-resident); ids per sweep = padded time tiles * xcd_mg
   int prec;             // 0 exact fp32 MFMA; 1 split-bf16 ("bf16x3") on the bf16 matrix cores (opt-in)
   int m32;              // 1: weights packed for / launched on the 32x32x2 kernel (conv_mfma32.hip)
   int cfg32;            // tile shape id chosen for this launch (conv32_pick_cfg), -1 = the class default

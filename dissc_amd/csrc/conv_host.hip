@@ -128,6 +128,7 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
   a.CIN = dc.CIN; a.M = dc.M; a.KS = dc.KS; a.dil = dc.dil; a.nchunk = dc.nchunk;
   a.pad_left = dc.pad_left >= 0 ? dc.pad_left : ((dc.KS - 1) * dc.dil) / 2;
   a.mfast = 0;
+  a.xcd = 0; a.xcd_ntile = 0; a.xcd_nb = 0; a.xcd_mg = 0; a.xcd_span = 0;
   a.ragged_enum = 0;
   a.groups = dc.groups; a.nsub_group = dc.Mpad / (dc.m32 ? 32 : 16); a.act = dc.act; a.m32 = dc.m32; a.prec = dc.prec;
   a.cfg32 = -1;

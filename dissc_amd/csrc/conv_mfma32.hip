@@ -37,17 +37,35 @@ __global__ void __launch_bounds__(64 * WM * WN, DMA ? DISSC_LB32_DMA : DISSC_LB3
 
   int b = blockIdx.z;
   int bx = a.mfast ? blockIdx.y : blockIdx.x;  // time tile
-  const int by = a.mfast ? blockIdx.x : blockIdx.y;  // (group, M tile)
+  int by = a.mfast ? blockIdx.x : blockIdx.y;  // (group, M tile)
+  int ntile_g = a.mfast ? gridDim.y : gridDim.x, nb_g = gridDim.z;
+  if (a.xcd) {
+    // XCD order (1-D grid): the hardware deals workgroup ids round-robin over the 8 XCDs, each with its own 4 MB L2.
+    // The ids are cut into SWEEPS over all time tiles, one per group of xcd_mg M tiles (weight slabs that fit the L2
+    // together); inside a sweep the xcd_mg M tiles of one time tile -- which read the same input window -- take
+    // consecutive slots of ONE XCD.  So a window crosses the fabric once per sweep (not once per M tile) and a weight
+    // slab once per XCD (not once per utterance).
+    const int mt = a.mt_per_group * a.groups, mg = a.xcd_mg;
+    const int sweep = blockIdx.x / a.xcd_span, r = blockIdx.x - sweep * a.xcd_span;
+    const int s = r >> 3, sq = s / mg;
+    const int tt = (r & 7) + 8 * sq;
+    by = sweep * mg + (s - sq * mg);
+    ntile_g = a.xcd_ntile;
+    nb_g = a.xcd_nb;
+    if (tt >= ntile_g * nb_g || by >= mt) return;
+    b = tt / ntile_g;
+    bx = tt - b * ntile_g;
+  }
   if (a.ragged_enum) {
     // Ragged batch: (time tile, utterance) pairs are re-dealt so that only the tiles that EXIST are enumerated --
     // utterance 0's ceil(olen_0 / BN) tiles, then utterance 1's, ... -- and the workgroups left over all sit at the END of
     // the dispatch order (z slowest) and return at once, instead of lying between the real ones (conv_wino.hip has the
     // measurements).  Every wave finds its pair by a prefix sum of the tile counts over its lanes.  Not for
     // EPI_STORE_ACT, whose tiles beyond an utterance's end still have zero tails to write.
-    const int ntile = a.mfast ? gridDim.y : gridDim.x;
+    const int ntile = ntile_g;
     const int lin = b * ntile + bx;
     const int lane_ = threadIdx.x & 63;
-    const int nb = gridDim.z;
+    const int nb = nb_g;
     int base = 0;
     b = -1;
     for (int b0 = 0; b0 < nb; b0 += 64) {
@@ -307,6 +325,11 @@ static const TileCfg32 kCfgs32[] = {
 // option "conv_pad_lds" (Options::conv_pad_lds, default 0): "conv_pad_lds" option (diagnostics): extra LDS bytes per workgroup
 // option "c64_wide" (Options::c64_wide, default 1): "c64_wide" option: 64 x 256 tile (64 x 64 wave tiles) for the DMA-staged second convs of the C = 64 stage
 // option "conv2_dma" (Options::conv2_dma, default 1): "conv2_dma" option: stride-2 valid convs stage their window with global_load_lds
+// option "xcd_order" (Options::xcd_order, default 3): XCD-aware workgroup order (bit 0: 1x1 convs, 1: stride-2 convs, 2: the rest).
+//   Encoder, 32 x 10 s (profiles/r05/xcd_order.md): fabric traffic (PMC) 39.60 -> 31.25 GB per forward (conv1 7.98 -> 5.41,
+//   fc1 1.217 -> 0.746, qkv 0.752 -> 0.569), time unchanged (27.66 vs 27.66 ms); the generator's few instances: no change
+//   in either (bit 2 stays off).
+// option "xcd_mg" (Options::xcd_mg, default 0 = automatic): M tiles per sweep of that order
 // option "mfast" (Options::mfast, default 0): measured neutral on HuBERT linears (weights are L2/MALL resident either way)
 
 void conv32_set_cfg(int bm_class, int cfg) {
@@ -396,6 +419,28 @@ static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   a.mfast = (a.mt_per_group * a.groups >= 3 && opts().mfast) ? 1 : 0;
   if (a.mfast) grid = dim3(grid.y, grid.x, grid.z);
   a.ragged_enum = (opts().ragged_enum && (a.lengths || a.lengths_out) && a.epi != EPI_STORE_ACT && B > 1) ? 1 : 0;
+  // option "xcd_order" (Options::xcd_order): bit 0: 1x1 convs (linears), bit 1: stride-2 convs, bit 2: every other
+  // instance -- launches with >= 2 M tiles only (with one there is nothing to share)
+  const int xcd_bit = (STRIDE == 2) ? 2 : (SPAN == 0 ? 1 : 4);
+  a.xcd = ((opts().xcd_order & xcd_bit) && a.mt_per_group * a.groups >= 2 && !a.mfast) ? 1 : 0;
+  if (a.xcd) {
+    // M tiles per sweep: as many 32*MI*WM-row weight slabs as stay L2-resident next to the streamed windows (~3.2 MB of
+    // the 4 MB, and a divisor of the M tile count); "xcd_mg" overrides.  Slabs of which fewer than two fit (fc2, K = 3072: 3 MB
+    // each) are re-fetched whatever the order: such launches keep all their M tiles in one sweep (every window read once).
+    const int mt = a.mt_per_group * a.groups;
+    const double slab = (double)BM * a.CIN * a.KS * sizeof(float);
+    int mg = (int)(3.2 * 1024 * 1024 / slab);
+    if (mg < 2 || mg > mt) mg = mt;
+    while (mt % mg) --mg;  // whole sweeps only: a short last sweep would add a partly filled round of workgroups (qkv, 9 M tiles
+                           // in sweeps of 4 + 4 + 1: 467 -> 609 us)
+    if (opts().xcd_mg > 0) mg = opts().xcd_mg < mt ? opts().xcd_mg : mt;
+    a.xcd_ntile = (int)grid.x;
+    a.xcd_nb = B;
+    a.xcd_mg = mg;
+    const long long tt_pad = ((long long)grid.x * B + 7) / 8 * 8;
+    a.xcd_span = (int)(tt_pad * mg);
+    grid = dim3((unsigned)(tt_pad * mg * ((mt + mg - 1) / mg)), 1, 1);
+  }
   size_t lds_f = (size_t)2 * KC * CPB * a.XW;
   if (lds_f < (size_t)NW * 8 * CW) lds_f = (size_t)NW * 8 * CW;
   const size_t lds = lds_f * sizeof(float) + (size_t)opts().conv_pad_lds;  // (+ diagnostics: occupancy experiments)

@@ -136,6 +136,39 @@ def test_split_batch_forward_is_bit_identical(env):
             assert torch.equal(d[i, :T], outs[0][1][i, :T])
 
 
+def test_xcd_workgroup_order_is_bit_identical(env):
+    """option "xcd_order" (default 3): the implicit-GEMM launches of the encoder deal their workgroups in XCD order -- sweeps over
+    groups of M tiles whose weight slabs share an L2, the M tiles of one input window on one XCD (conv_mfma32.hip) -- which
+    changes WHO computes a tile and WHEN, never what: units and dense features equal those of the plain 3-D grid bit for bit,
+    on a ragged batch with NaN padding (tiles that do not exist are skipped by both enumerations), for the automatic sweep
+    size and for forced ones that leave a short last sweep."""
+    from dissc_amd import _lib
+    from dissc_amd.hubert import HubertEncoder
+    synth = env["synth"]
+    rs = np.random.RandomState(11)
+    ns = [int(v) for v in rs.randint(9000, 70001, size=13)] + [400, 16000]
+    wav = torch.full((len(ns), max(ns) + 320), float("nan"))
+    for i, n in enumerate(ns):
+        wav[i, :n] = torch.from_numpy(synth.synth_waveform(n, seed=700 + i))
+    outs = []
+    try:
+        for order, mg in ((0, 0), (3, 0), (3, 2), (1, 5), (2, 1)):  # (options are frozen per handle: one encoder per setting)
+            assert _lib.lib.dissc_set_option(b"xcd_order", order) == 0 and _lib.lib.dissc_set_option(b"xcd_mg", mg) == 0
+            enc = HubertEncoder(env["sd"], env["centers"], n_layers=6).to("cuda:0")
+            o = enc(wav, n_samples=torch.tensor(ns))
+            outs.append((o["units"].cpu(), o["dense"].cpu(), o["frames"].cpu()))
+            del enc
+    finally:
+        _lib.lib.dissc_set_option(b"xcd_order", 3)
+        _lib.lib.dissc_set_option(b"xcd_mg", 0)
+    for u, d, f in outs[1:]:
+        assert torch.equal(f, outs[0][2])
+        for i in range(len(ns)):
+            T = int(f[i])
+            assert torch.equal(u[i, :T], outs[0][0][i, :T])
+            assert torch.equal(d[i, :T], outs[0][1][i, :T])
+
+
 def test_units_differ_from_the_oracle_only_at_constructed_near_ties(env):
     """Centres built so that many frames sit (almost) exactly between two centres: the HIP units may
     then differ from the oracle's -- but only on those frames.  (With the random synthetic centres no

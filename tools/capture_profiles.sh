@@ -14,7 +14,7 @@ else
   CMD="python ${GRAFT_REPO_ROOT:-$PWD}/tools/encode_bench.py --iters 3"
 fi
 cd /tmp && export TMPDIR=/tmp
-export DISSC_OPTIONS=multistream=0
+export DISSC_OPTIONS=multistream=0${EXTRA_OPTS:+,$EXTRA_OPTS}
 run() {  # name, rocprof args...
   local name=$1; shift
   timeout 300 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o "$name" -- $CMD > "$OUT/$name.log" 2>&1
