@@ -13,9 +13,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <functional>
 #include <map>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <tuple>
+#include <vector>
 
 #include "common.h"
 
@@ -204,13 +209,60 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
     delete g;
     return code;
   };
+  // Packing a layer's weights (direct fragments, Toom-Cook transforms in double) is host work of ~60 ms for this model when done
+  // one layer after the other: the layers are independent, so their make_* calls are collected as tasks and run on a few host
+  // threads at the end (run_pack_tasks; DISSC_PACK_THREADS, default min(8, cores); 1 = in place).  Each task writes one
+  // pre-sized slot of the handle; a worker carries the creating thread's device, options snapshot and packing precision.
+  std::vector<std::function<int()>> tasks;
+  auto run_pack_tasks = [&]() -> int {
+    int nthr = 8;
+    if (const char* e = getenv("DISSC_PACK_THREADS")) nthr = atoi(e);
+    const unsigned hc = std::thread::hardware_concurrency();
+    if (hc && nthr > (int)hc) nthr = (int)hc;
+    if (nthr > (int)tasks.size()) nthr = (int)tasks.size();
+    if (nthr <= 1) {
+      for (auto& t : tasks)
+        if (int r = t()) return r;
+      return DISSC_OK;
+    }
+    int dev = 0;
+    DISSC_HIP_CHECK(hipGetDevice(&dev));
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_rc{DISSC_OK};
+    std::mutex err_mu;
+    std::string err_msg;
+    auto worker = [&]() {
+      if (hipSetDevice(dev) != hipSuccess) {
+        first_rc = DISSC_EHIP;
+        return;
+      }
+      OptScope scope(&g->opt);
+      g_conv_prec = prec;
+      for (size_t i = next++; i < tasks.size() && first_rc == DISSC_OK; i = next++) {
+        const int r = tasks[i]();
+        if (r != DISSC_OK) {
+          std::lock_guard<std::mutex> lk(err_mu);
+          if (first_rc == DISSC_OK) {
+            first_rc = r;
+            err_msg = g_err;  // the worker's thread-local message
+          }
+        }
+      }
+      g_conv_prec = 0;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthr; ++t) pool.emplace_back(worker);
+    for (auto& t : pool) t.join();
+    if (first_rc != DISSC_OK) set_error("%s", err_msg.empty() ? "dissc_gen_create: a packing thread failed" : err_msg.c_str());
+    return first_rc;
+  };
   if (in_dim != E + (cfg->has_f0 ? 1 : 0) + (cfg->has_spkr ? E : 0)) {
     set_error("dissc_gen_create: model_in_dim %d != embedding_dim %d (+1 f0) (+%d spkr)", in_dim, E, E);
     return fail(DISSC_EINVAL);
   }
   if ((rc = get("conv_pre.weight", {c0, in_dim, 7}, &w))) return fail(rc);
   if ((rc = get("conv_pre.bias", {c0}, &b))) return fail(rc);
-  if ((rc = make_conv(w, b, c0, in_dim, 7, 1, g->conv_pre))) return fail(rc);
+  tasks.push_back([=]() { return make_conv(w, b, c0, in_dim, 7, 1, g->conv_pre); });
 
   int ch = c0, mul = 1;
   g->ups.resize(cfg->num_upsamples);
@@ -233,7 +285,7 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
     if ((rc = get(name, {ch, cout, k}, &w))) return fail(rc);
     snprintf(name, sizeof(name), "ups.%d.bias", i);
     if ((rc = get(name, {cout}, &b))) return fail(rc);
-    if ((rc = make_convT(w, b, ch, cout, k, s, g->ups[i]))) return fail(rc);
+    tasks.push_back([=]() { return make_convT(w, b, ch, cout, k, s, g->ups[i]); });
     ch = cout;
     mul *= s;
     g->stage_C.push_back(ch);
@@ -256,9 +308,13 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         if ((rc = get(name, {ch}, &b))) return fail(rc);
         const bool wino = prec == 0 && wino_wanted(ch, rk) && wino_supported(ch, ch, rk, d);
         const bool w8 = wino && wino8_wanted(ch, rk, d);  // the eight-point forms on 8-wave workgroups (per shape: conv_wino8.hip)
-        if ((rc = w8 ? make_wino8(w, b, ch, rk, d, g->rb1[idx], wino8_taps(ch, rk, d))
-                     : wino ? make_wino(w, b, ch, rk, d, g->rb1[idx]) : make_conv(w, b, ch, ch, rk, d, g->rb1[idx])))
-          return fail(rc);
+        {
+          const int taps1 = w8 ? wino8_taps(ch, rk, d) : 0;
+          tasks.push_back([=]() {
+            return w8 ? make_wino8(w, b, ch, rk, d, g->rb1[idx], taps1)
+                      : wino ? make_wino(w, b, ch, rk, d, g->rb1[idx]) : make_conv(w, b, ch, ch, rk, d, g->rb1[idx]);
+          });
+        }
         const float* w1c = w;
         const float* b1c = b;
         if (bf3) {
@@ -271,14 +327,17 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
         if ((rc = get(name, {ch}, &b))) return fail(rc);
         const bool wino2 = wino;
         const bool w82 = wino && wino8_wanted(ch, rk, 1);
-        if ((rc = w82 ? make_wino8(w, b, ch, rk, 1, g->rb2[idx], wino8_taps(ch, rk, 1))
-                     : wino2 ? make_wino(w, b, ch, rk, 1, g->rb2[idx]) : make_conv(w, b, ch, ch, rk, 1, g->rb2[idx])))
-          return fail(rc);
+        {
+          const int taps2 = w82 ? wino8_taps(ch, rk, 1) : 0;
+          tasks.push_back([=]() {
+            return w82 ? make_wino8(w, b, ch, rk, 1, g->rb2[idx], taps2)
+                       : wino2 ? make_wino(w, b, ch, rk, 1, g->rb2[idx]) : make_conv(w, b, ch, ch, rk, 1, g->rb2[idx]);
+          });
+        }
         // the whole pair as one transform-domain launch (respair_wino.hip): C = 32, k = 7 / 11 and C = 64, k = 3
         // (C = 64: only a chain's FIRST pair -- the later ones update x_k in place, which a fused pair cannot)
-        if (prec == 0 && opts().wino && pairw_wanted(ch, rk, d) && (ch > 32 ? (wino && m == 0) : ch <= opts().pair_max_c) &&
-            (rc = make_pairw(w1c, b1c, w, b, ch, rk, d, g->pw[idx])))
-          return fail(rc);
+        if (prec == 0 && opts().wino && pairw_wanted(ch, rk, d) && (ch > 32 ? (wino && m == 0) : ch <= opts().pair_max_c))
+          tasks.push_back([=]() { return make_pairw(w1c, b1c, w, b, ch, rk, d, g->pw[idx]); });
         if (bf3) {
           w6[2 * m + 1] = w;
           fb.insert(fb.end(), b, b + ch);
@@ -309,6 +368,7 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
     if ((rc = upload(std::vector<float>(w, w + (size_t)cfg->num_speakers * E), &g->spkr_w)))
       return fail(rc);
   }
+  if ((rc = run_pack_tasks())) return fail(rc);
   if (opts().multistream && nk > 1) {
     if (hipEventCreateWithFlags(&g->ev_x, hipEventDisableTiming) != hipSuccess) return fail(DISSC_EHIP);
     for (int j = 0; j < nk; ++j) {

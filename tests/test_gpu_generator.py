@@ -610,3 +610,22 @@ def test_options_are_frozen_into_the_handle(env):
     finally:
         for k, v in saved.items():
             lib.dissc_set_option(k.encode(), v)
+
+
+def test_parallel_weight_packing_is_bit_identical(env, monkeypatch):
+    """dissc_gen_create packs the layers' weights on a few host threads (DISSC_PACK_THREADS, default 8): the handle must not
+    depend on how many -- same waveform, bit for bit, from handles built with 1, 3 and 16 packing threads."""
+    import dissc_amd
+    synth = env["synth"]
+    code, f0, spkr, _ = synth.synth_generator_inputs(3, 37, seed=21)
+    kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr))
+    outs = []
+    for n in ("1", "3", "16"):
+        monkeypatch.setenv("DISSC_PACK_THREADS", n)
+        g = dissc_amd.CodeGenerator(synth.VCTK_CONFIG).to("cuda:0")
+        g.load_state_dict(synth.synth_generator_state_dict(seed=0))
+        g.eval().remove_weight_norm()
+        outs.append(g(**kw).cpu())
+        del g
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], env["g"](**kw).cpu())
