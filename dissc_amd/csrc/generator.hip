@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <exception>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -239,7 +240,13 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
       OptScope scope(&g->opt);
       g_conv_prec = prec;
       for (size_t i = next++; i < tasks.size() && first_rc == DISSC_OK; i = next++) {
-        const int r = tasks[i]();
+        int r;
+        try {
+          r = tasks[i]();
+        } catch (const std::exception& e) {  // (an exception leaving a std::thread would terminate the process)
+          set_error("dissc_gen_create: packing a layer failed: %s", e.what());
+          r = DISSC_ENOMEM;
+        }
         if (r != DISSC_OK) {
           std::lock_guard<std::mutex> lk(err_mu);
           if (first_rc == DISSC_OK) {
@@ -251,8 +258,13 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
       g_conv_prec = 0;
     };
     std::vector<std::thread> pool;
-    for (int t = 0; t < nthr; ++t) pool.emplace_back(worker);
+    try {
+      for (int t = 0; t + 1 < nthr; ++t) pool.emplace_back(worker);
+    } catch (const std::exception&) {  // no more threads to be had: whoever started shares the tasks with this thread
+    }
+    worker();  // the creating thread packs too (and alone, if no thread could be started)
     for (auto& t : pool) t.join();
+    g_conv_prec = prec;  // (worker() cleared this thread's copy; the bf3 tail below and PrecScope's exit expect it set)
     if (first_rc != DISSC_OK) set_error("%s", err_msg.empty() ? "dissc_gen_create: a packing thread failed" : err_msg.c_str());
     return first_rc;
   };
