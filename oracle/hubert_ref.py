@@ -115,7 +115,8 @@ def kmeans_margin(x, centers):
     return top2[:, 1] - top2[:, 0]
 
 
-FEAT_EPS_L2_REL = 2e-4  # asserted bound on ||x_gpu[t] - x_ref[t]||_2 / ||x_ref[t]||_2 (the GPU tests assert it per frame)
+FEAT_EPS_L2_REL = 2e-5  # asserted bound on ||x_gpu[t] - x_ref[t]||_2 / ||x_ref[t]||_2, per frame: <= 10x the measured 1.6e-6 ... 3.7e-6
+                        # (profiles/r05/s2tc_encode_ab.txt) -- a regression guard, not the acceptance bar (round 5 verdict, weak #1)
 
 
 def unit_flip_allowed(x_ref, centers, eps_l2=None, eps_rel=FEAT_EPS_L2_REL):
@@ -153,10 +154,11 @@ def unit_flip_allowed(x_ref, centers, eps_l2=None, eps_rel=FEAT_EPS_L2_REL):
     return allowed.numpy(), int((allowed.sum(1) > 1).sum())
 
 
-def check_units(units, units_ref, x_ref, centers, x_dev=None, tag="units", max_mismatch_frac=0.02):
+def check_units(units, units_ref, x_ref, centers, x_dev=None, tag="units", max_mismatch=1):
     """Assert: every frame where ``units`` differs from the reference's is explained by the feature error (measured when
     ``x_dev`` is given, else the asserted FEAT_EPS_L2_REL bound) -- and the unit chosen instead is one of the explicable
-    ones -- and no more than ``max_mismatch_frac`` of the frames (+ 1) differ at all (None: unbounded, for constructed ties).
+    ones -- and no more than ``max_mismatch`` frames of the utterance differ at all (measured on every golden: 0; None: unbounded,
+    for constructed ties).
     Returns (n_mismatch, n_ambiguous)."""
     import numpy as np
     x_ref = torch.as_tensor(x_ref)
@@ -173,8 +175,8 @@ def check_units(units, units_ref, x_ref, centers, x_dev=None, tag="units", max_m
     print(f"{tag}: {int(mism.sum())} mismatching frames, {n_amb} ambiguous frames of {len(units)}"
           + (f", feature error <= {float(rel.max()):.2e} (l2, relative, per frame)" if x_dev is not None else ""))
     assert ok.all(), f"{tag}: frames {np.nonzero(~ok)[0][:10]} got units {units[~ok][:10]}, reference {units_ref[~ok][:10]}"
-    if max_mismatch_frac is not None:
-        assert int(mism.sum()) <= max_mismatch_frac * len(units) + 1, f"{tag}: {int(mism.sum())} of {len(units)} units differ"
+    if max_mismatch is not None:
+        assert int(mism.sum()) <= max_mismatch, f"{tag}: {int(mism.sum())} of {len(units)} units differ (allowed: {max_mismatch})"
     return int(mism.sum()), n_amb
 
 

@@ -1,7 +1,7 @@
 """GPU parity of the HuBERT unit encoder vs the HF/sklearn goldens and the CPU oracle.
 
 PARITY UNPINNED against fairseq/textless themselves (sources and weights absent, see
-oracle/hubert_ref.py); what is asserted here: dense features within 5e-4 (relative to the feature
+oracle/hubert_ref.py); what is asserted here: dense features within FEAT_MAX_REL = 2e-5 (relative to the feature
 scale) of HF ``HubertModel`` / the oracle, and unit indices equal EXCEPT where the MEASURED feature error can
 explain the other unit (oracle.hubert_ref.unit_flip_allowed: s_j - s_i <= 2 ||c_i - c_j|| ||delta|| + the fp32 rounding
 of the two score evaluations) -- and then the unit chosen must be one of the explicable ones; counts printed."""
@@ -12,6 +12,11 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+# Regression guard on the dense features, max |error| relative to the feature scale: <= 10x what the fp32 kernels deliver
+# (printed by every test below; the per-frame l2 figure is oracle.hubert_ref.FEAT_EPS_L2_REL).  The north-star bar for the
+# encoder is the UNITS; this guard is what catches a noisier kernel (split-bf16, a reordered transform) swapped in by accident.
+FEAT_MAX_REL = 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -28,10 +33,10 @@ def env(golden_dir):
                 g=np.load(os.path.join(golden_dir, "hubert.npz")))
 
 
-def _check_units(hr, units, dense_ref, centers, want, tag="", dense_dev=None, max_mismatch_frac=0.02):
+def _check_units(hr, units, dense_ref, centers, want, tag="", dense_dev=None, max_mismatch=1):
     """every frame where ``units`` differs from the reference's must be explained by the (measured) feature error:
     oracle.hubert_ref.check_units -- bound 2 ||c_i - c_j|| ||delta|| + fp32 rounding of the score, no hand-set margin"""
-    mism, amb = hr.check_units(units, want, dense_ref, centers, x_dev=dense_dev, tag=tag, max_mismatch_frac=max_mismatch_frac)
+    mism, amb = hr.check_units(units, want, dense_ref, centers, x_dev=dense_dev, tag=tag, max_mismatch=max_mismatch)
     return amb, mism
 
 
@@ -44,7 +49,8 @@ def test_hubert_matches_hf_golden(env, n):
     want = g[f"n{n}/dense"]
     assert dense.shape == want.shape
     err = np.abs(dense - want).max()
-    assert err <= 5e-4 * max(1.0, np.abs(want).max()), err
+    print(f"n={n}: max |dense error| {err:.3e} = {err / max(1.0, np.abs(want).max()):.2e} of the feature scale")
+    assert err <= FEAT_MAX_REL * max(1.0, np.abs(want).max()), err
     _check_units(env["hr"], out["units"][0].cpu().numpy(), want, env["centers"], g[f"n{n}/units"], f"n={n}", dense)
 
 
@@ -65,7 +71,7 @@ def test_hubert_ragged_batch_is_per_utterance_exact(env):
         assert np.isfinite(a).all()
         assert np.abs(a - b).max() <= 1e-5  # same kernels; only tile partitioning may differ
         want = env["g"][f"n{n}/dense"]
-        assert np.abs(a - want).max() <= 5e-4 * max(1.0, np.abs(want).max())
+        assert np.abs(a - want).max() <= FEAT_MAX_REL * max(1.0, np.abs(want).max())
 
 
 def test_hubert_10s_against_oracle(env):
@@ -75,7 +81,8 @@ def test_hubert_10s_against_oracle(env):
     assert out["units"].shape == (1, 499)
     units_ref, dense_ref = env["hr"].encode(env["sd"], env["centers"], wav)
     err = np.abs(out["dense"][0].cpu().numpy() - dense_ref.numpy()).max()
-    assert err <= 5e-4 * max(1.0, float(dense_ref.abs().max())), err
+    print(f"10 s: max |dense error| {err:.3e} = {err / max(1.0, float(dense_ref.abs().max())):.2e} of the feature scale")
+    assert err <= FEAT_MAX_REL * max(1.0, float(dense_ref.abs().max())), err
     _check_units(env["hr"], out["units"][0].cpu().numpy(), dense_ref.numpy(), env["centers"], units_ref.numpy(), "10 s",
                  out["dense"][0].cpu().numpy())
 
@@ -98,7 +105,7 @@ def test_hubert_batch32_ragged_2_to_10s_against_oracle(env):
         assert int(out["frames"][i]) == T
         u_ref, d_ref = hr.encode(env["sd"], env["centers"], wav[i:i + 1, :ns[i]])
         err = float((dense[i, :T] - d_ref).abs().max())
-        assert err <= 5e-4 * max(1.0, float(d_ref.abs().max())), (i, err)
+        assert err <= FEAT_MAX_REL * max(1.0, float(d_ref.abs().max())), (i, err)
         _check_units(hr, units[i, :T], d_ref, env["centers"], u_ref.numpy(), f"utt {i} ({ns[i]} samples)", dense[i, :T])
     for i in range(32):
         T = int(out["frames"][i])
@@ -189,7 +196,7 @@ def test_units_differ_from_the_oracle_only_at_constructed_near_ties(env):
     u_ref = hr.kmeans_assign(dense_ref, centers).numpy()
     enc = HubertEncoder(env["sd"], centers, n_layers=6).to("cuda:0")
     out = enc(wav)
-    near, mism = _check_units(hr, out["units"][0].cpu().numpy(), dense_ref, centers, u_ref, "constructed ties", max_mismatch_frac=None)
+    near, mism = _check_units(hr, out["units"][0].cpu().numpy(), dense_ref, centers, u_ref, "constructed ties", max_mismatch=None)
     assert near >= 50  # (every frame whose nearest centre is one of a twin pair is a near-tie by construction)
 
 
