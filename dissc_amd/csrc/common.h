@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -40,6 +42,9 @@ void set_error(const char* fmt, ...);
   X(lin_tile, 2, "lin_tile") \
   X(cpb2, 0, "cpb2") \
   X(lin_dma, 1, "lin_dma") \
+  X(lin128, 1, "lin128") \
+  X(lin128_dbg, 0, "lin128_dbg") \
+  X(lin128_stagger, 0, "lin128_stagger") \
   X(conv_pad_lds, 0, "conv_pad_lds") \
   X(c64_wide, 1, "c64_wide") \
   X(conv2_dma, 1, "conv2_dma") \
@@ -103,18 +108,28 @@ struct OptScope {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// One-time-per-DEVICE guard for hipFuncSetAttribute(MaxDynamicSharedMemorySize): the attribute is per device, and a process may
-// hold handles on several GPUs (a process-wide flag would set it on the first device only).  Usage:
-//   static DeviceOnce once;  if (once.first()) { hipFuncSetAttribute(...); }
+// One-time-per-DEVICE hipFuncSetAttribute(MaxDynamicSharedMemorySize): the attribute is per device, and a process may hold handles
+// on several GPUs (a process-wide flag would set it on the first device only).  Thread-safe (forwards are re-entrant per handle:
+// two threads may make their first launch of a kernel at once): the flag of a device is set only AFTER the attribute call has
+// succeeded, under a lock, so no thread can see "done" and launch before the attribute is in place; a failed call is retried
+// by the next launch.  Usage:  static DeviceOnce once;  DISSC_HIP_CHECK(once.max_lds(fn, bytes));
 struct DeviceOnce {
-  bool done[64] = {};
-  bool first() {
+  std::mutex mu;
+  std::atomic<bool> done[64];
+  DeviceOnce() {
+    for (auto& d : done) d.store(false, std::memory_order_relaxed);
+  }
+  hipError_t max_lds(const void* fn, int bytes) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return true;
-    bool& d = done[dev & 63];
-    const bool f = !d;
-    d = true;
-    return f;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::atomic<bool>& d = done[dev & 63];
+    if (d.load(std::memory_order_acquire)) return hipSuccess;
+    std::lock_guard<std::mutex> g(mu);
+    if (d.load(std::memory_order_relaxed)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) d.store(true, std::memory_order_release);
+    return e;
   }
 };
 
@@ -202,6 +217,7 @@ struct ConvArgs {
   int epi;
   int up;               // 1 = conv; s = ConvTranspose stride
   int up_np, up_p0;     // ConvTranspose phase group: row = co*up_np + pi, phase = up_p0 + pi
+  int stagger = 0;      // lin128_kernel: the second workgroup of every CU starts this many 1024-cycle ticks late (set by its launcher)
 };
 
 constexpr int MAX_TAP_SPAN = 60;    // (KS-1)*dil of the default instances (staging register budget)
@@ -216,6 +232,9 @@ void conv_set_cfg(int bm_class, int cfg);  // tuning hook (dissc_conv_bench / di
 int conv_xw(int M, int KS, int dil, int stride = 1, int m32 = 0, int bn = 0);  // bn > 0: explicit time tile
 // 32x32x2 form (conv_mfma32.hip)
 int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t stream);
+// HuBERT's linears on 256 x 128 tiles, two waves per SIMD (lin_gemm.hip); bit-identical to the 256 x 64 instances of launch_conv32
+bool lin128_supported(const ConvArgs& a);
+int launch_lin128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream);
 int conv32_tile_bn(int M);
 int conv32_cfg(int M);
 int conv32_pick_cfg(int M, int B, int Lmax_out);  // per-launch choice (steps down on small grids)

@@ -231,10 +231,7 @@ static int launch_bf3_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   size_t lds = (size_t)2 * 4 * a.XW * 16;
   if (lds < (size_t)WM * WN * 8 * CW * sizeof(float)) lds = (size_t)WM * WN * 8 * CW * sizeof(float);
   static DeviceOnce attr_once;  // per device (common.h)
-  if (attr_once.first()) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<MI, NI, WM, WN>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&conv_bf3_kernel<MI, NI, WM, WN>), 160 * 1024));
   hipLaunchKernelGGL((conv_bf3_kernel<MI, NI, WM, WN>), grid, dim3(64 * WM * WN), lds, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;

@@ -379,11 +379,7 @@ static int launch_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   if (lds_f < (size_t)NW * 16 * CW) lds_f = (size_t)NW * 16 * CW;
   const size_t lds = lds_f * sizeof(float);
   static DeviceOnce attr_once;  // per device (common.h)
-  if (attr_once.first()) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_mfma_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&conv_mfma_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>), 160 * 1024));
   hipLaunchKernelGGL((conv_mfma_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB>), grid, dim3(64 * WM * WN), lds,
                      stream, a);
   DISSC_HIP_CHECK(hipGetLastError());

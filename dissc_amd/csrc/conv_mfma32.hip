@@ -445,11 +445,7 @@ static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
   if (lds_f < (size_t)NW * 8 * CW) lds_f = (size_t)NW * 8 * CW;
   const size_t lds = lds_f * sizeof(float) + (size_t)opts().conv_pad_lds;  // (+ diagnostics: occupancy experiments)
   static DeviceOnce attr_once;  // per device (common.h)
-  if (attr_once.first()) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB, DMA>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB, DMA>), 160 * 1024));
   hipLaunchKernelGGL((conv_mfma32_kernel<MI, NI, WM, WN, STRIDE, SPAN, CPB, DMA>), grid, dim3(64 * WM * WN), lds,
                      stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
@@ -478,6 +474,7 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
     set_error("launch_conv32: kernel %d x dilation %d unsupported for %d rows", a.KS, a.dil, a.M);
     return DISSC_EINVAL;
   }
+  if (span == 0 && stride == 1 && opts().lin128 && lin128_supported(a) && a.nchunk >= 8) return launch_lin128(a, B, Lmax_out, stream);
   if (span == 0 && bm32_of(a.M) == 256 && a.nchunk >= 8) {  // 1x1 convs: 64 channels per barrier
     // (the tile must stay the default 256 x 64: a.XW was sized for its BN)
     const bool dma = opts().lin_dma && a.slope == 1.0f && a.pad_left == 0 && a.up == 1 && a.groups == 1 &&

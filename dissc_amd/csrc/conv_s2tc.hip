@@ -424,10 +424,7 @@ double s2tc_executed_macs_per_out(int Cout, int Cin) { return (double)Cout * Cin
 template <int DBG>
 static int launch_s2tc_t(const S2tcArgs& a, long long nwg, hipStream_t stream) {
   static DeviceOnce attr_once;  // per device (common.h)
-  if (attr_once.first()) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2tc_kernel<DBG>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&conv_s2tc_kernel<DBG>), 160 * 1024));
   hipLaunchKernelGGL(conv_s2tc_kernel<DBG>, dim3((unsigned)nwg), dim3(S2_NTH), (size_t)S2_LDS_FLOATS * sizeof(float), stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;

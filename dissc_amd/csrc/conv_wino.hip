@@ -681,10 +681,7 @@ static int launch_wino_c(const WinoArgs& a, int B, int Lmax, hipStream_t stream)
   const size_t epi_f = (size_t)6 * 32 * (32 * TW + 4) + ((DISSC_WINO_EPI2 && D != 1 && D % 4 != 0) ? (size_t)32 * (4 * D * NTU + 4) : 0);
   if (lds_f < epi_f) lds_f = epi_f;
   static DeviceOnce attr_once;  // per device (common.h)
-  if (attr_once.first()) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, DIL, CPR, RH, TW, SHV>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&conv_wino_kernel<NS, DIL, CPR, RH, TW, SHV>), 160 * 1024));
   WinoArgs aa = a;
   aa.gx = (Lmax + OT - 1) / OT;
   aa.gy = a.C / (32 * TW * RH);

@@ -624,10 +624,7 @@ template <int NS, int DIL, int MI, int NI, int WPS = 2, int R = 3>
 static int launch_wino8_t(const Wino8Args& a, int B, int Lmax, hipStream_t stream) {
   using G = Wino8Geo<NS, DIL, MI, NI, WPS, R>;
   static DeviceOnce attr_once;  // per device (common.h)
-  if (attr_once.first()) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<NS, DIL, MI, NI, WPS, R>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&conv_wino8_kernel<NS, DIL, MI, NI, WPS, R>), 160 * 1024));
   Wino8Args aa = a;
   aa.gx = (Lmax + G::OT - 1) / G::OT;
   aa.gy = a.C / (32 * MI);

@@ -23,6 +23,8 @@
 #include <tuple>
 #include <vector>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace dissc {
@@ -941,6 +943,9 @@ int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int e
     s = s * 1664525u + 1013904223u;
     v = ((s >> 8) / 16777216.0f - 0.5f) * 0.05f;
   }
+  // flags bit 5 (0x20): zero-filled operands (the chip clocks to its power budget: how much of a launch's time is the data's
+  // switching activity, not the schedule?  never a number to quote)
+  if (flags & 0x20) std::fill(w.begin(), w.end(), 0.f);
   DevConv dc;
   g_conv_prec = opts().precision;  // diagnostics follow the "precision" option like the generator does
   const bool w8 = (flags & 4) && wino8_supported(Cout, Cin, k, dilation);
@@ -958,6 +963,7 @@ int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int e
     s = s * 1664525u + 1013904223u;
     v = ((s >> 8) / 16777216.0f - 0.5f) * 2.f;
   }
+  if (flags & 0x20) std::fill(hx.begin(), hx.end(), 0.f);
   DISSC_HIP_CHECK(hipMalloc((void**)&x, nx * 4));
   DISSC_HIP_CHECK(hipMalloc((void**)&y, no * 4));
   DISSC_HIP_CHECK(hipMalloc((void**)&r, no * 4));
@@ -985,6 +991,14 @@ int dissc_conv_bench(int B, int Cin, int Cout, int k, int dilation, int L, int e
   *ms_out = ms / iters;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (const char* tlp = getenv("DISSC_TIMELINE")) {  // diagnostics: the head of the accumulator buffer (a kernel's timeline stamps)
+    std::vector<char> hb(std::min<size_t>(no * 4, (size_t)4096 * 64));
+    if (hipMemcpy(hb.data(), a, hb.size(), hipMemcpyDeviceToHost) == hipSuccess)
+      if (FILE* f = fopen(tlp, "wb")) {
+        fwrite(hb.data(), 1, hb.size(), f);
+        fclose(f);
+      }
+  }
   (void)hipFree(x); (void)hipFree(y); (void)hipFree(r); (void)hipFree(a);
   free_conv(dc);
   if (rc) return rc;

@@ -399,10 +399,7 @@ static int launch_bf3(ResblockBf3Args a, int B, int Lmax, hipStream_t stream) {
   a.BN = COLS - 2 * a.H4;
   const size_t lds = (size_t)4 * (C / 8) * XW * 16;
   static DeviceOnce attr_once;  // per device (common.h)
-  if (attr_once.first()) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bf3_kernel<C, KS, NW, NI>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&resblock_bf3_kernel<C, KS, NW, NI>), 160 * 1024));
   dim3 grid((Lmax + a.BN - 1) / a.BN, B);
   hipLaunchKernelGGL((resblock_bf3_kernel<C, KS, NW, NI>), grid, dim3(64 * NW), lds, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());

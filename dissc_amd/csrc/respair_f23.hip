@@ -316,10 +316,7 @@ template <int KS_, int DIL>
 static int launch_f23_t(const PairFArgs& a, int B, int Lmax, hipStream_t stream) {
   using G = F23Geo<KS_, DIL>;
   static DeviceOnce attr_once;  // per device (common.h)
-  if (attr_once.first()) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&respair32_f23_kernel<KS_, DIL>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&respair32_f23_kernel<KS_, DIL>), 160 * 1024));
   dim3 grid((Lmax + G::WOUT - 1) / G::WOUT, B);
   hipLaunchKernelGGL((respair32_f23_kernel<KS_, DIL>), grid, dim3(256), sizeof(float) * G::C * G::XW, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());

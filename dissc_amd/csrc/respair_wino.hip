@@ -662,10 +662,7 @@ template <int C, int KS, int DIL, int CHV>
 static int launch_pairw_t(PairWArgs a, int B, int Lmax, hipStream_t stream) {
   using G = PairWGeo<C, KS, DIL, CHV>;
   static DeviceOnce attr_once;  // per device (common.h)
-  if (attr_once.first()) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&respair_wino_kernel<C, KS, DIL, CHV>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&respair_wino_kernel<C, KS, DIL, CHV>), 160 * 1024));
   a.gx = (Lmax + G::OT - 1) / G::OT;
   a.B = B;
   const int grid = a.gx * B;

@@ -562,10 +562,7 @@ int dissc_yaapt_spectral(dissc_yaapt_t y, const float* wav, const int32_t* n_sam
     a.cand_pitch = cand_pitch; a.cand_merit = cand_merit; a.shc_out = shc_out;
     const size_t lds = ((size_t)SHC_FR * (y->half + y->shc_nb) + (size_t)SHC_FR * y->max_shc) * sizeof(float);
     static DeviceOnce attr_once;  // per device (common.h)
-    if (attr_once.first()) {
-      DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&yaapt_shc_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&yaapt_shc_kernel), 160 * 1024));
     if (lds > 160 * 1024) {
       set_error("dissc_yaapt_spectral: %zu bytes of LDS needed", lds);
       return DISSC_EINVAL;

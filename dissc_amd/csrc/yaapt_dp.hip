@@ -536,10 +536,7 @@ int dissc_yaapt_spec_track(const DisscYaaptTrackConfig* cfg, const float* energy
   const size_t lds = (size_t)4 * F;
   a.back_in_lds = lds <= kLdsBack;
   static DeviceOnce attr_once;  // per device (common.h)
-  if (attr_once.first()) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&yaapt_spec_track_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBack));
-  }
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&yaapt_spec_track_kernel), (int)kLdsBack));
   hipLaunchKernelGGL(yaapt_spec_track_kernel, dim3(B), dim3(DP_NT), a.back_in_lds ? lds : 0, (hipStream_t)stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
@@ -569,10 +566,7 @@ int dissc_yaapt_final_track(const DisscYaaptTrackConfig* cfg, const float* tp1, 
   const size_t lds = (size_t)8 * F;
   a.back_in_lds = lds <= kLdsBack;
   static DeviceOnce attr_once;  // per device (common.h)
-  if (attr_once.first()) {
-    DISSC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&yaapt_final_track_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBack));
-  }
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&yaapt_final_track_kernel), (int)kLdsBack));
   hipLaunchKernelGGL(yaapt_final_track_kernel, dim3(B), dim3(DP_NT), a.back_in_lds ? lds : 0, (hipStream_t)stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
