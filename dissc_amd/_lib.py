@@ -106,6 +106,10 @@ def _load():
     L.dissc_pitch_stats.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     i64 = ctypes.c_longlong
     L.dissc_pack_rows.argtypes = [vp, i64, vp, vp, i32, i32, vp, vp]
+    L.dissc_comm_unique_id.argtypes = [ctypes.c_char_p]
+    L.dissc_comm_create.argtypes = [ctypes.c_char_p, i32, i32, ctypes.POINTER(vp)]
+    L.dissc_comm_destroy.argtypes = [vp]
+    L.dissc_allgather_waves.argtypes = [vp, vp, ctypes.c_size_t, vp, vp]
     L.dissc_resample.argtypes = [vp, i32, vp, i32, ctypes.c_double, vp, vp, i32, i32, vp]
     return L
 

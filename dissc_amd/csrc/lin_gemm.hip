@@ -366,9 +366,24 @@ int launch_lin128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream) {
     case 32: return launch_lin128_t<2, 32, 2, 32>(a, B, Lmax_out, stream);
     default: set_error("lin128_dbg: no instance %d", opts().lin128_dbg); return DISSC_EINVAL;
   }
-  switch (opts().lin128) {
-    case 2: return launch_lin128_t<2, 32, 2>(a, B, Lmax_out, stream);
-    default: return launch_lin128_t<2, 64, 2>(a, B, Lmax_out, stream);
+  // Tile shape per launch (option "lin128": 1 = this policy; 2 / 3 / 5 force a shape, for the gate records).  All shapes give the same
+  // bits.  A CU works its tiles off two or three at a time; what decides is how evenly the tile count divides over 256 CUs
+  // (profiles/r06/lin128_gate_v7.txt, B = 32 x T = 499, us, old kernel / 256 x 128 / 128 x 128 x3 per CU / 128 x 128 x2 per CU, 64
+  // channels per barrier: fc1 619 / 581 / 628 / 594, fc2 629 / 748 / 592 / 579, qkv 470 / 491 / 474 / 448, out_proj 182 / 198 / 164 /
+  // 192, proj 116 / 134 / 114 / 134):
+  //   256 x 128 (64-row waves: half the A traffic per MFMA) when that leaves no CU with more row-tile work than 128-row tiles would;
+  //   else 128 x 128: three workgroups per CU when a CU gets at most three tiles of a short K loop (one round, nobody alone),
+  //   else two per CU with 64 channels per barrier.
+  int mode = opts().lin128;
+  if (mode == 1) {
+    const long long ct = (long long)((Lmax_out + 127) / 128) * B;  // column tiles (an upper bound for ragged batches)
+    const long long m1 = (ct * ((a.M + 127) / 128) + 255) / 256, m2 = (ct * ((a.M + 255) / 256) + 255) / 256;
+    mode = (2 * m2 <= m1) ? 2 : ((m1 <= 3 && a.CIN < 2048) ? 3 : 5);
+  }
+  switch (mode) {
+    case 2: return launch_lin128_t<2, 32, 2>(a, B, Lmax_out, stream);  // 256 x 128 tiles, two workgroups per CU
+    case 3: return launch_lin128_t<1, 32, 3>(a, B, Lmax_out, stream);  // 128 x 128 tiles, three workgroups per CU
+    default: return launch_lin128_t<1, 64, 2>(a, B, Lmax_out, stream); // 128 x 128 tiles, two per CU, 64 channels per barrier
   }
 }
 

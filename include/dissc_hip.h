@@ -35,6 +35,8 @@ extern "C" {
 #define DISSC_ENOMEM (-2)   /* workspace too small / device allocation failed */
 #define DISSC_EHIP (-3)     /* a HIP runtime call failed */
 #define DISSC_ENOTFOUND (-4) /* a required weight tensor is missing */
+#define DISSC_ENOTSUP (-5)  /* an optional dependency is absent (RCCL for the dissc_comm_* / dissc_allgather_waves entries) */
+#define DISSC_ECOMM (-6)    /* an RCCL call failed */
 
 /* A named host tensor (fp32, contiguous, PyTorch layout). */
 typedef struct {
@@ -351,6 +353,30 @@ int dissc_wav_postprocess(float* wav, const int32_t* n_samples, int B, int ld, v
  * ------------------------------------------------------------------------- */
 int dissc_pack_rows(const float* wav, long long ld_wav, const int32_t* n_samples, const long long* offsets,
                     int B, int n_max, float* data, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * The path's one collective: the all-gather of the waveform exchange buffers over RCCL (xGMI inside a node).
+ * Replaces: the reference's Pool(8) result hand-back (sr/inference.py:288-292,351-354: every worker writes its own
+ * files, the parent joins) -- north_star's "single RCCL all-gather of decoded waveforms".  With these four entries a
+ * maintainer who binds the C ABI alone (no torch.distributed) can run the multi-GPU path: pack with dissc_pack_rows,
+ * gather with dissc_allgather_waves, unpack on the host (layout above).
+ * librccl.so is NOT a link dependency of this library: the entries resolve ncclGetUniqueId / ncclCommInitRank /
+ * ncclAllGather / ncclCommDestroy at first use from the RCCL the process already holds (PyTorch's, when it was imported
+ * first), else from $DISSC_RCCL_LIB, librccl.so.1, /opt/rocm/lib/librccl.so.1 -- DISSC_ENOTSUP when none loads.
+ *   dissc_comm_unique_id   rank 0 makes the 128-byte id (DISSC_COMM_ID_BYTES) and hands it to the other ranks out of band
+ *   dissc_comm_create      collective over the nranks processes, each on its own current HIP device (RCCL: one GPU per rank);
+ *                          *comm is an ncclComm_t
+ *   dissc_allgather_waves  nccl_comm: an ncclComm_t -- from dissc_comm_create or any other owner (e.g. the one PyTorch's
+ *                          ProcessGroupNCCL holds); send: n_floats f32 on this rank's device, recv: nranks * n_floats f32, rank r's
+ *                          block at r * n_floats (send may alias its own block: in place); enqueued on `stream`, returns at once
+ *                          (ordering and completion are the stream's); n_floats must be the same on every rank
+ *   dissc_comm_destroy     after the stream has drained
+ * ------------------------------------------------------------------------- */
+#define DISSC_COMM_ID_BYTES 128
+int dissc_comm_unique_id(void* id_out);
+int dissc_comm_create(const void* id, int nranks, int rank, void** comm_out);
+int dissc_comm_destroy(void* comm);
+int dissc_allgather_waves(void* nccl_comm, const float* send, size_t n_floats, float* recv, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * YAAPT F0 tracker, device front end.

@@ -60,3 +60,17 @@ def test_generator_wrapper_host_logic(built):
         g.to("cpu")  # no CPU fallback
     assert torch.equal(g._upsample(torch.arange(3.).view(1, 1, 3), 6),
                        torch.tensor([0., 0, 1, 1, 2, 2]).view(1, 1, 6))
+
+
+def test_collective_entries_refuse_bad_arguments_without_a_gpu(built):
+    """dissc_comm_* / dissc_allgather_waves (SURVEY 8(b)'s collective): argument errors are reported, nothing is launched."""
+    import dissc_amd.collective as coll
+    L = built.lib
+    assert L.dissc_allgather_waves(None, None, 0, None, None) == -1 and b"bad argument" in L.dissc_last_error()
+    assert L.dissc_comm_unique_id(None) == -1
+    h = ctypes.c_void_p()
+    assert L.dissc_comm_create(b"\0" * 128, 0, 0, ctypes.byref(h)) == -1 and h.value is None
+    assert L.dissc_comm_create(b"\0" * 128, 2, 2, ctypes.byref(h)) == -1
+    assert L.dissc_comm_destroy(None) == 0
+    with pytest.raises(ValueError):
+        coll.WaveComm(b"short", 1, 0, device="cuda:0")

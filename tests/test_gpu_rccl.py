@@ -153,3 +153,99 @@ def test_to_host_double_buffered_path_on_a_non_current_device():
         t.mul_(2.0).mul_(0.5)
         got = harness._to_host(t)
     assert got.shape == (n,) and np.array_equal(got, want.numpy())
+
+
+def _cabi_rank(rank, world, uid_path, out_path):
+    """one rank of the C-ABI all-gather: its own GPU, a WaveComm made from the id rank 0 wrote, one gather_store round"""
+    import time
+    import torch as th
+    from dissc_amd import collective, harness
+    dev = f"cuda:{rank}"
+    th.cuda.set_device(rank)
+    if rank == 0:
+        uid = collective.unique_id()
+        with open(uid_path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(uid_path + ".tmp", uid_path)
+    else:
+        for _ in range(600):
+            if os.path.exists(uid_path):
+                break
+            time.sleep(0.1)
+        uid = open(uid_path, "rb").read()
+    comm = collective.WaveComm(uid, world, rank, device=dev)
+    rs = np.random.RandomState(100 + rank)
+    lens = [4097 + 13 * rank, 1, 160000 - 7 * rank, 0, 12288]
+    ids = [1000 * rank + k for k in range(len(lens))]
+    st = harness.WaveStore(dev)
+    w = th.full((len(lens), max(lens) + 8), float("nan"), device=dev)
+    for r, n in enumerate(lens):
+        w[r, :n] = th.from_numpy(rs.standard_normal(n).astype(np.float32)).to(dev)
+    st.add(w, lens, ids)
+    n_cap, d_cap = len(lens) + 1, 180000 + 4 * 4097 + 64
+    out = harness.gather_store(st, n_cap, d_cap, rank, world, comm, unpack_ranks=None)
+    comm.destroy()
+    np.savez(out_path, **{str(k): v for k, v in out.items()})
+
+
+def _cabi_expected(world):
+    want = {}
+    for rank in range(world):
+        rs = np.random.RandomState(100 + rank)
+        for k, n in enumerate([4097 + 13 * rank, 1, 160000 - 7 * rank, 0, 12288]):
+            want[1000 * rank + k] = rs.standard_normal(n).astype(np.float32)
+    return want
+
+
+def test_cabi_allgather_world_size_one_equals_torch_distributed(tmp_path):
+    """dissc_comm_* + dissc_allgather_waves on a world-size-1 RCCL communicator made through the C ABI: the gathered buffer is
+    byte-identical to torch.distributed's all_gather_into_tensor of the same packed buffer (the CLIs' default route), in place
+    and out of place, and a whole gather_store round through the WaveComm returns every waveform."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.distributed as dist
+    from dissc_amd import collective, harness
+    _cabi_rank(0, 1, str(tmp_path / "uid"), str(tmp_path / "r0.npz"))
+    got = np.load(str(tmp_path / "r0.npz"))
+    want = _cabi_expected(1)
+    assert sorted(int(k) for k in got.files) == sorted(want)
+    for k, v in want.items():
+        np.testing.assert_array_equal(got[str(k)], v)
+    # the raw collective against torch.distributed on the same bytes
+    buf = torch.randn(300001, device=DEV)
+    comm = collective.WaveComm(collective.unique_id(), 1, 0, device=DEV)
+    out_c = torch.empty_like(buf)
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    comm.all_gather_into_tensor(out_c, buf, async_op=True, stream=side).wait()
+    inplace = buf.clone()
+    comm.all_gather_into_tensor(inplace, inplace)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        out_t = torch.empty_like(buf)
+        dist.all_gather_into_tensor(out_t, buf)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    comm.destroy()
+    assert torch.equal(out_c.view(torch.int32), out_t.view(torch.int32)) and torch.equal(inplace, buf)
+    with pytest.raises(Exception):
+        comm.all_gather_into_tensor(out_c, buf)  # destroyed
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: auto-enables on a box with >= 2 GPUs")
+def test_cabi_allgather_two_ranks_over_xgmi(tmp_path):
+    """two processes, one GPU each, the communicator and the all-gather through the C ABI only (no torch.distributed)"""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_rccl as t; "
+            "t._cabi_rank(int(sys.argv[1]), 2, sys.argv[2], sys.argv[3])") % (ROOT, os.path.join(ROOT, "tests"))
+    uid = str(tmp_path / "uid")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), uid, str(tmp_path / f"r{r}.npz")], env=_env(), cwd=ROOT)
+             for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    want = _cabi_expected(2)
+    for r in range(2):
+        got = np.load(str(tmp_path / f"r{r}.npz"))
+        assert sorted(int(k) for k in got.files) == sorted(want)
+        for k, v in want.items():
+            np.testing.assert_array_equal(got[str(k)], v)
