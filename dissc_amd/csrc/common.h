@@ -44,6 +44,7 @@ void set_error(const char* fmt, ...);
   X(lin_dma, 1, "lin_dma") \
   X(lin128, 1, "lin128") \
   X(lin128_dbg, 0, "lin128_dbg") \
+  X(conv2s128, 1, "conv2s128") \
   X(lin128_stagger, 0, "lin128_stagger") \
   X(conv_pad_lds, 0, "conv_pad_lds") \
   X(c64_wide, 1, "c64_wide") \
@@ -181,6 +182,7 @@ constexpr int ZERO_TAIL = 8;  // >= the largest padding of a consumer ((11 - 1) 
 struct ConvArgs {
   const float* x;       // [B][CIN][ldx]
   const float* wpack;   // packed A fragments, see pack_conv_weights()
+  const float* wpack2 = nullptr;  // the same weights in conv2s128_kernel's order (stride-2, k = 3 layers only; lin_gemm.hip)
   const float* bias;    // [Mpad] one per GEMM row
   const float* scale;   // [Mpad] optional per-row affine after bias (nullptr = none)
   const float* shift;
@@ -235,6 +237,11 @@ int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_
 // HuBERT's linears on 256 x 128 tiles, two waves per SIMD (lin_gemm.hip); bit-identical to the 256 x 64 instances of launch_conv32
 bool lin128_supported(const ConvArgs& a);
 int launch_lin128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream);
+// HuBERT's stride-2, k = 3 feature convs on the same tiles (another K order: not bit-identical to launch_conv32's instance)
+bool conv2s128_shape(int Cout, int Cin, int KS, int stride, int groups);
+void pack_s2_weights128(const float* w, int Cout, int Cin, std::vector<float>& packed);
+bool conv2s128_supported(const ConvArgs& a);
+int launch_conv2s128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream);
 int conv32_tile_bn(int M);
 int conv32_cfg(int M);
 int conv32_pick_cfg(int M, int B, int Lmax_out);  // per-launch choice (steps down on small grids)
@@ -263,6 +270,7 @@ void convT_phase_weights(const float* w, int Cin, int Cout, int k, int s, int p0
 // Device-resident conv layer (conv_host.hip).
 struct DevConv {
   float* wpack = nullptr;
+  float* wpack2 = nullptr;  // conv2s128_kernel's packing of the same weights (stride-2, k = 3 layers)
   float* bias = nullptr;
   float* scale = nullptr;  // optional per-row affine applied after bias: v*scale + shift
   float* shift = nullptr;  // (eval-mode BatchNorm1d / label de-normalisation)

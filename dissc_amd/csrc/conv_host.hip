@@ -39,6 +39,11 @@ int make_conv(const float* w, const float* bias, int Cout, int Cin, int KS, int 
   dc.macs_per_t = (double)Cout * Cg * KS;
   int rc = upload(packed, &dc.wpack);
   if (rc) return rc;
+  if (dc.m32 && !dc.prec && dil == 1 && conv2s128_shape(Cout, Cin, KS, stride, groups) && opts().conv2s128) {
+    std::vector<float> p2;  // the second packing costs 4 Cout Cin KS bytes (3 MB per HuBERT feature conv)
+    pack_s2_weights128(w, Cout, Cin, p2);
+    if ((rc = upload(p2, &dc.wpack2))) return rc;
+  }
   return upload(b, &dc.bias);
 }
 
@@ -109,10 +114,11 @@ int set_affine(DevConv& dc, const float* scale, const float* shift, int n) {
 
 void free_conv(DevConv& dc) {
   if (dc.wpack) (void)hipFree(dc.wpack);
+  if (dc.wpack2) (void)hipFree(dc.wpack2);
   if (dc.bias) (void)hipFree(dc.bias);
   if (dc.scale) (void)hipFree(dc.scale);
   if (dc.shift) (void)hipFree(dc.shift);
-  dc.wpack = dc.bias = dc.scale = dc.shift = nullptr;
+  dc.wpack = dc.wpack2 = dc.bias = dc.scale = dc.shift = nullptr;
 }
 
 
@@ -121,7 +127,7 @@ int run_conv_ex(const DevConv& dc, const float* x, float* out, const float* res,
                 int epi, float mrf_div, hipStream_t stream, float out_slope, int dma_in) {
   ConvArgs a;
   a.out_slope = out_slope; a.dma_in = dma_in;
-  a.x = x; a.wpack = dc.wpack; a.bias = dc.bias; a.scale = dc.scale; a.shift = dc.shift; a.res = res;
+  a.x = x; a.wpack = dc.wpack; a.wpack2 = dc.wpack2; a.bias = dc.bias; a.scale = dc.scale; a.shift = dc.shift; a.res = res;
   a.out = out; a.acc = acc;
   a.lengths = io.lengths_in; a.len_default = io.len_default; a.len_mul = io.len_mul;
   a.lengths_out = io.lengths_out; a.olen_default = io.olen_default;

@@ -455,6 +455,7 @@ static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
 int launch_conv32(const ConvArgs& a, int B, int Lmax_out, int stride, hipStream_t stream) {
   const int span = (a.KS - 1) * a.dil;
   const int cfg = a.cfg32 >= 0 ? a.cfg32 : conv32_cfg(a.M);
+  if (stride == 2 && opts().conv2s128 && conv2s128_supported(a)) return launch_conv2s128(a, B, Lmax_out, stream);
   if (stride == 2 && span <= MAX_TAP_SPAN && a.up == 1) {
     // valid (unpadded) convs on an already-activated input: raw LDS-DMA window, nothing to mask -- every output column
     // below the utterance's output length reads inputs below its input length

@@ -581,9 +581,15 @@ int dissc_conv_s2_bench(int B, int C, int L, int form, int iters, float* ms_out)
   dc.act = 1;
   ConvIO io;
   io.len_default = L; io.olen_default = Lo;
+  float* tlbuf = nullptr;  // diagnostics (DISSC_TIMELINE): a kernel's timeline stamps, handed over as the accumulator pointer
+  const char* tlp = getenv("DISSC_TIMELINE");
+  if (tlp) {
+    DISSC_HIP_CHECK(hipMalloc((void**)&tlbuf, (size_t)4096 * 64));
+    DISSC_HIP_CHECK(hipMemset(tlbuf, 0, (size_t)4096 * 64));
+  }
   auto once = [&]() {
     return form == 1 ? run_s2tc(tc, x, y, nullptr, nullptr, L, Lo, B, ldx, ldo, Lo, nullptr)
-                     : run_conv_ex(dc, x, y, nullptr, io, B, C, ldx, ldo, Lo, 1.0f, EPI_STORE, nullptr);
+                     : run_conv_ex(dc, x, y, nullptr, tlbuf, io, B, C, ldx, ldo, Lo, 1.0f, EPI_STORE, 1.f, nullptr);
   };
   hipEvent_t e0, e1;
   DISSC_HIP_CHECK(hipEventCreate(&e0));
@@ -598,6 +604,15 @@ int dissc_conv_s2_bench(int B, int C, int L, int form, int iters, float* ms_out)
   *ms_out = ms / iters;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (tlbuf) {
+    std::vector<char> hb((size_t)4096 * 64);
+    if (hipMemcpy(hb.data(), tlbuf, hb.size(), hipMemcpyDeviceToHost) == hipSuccess)
+      if (FILE* f = fopen(tlp, "wb")) {
+        fwrite(hb.data(), 1, hb.size(), f);
+        fclose(f);
+      }
+    (void)hipFree(tlbuf);
+  }
   (void)hipFree(x); (void)hipFree(y);
   free_s2tc(tc);
   free_conv(dc);

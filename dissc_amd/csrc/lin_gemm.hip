@@ -24,6 +24,29 @@
 
 namespace dissc {
 
+// ---- hand-counted VMEM waits -------------------------------------------------------------------------------------------------
+// hipcc (ROCm 7.2) waits vmcnt(0) at the next use of ANY global load's result while an LDS-DMA is in flight, and vmcnt retires in
+// order: with compiler-issued loads a window DMA is drained by the first A fragment used after it -- one or two groups of MFMAs
+// after it was issued -- and every A fragment behind it with it (knock-outs, profiles/r06/conv2s128_ko.txt: A loads 7.3 %, DMA
+// 4.5 % of conv1).  These helpers issue the loads in inline asm, where the compiler keeps no score, and wait with exact counts:
+//   vm_load16   one global_load_dwordx4 (the result is NOT valid until a vm_wait that covers it)
+//   vm_dma16    one global_load_lds_dwordx4 (M0 = wave-uniform LDS byte address; lane l lands at + 16 l)
+//   vm_wait<N>  s_waitcnt vmcnt(N), tied to the registers it makes valid so that their readers stay behind it
+// (addresses: a wave-uniform 64-bit base in SGPRs + the lane's 32-bit byte offset -- the saddr form; the compiler's own loads carry
+// 64-bit per-lane addresses made by v_lshl_add_u64, VALU work that is paid in matrix-pipe time)
+__device__ __forceinline__ f32x4 vm_load16(const void* sbase, unsigned voff) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase));
+  return v;
+}
+__device__ __forceinline__ void vm_dma16(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait(f32x4& r0, f32x4& r1) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(N));
+}
+
 // The epilogue of one wave: rows (ms0 + mi) * 32 + 8 j + 4 h + i (register r = 4 j + i of block mi), four consecutive frames per lane.
 // Every load is issued before anything depends on it: the 32 bias values (and the affine pair) as float4s -- rows 8 j + 4 h .. + 3 are
 // adjacent in the [Mpad] arrays --, the residual four rows at a time.  (A first version loaded bias[row] inside the row loop: 32
@@ -81,27 +104,39 @@ __device__ __forceinline__ void lin128_epilogue(const ConvArgs& a, f32x16 (&acc)
   }
 }
 
-// DBG (knock-outs for the gate record, option "lin128_dbg"; results are garbage): bit 0: no A loads in the loop, 1: no window DMA,
-// 2: no B reads, 3: no epilogue, 4: no wait + barrier per stage
-template <int MI, int KCB, int WGPC, int DBG = 0>
-__global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
-  constexpr int BN = 128, NT = 256, NI = 4;
-  constexpr int CH = KCB / KC;        // 16-channel chunks per barrier
-  constexpr int ND = KCB * 32 / NT;   // DMA instructions per thread and stage (one = 16 bytes per lane = two 128-frame rows per wave)
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x [KCB][128]
-
-  int b = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
-  int ntile_g = gridDim.x, nb_g = gridDim.z;
-  if (a.stagger) {
-    // The dispatcher deals workgroup ids round-robin over the 8 XCDs and, inside an XCD, breadth-first over its 32 CUs: ids 0 .. 255
-    // take the first slot of every CU, ids 256 .. 511 the second.  Those start late, so that the two workgroups of a CU are
-    // never in their epilogues (an HBM write burst with the matrix pipe idle) or prologues at the same time; every later
-    // workgroup starts when a slot frees up and inherits the offset.
-    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (id >= 256u && id < 512u)
-      for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles
+// Stores of one wave: uniform choice of one straight-line epilogue body per (activation, residual, affine) combination -- no per-row
+// branches, no per-row dependent loads; FULL: no lane of this wave holds the partial last float4 of an utterance.
+template <int MI>
+__device__ __forceinline__ void lin128_store(const ConvArgs& a, f32x16 (&acc)[MI][4], int ms0, int h, int b, int tcol, int olen) {
+  if (tcol >= olen) return;
+  const int fl = (a.act == 1 ? 1 : 0) | (a.epi == EPI_RES ? 2 : 0) | (a.scale ? 4 : 0);
+  const size_t o0 = (size_t)b * a.o_bstride + tcol;
+  const int nv = olen - tcol;
+  const bool full = __builtin_amdgcn_ballot_w64(nv < 4) == 0;
+#define DISSC_LIN128_EPI(ACT, RES, AFF)                                                     \
+  if (full) lin128_epilogue<MI, ACT, RES, AFF, true>(a, acc, ms0, h, o0, nv);                \
+  else lin128_epilogue<MI, ACT, RES, AFF, false>(a, acc, ms0, h, o0, nv);                    \
+  break;
+  switch (fl) {
+    case 0: DISSC_LIN128_EPI(false, false, false)
+    case 1: DISSC_LIN128_EPI(true, false, false)
+    case 2: DISSC_LIN128_EPI(false, true, false)
+    case 3: DISSC_LIN128_EPI(true, true, false)
+    case 4: DISSC_LIN128_EPI(false, false, true)
+    case 5: DISSC_LIN128_EPI(true, false, true)
+    case 6: DISSC_LIN128_EPI(false, true, true)
+    default: DISSC_LIN128_EPI(true, true, true)
   }
-  if (a.xcd) {  // XCD order, as in conv_mfma32_kernel (conv_mfma32.hip has the description)
+#undef DISSC_LIN128_EPI
+}
+
+// Which tile is this workgroup's?  XCD order and ragged enumeration as in conv_mfma32_kernel (conv_mfma32.hip has the descriptions).
+// false: nothing to do.
+__device__ __forceinline__ bool tile128_of(const ConvArgs& a, int& b, int& bx, int& by) {
+  constexpr int BN = 128;
+  b = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+  int ntile_g = gridDim.x, nb_g = gridDim.z;
+  if (a.xcd) {
     const int mt = a.mt_per_group, mg = a.xcd_mg;
     const int sweep = blockIdx.x / a.xcd_span, r = blockIdx.x - sweep * a.xcd_span;
     const int s = r >> 3, sq = s / mg;
@@ -109,11 +144,11 @@ __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
     by = sweep * mg + (s - sq * mg);
     ntile_g = a.xcd_ntile;
     nb_g = a.xcd_nb;
-    if (tt >= ntile_g * nb_g || by >= mt) return;
+    if (tt >= ntile_g * nb_g || by >= mt) return false;
     b = tt / ntile_g;
     bx = tt - b * ntile_g;
   }
-  if (a.ragged_enum) {  // only the (time tile, utterance) pairs that exist, as in conv_mfma32_kernel
+  if (a.ragged_enum) {
     const int lin = b * ntile_g + bx;
     const int lane_ = threadIdx.x & 63;
     int base = 0;
@@ -140,8 +175,36 @@ __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
       }
       base += total;
     }
-    if (b < 0) return;
+    if (b < 0) return false;
   }
+  // wave-uniform by construction; say so (the ragged search's __shfl results look divergent to the compiler, and with them every
+  // address derived from the tile: 64-bit per-lane address math instead of scalar bases)
+  b = __builtin_amdgcn_readfirstlane(b);
+  bx = __builtin_amdgcn_readfirstlane(bx);
+  by = __builtin_amdgcn_readfirstlane(by);
+  return true;
+}
+
+// DBG (diagnostics, option "lin128_dbg"): bit 3: no epilogue, bit 5: timeline stamps into a.acc (the knock-outs of the first,
+// compiler-scheduled form -- A loads 5.7 %, epilogue 8 %, barrier 3 % of fc1 -- are on record in profiles/r06/lin128_gate_v3.txt)
+template <int MI, int KCB, int WGPC, int DBG = 0>
+__global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
+  constexpr int BN = 128, NT = 256, NI = 4;
+  constexpr int CH = KCB / KC;        // 16-channel chunks per barrier
+  constexpr int ND = KCB * 32 / NT;   // DMA instructions per thread and stage (one = 16 bytes per lane = two 128-frame rows per wave)
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x [KCB][128]
+
+  int b, bx, by;
+  if (a.stagger) {
+    // The dispatcher deals workgroup ids round-robin over the 8 XCDs and, inside an XCD, breadth-first over its 32 CUs: ids 0 .. 255
+    // take the first slot of every CU, ids 256 .. 511 the second.  Those start late, so that the two workgroups of a CU are
+    // never in their epilogues (an HBM write burst with the matrix pipe idle) or prologues at the same time; every later
+    // workgroup starts when a slot frees up and inherits the offset.
+    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (id >= 256u && id < 512u)
+      for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles
+  }
+  if (!tile128_of(a, b, bx, by)) return;
   unsigned long long* tl = nullptr;  // DBG bit 5: 100 MHz wall-clock stamps of wave 0 (start, loop start, loop end, stores issued) + placement
   if constexpr ((DBG & 32) != 0) {
     const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -164,19 +227,22 @@ __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
   const int nq = a.nchunk;
   const float* xb = a.x + (size_t)b * a.x_bstride;
 
-  // DMA: slot e = tid + 256 i -> channel row (tid >> 5) + 8 i of the stage, frames t0 + 4 (tid & 31) .. + 3.  Frames beyond the row
-  // are clamped into it (their columns are >= olen and never stored); nothing is masked: a 1x1 conv's column reads its own column.
-  int tcl = t0 + 4 * (tid & 31);
+  // DMA: slot e = tid + 256 i -> channel row (tid >> 5) + 8 i of the stage, frames t0 + 4 (tid & 31) .. + 3: one wave instruction moves
+  // two rows, rows 2 w + 8 i (lanes 0 .. 31) and + 1 (lanes 32 .. 63).  Frames beyond the row are clamped into it (their columns are
+  // >= olen and never stored); nothing is masked: a 1x1 conv's column reads its own column.  Every address is a wave-uniform base in
+  // SGPRs + the lane's 32-bit byte offset (vm_load16 / vm_dma16 above).
+  int tcl = t0 + 4 * l31;
   tcl = tcl > a.ldx - 4 ? a.ldx - 4 : tcl;
-  const float* src = xb + (size_t)(tid >> 5) * a.ldx + tcl;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const float* xw = xb + (size_t)(2 * wave_s) * a.ldx;
+  const unsigned vx_off = ((unsigned)h * (unsigned)a.ldx + (unsigned)tcl) * 4u;
   const size_t row8 = (size_t)8 * a.ldx;
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // scalar: the DMA's LDS address (M0) is made on the SALU
-  auto stage_dma = [&](float* buf, int s) __attribute__((always_inline)) {
-    const float* p = src + (size_t)s * KCB * a.ldx;
+  const unsigned xs_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)xs);
+  auto stage_dma = [&](int bufi, int s) __attribute__((always_inline)) {
+    const float* p = xw + (size_t)s * KCB * a.ldx;
+    const unsigned baddr = xs_addr + bufi * (KCB * BN * 4);
 #pragma unroll
-    for (int i = 0; i < ND; ++i)
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(p + i * row8),
-                                       (void __attribute__((address_space(3)))*)(buf + (i * NT + wave_s * 64) * 4), 16, 0, 0);
+    for (int i = 0; i < ND; ++i) vm_dma16(p + i * row8, vx_off, baddr + (i * NT + wave_s * 64) * 16);
   };
 
   f32x16 acc[MI][NI];
@@ -190,16 +256,23 @@ __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
   // A fragments of one 16-channel chunk: two float4 per lane and 32-row subtile ([chunk][half][lane], pack_conv_weights32); two
   // register sets take turns (chunk q in set q & 1; CH is even, so the roles are the same at every stage's start)
   static_assert(CH % 2 == 0, "two A register sets take turns over the chunks of a stage");
+  constexpr int LA = 2 * MI;  // A loads per chunk and wave
+  const unsigned lane16 = lane * 16u;
   const f32x4* wp[MI];
   f32x4 av[2][MI][2];
+  auto wait_a = [&](int set, auto cnt_tag) __attribute__((always_inline)) {
+    constexpr int CNT = decltype(cnt_tag)::value;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) vm_wait<CNT>(av[set][mi][0], av[set][mi][1]);
+  };
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)(ms0 + mi) * nq * 128 + lane;
-    av[0][mi][0] = wp[mi][0];
-    av[0][mi][1] = wp[mi][64];
+    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)(by * (MI * 4) + wave_s * MI + mi) * nq * 128;
+    av[0][mi][0] = vm_load16(wp[mi], lane16);
+    av[0][mi][1] = vm_load16(wp[mi] + 64, lane16);
   }
-  stage_dma(xs, 0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  stage_dma(0, 0);
+  wait_a(0, std::integral_constant<int, 0>{});
   __syncthreads();
 
   if constexpr ((DBG & 32) != 0) {
@@ -209,31 +282,34 @@ __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
   const int boff = h * BN + 4 * l31;
   const int nstage = a.CIN / KCB;
   f32x4 bv[8];
-  // One stage = CH chunks, fully unrolled.  Order of issue inside a chunk: the NEXT chunk's A fragments (global -> the other register
-  // set), in the stage's first chunk then the next stage's window (LDS-DMA; issued AFTER the A loads: vmcnt retires in order, so
-  // the wait for those A loads one chunk later leaves the DMA in flight -- it has two chunks = 128 MFMAs to land), then per k-step
-  // 8 MFMAs followed by the ds_read_b128 that refills this k-step's B registers with the next chunk's values (one chunk ahead,
-  // no second register set: the MFMAs that read them have been issued).  The last chunk of a stage refills nothing -- the next
-  // stage's buffer is valid after the barrier only -- and the first chunk's eight reads follow the barrier.
+  // One stage = CH chunks, fully unrolled.  Order of issue inside a chunk: the NEXT chunk's A fragments (into the other register set),
+  // in the stage's first chunk then the next stage's window (LDS-DMA), then the hand-counted wait for THIS chunk's fragments --
+  // vmcnt retires in order: what may stay in flight is the next chunk's LA loads and, in the stage's first two chunks, the ND DMA
+  // instructions issued behind this chunk's fragments (the window has two chunks = 128 MFMAs per wave to land) --, then per k-step 8
+  // MFMAs followed by the ds_read_b128 that refills this k-step's B registers with the next chunk's values (one chunk ahead, no
+  // second register set: the MFMAs that read them have been issued).  The last chunk of a stage refills nothing -- the next stage's
+  // buffer is valid after the barrier only -- and the first chunk's eight reads follow the barrier.
   auto stage = [&](int s, auto last_tag) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_tag)::value;
     const float* blk = xs + (s & 1) * (KCB * BN) + boff;
-    if (!(DBG & 4) || s == 0) {
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) bv[ks] = *reinterpret_cast<const f32x4*>(blk + ks * (2 * BN));
-    }
+    for (int ks = 0; ks < 8; ++ks) bv[ks] = *reinterpret_cast<const f32x4*>(blk + ks * (2 * BN));
 #pragma unroll
     for (int sc = 0; sc < CH; ++sc) {
       const int q = s * CH + sc;
       const int cur = sc & 1, nxt = cur ^ 1;
-      if (!(LAST && sc == CH - 1) && !(DBG & 1)) {
+      const bool pre = !(LAST && sc == CH - 1);
+      if (pre) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          av[nxt][mi][0] = wp[mi][(size_t)(q + 1) * 128];
-          av[nxt][mi][1] = wp[mi][(size_t)(q + 1) * 128 + 64];
+          av[nxt][mi][0] = vm_load16(wp[mi] + (size_t)(q + 1) * 128, lane16);
+          av[nxt][mi][1] = vm_load16(wp[mi] + (size_t)(q + 1) * 128 + 64, lane16);
         }
       }
-      if (!LAST && sc == 0 && !(DBG & 2)) stage_dma(xs + ((s + 1) & 1) * (KCB * BN), s + 1);
+      if (!LAST && sc == 0) stage_dma((s + 1) & 1, s + 1);
+      if (!LAST && sc <= 1) wait_a(cur, std::integral_constant<int, LA + ND>{});
+      else if (pre) wait_a(cur, std::integral_constant<int, LA>{});
+      else wait_a(cur, std::integral_constant<int, 0>{});
       __builtin_amdgcn_sched_barrier(0);
       const float* bnx = blk + (sc + 1) * (KC * BN);
 #pragma unroll
@@ -242,13 +318,16 @@ __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(DBG & 1) ? 0 : cur][mi][ks >> 2][ks & 3], bv[ks][ni], acc[mi][ni], 0, 0, 0);
-        if (sc + 1 < CH && !(DBG & 4)) bv[ks] = *reinterpret_cast<const f32x4*>(bnx + ks * (2 * BN));
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mi][ks >> 2][ks & 3], bv[ks][ni], acc[mi][ni], 0, 0, 0);
+        if (sc + 1 < CH) bv[ks] = *reinterpret_cast<const f32x4*>(bnx + ks * (2 * BN));
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (!LAST && !(DBG & 16)) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the next stage's window (and the next chunk's A fragments) have landed
+    if (!LAST) {
+      // every wave's DMA instructions must have landed before anyone reads the next buffer: with three or more chunks per stage
+      // the third chunk's wait has retired them (they are older than its fragments); with two, wait here -- the next chunk's
+      // fragments may stay in flight
+      if constexpr (CH <= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA) : "memory");
       __syncthreads();
     }
   };
@@ -276,30 +355,7 @@ __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
   // The epilogue (and the prologue) at raised priority: next to a wave that issues MFMAs back to back, this wave's ~500 VALU / store
   // instructions otherwise get an issue slot every 2-3 MFMAs (17-35 us instead of 3.5 alone, profiles/r06/lin128_timeline*.txt)
   if (a.stagger >= 0) __builtin_amdgcn_s_setprio(3);
-  const int tcol = t0 + 4 * l31;
-  if (tcol < olen) {
-    const int fl = (a.act == 1 ? 1 : 0) | (a.epi == EPI_RES ? 2 : 0) | (a.scale ? 4 : 0);
-    const size_t o0 = (size_t)b * a.o_bstride + tcol;
-    const int nv = olen - tcol;
-    // uniform choices: one straight-line body per combination (no per-row branches, no per-row dependent loads); FULL: no lane of
-    // this wave holds the partial last float4 of an utterance (three tiles in four at T = 499)
-    const bool full = __builtin_amdgcn_ballot_w64(nv < 4) == 0;
-#define DISSC_LIN128_EPI(ACT, RES, AFF)                                                     \
-  if (full) lin128_epilogue<MI, ACT, RES, AFF, true>(a, acc, ms0, h, o0, nv);                \
-  else lin128_epilogue<MI, ACT, RES, AFF, false>(a, acc, ms0, h, o0, nv);                    \
-  break;
-    switch (fl) {
-      case 0: DISSC_LIN128_EPI(false, false, false)
-      case 1: DISSC_LIN128_EPI(true, false, false)
-      case 2: DISSC_LIN128_EPI(false, true, false)
-      case 3: DISSC_LIN128_EPI(true, true, false)
-      case 4: DISSC_LIN128_EPI(false, false, true)
-      case 5: DISSC_LIN128_EPI(true, false, true)
-      case 6: DISSC_LIN128_EPI(false, true, true)
-      default: DISSC_LIN128_EPI(true, true, true)
-    }
-#undef DISSC_LIN128_EPI
-  }
+  lin128_store<MI>(a, acc, ms0, h, b, t0 + 4 * l31, olen);
   if constexpr ((DBG & 32) != 0) {
     if (threadIdx.x == 0) {
       tl[3] = __builtin_amdgcn_s_memrealtime();  // stores issued
@@ -353,37 +409,316 @@ static int launch_lin128_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) 
 }
 
 int launch_lin128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream) {
-  switch (opts().lin128_dbg) {  // knock-outs of the KCB = 32 form
-    case 0: case 64: break;
-    case 1: return launch_lin128_t<2, 32, 2, 1>(a, B, Lmax_out, stream);
-    case 2: return launch_lin128_t<2, 32, 2, 2>(a, B, Lmax_out, stream);
-    case 4: return launch_lin128_t<2, 32, 2, 4>(a, B, Lmax_out, stream);
-    case 8: return launch_lin128_t<2, 32, 2, 8>(a, B, Lmax_out, stream);
-    case 16: return launch_lin128_t<2, 32, 2, 16>(a, B, Lmax_out, stream);
-    case 18: return launch_lin128_t<2, 32, 2, 18>(a, B, Lmax_out, stream);
-    case 23: return launch_lin128_t<2, 32, 2, 23>(a, B, Lmax_out, stream);
-    case 31: return launch_lin128_t<2, 32, 2, 31>(a, B, Lmax_out, stream);
-    case 32: return launch_lin128_t<2, 32, 2, 32>(a, B, Lmax_out, stream);
-    default: set_error("lin128_dbg: no instance %d", opts().lin128_dbg); return DISSC_EINVAL;
-  }
+  if (opts().lin128_dbg == 32) return launch_lin128_t<2, 32, 2, 32>(a, B, Lmax_out, stream);  // timeline stamps (tools/lin128_timeline.py)
   // Tile shape per launch (option "lin128": 1 = this policy; 2 / 3 / 5 force a shape, for the gate records).  All shapes give the same
-  // bits.  A CU works its tiles off two or three at a time; what decides is how evenly the tile count divides over 256 CUs
-  // (profiles/r06/lin128_gate_v7.txt, B = 32 x T = 499, us, old kernel / 256 x 128 / 128 x 128 x3 per CU / 128 x 128 x2 per CU, 64
-  // channels per barrier: fc1 619 / 581 / 628 / 594, fc2 629 / 748 / 592 / 579, qkv 470 / 491 / 474 / 448, out_proj 182 / 198 / 164 /
-  // 192, proj 116 / 134 / 114 / 134):
-  //   256 x 128 (64-row waves: half the A traffic per MFMA) when that leaves no CU with more row-tile work than 128-row tiles would;
-  //   else 128 x 128: three workgroups per CU when a CU gets at most three tiles of a short K loop (one round, nobody alone),
-  //   else two per CU with 64 channels per barrier.
+  // bits.  With scalar-base loads and hand-counted waits (profiles/r06/lin128_gate_v8.txt; B = 32 x T = 499, us: old kernel / 256 x 128
+  // two per CU / 128 x 128 three per CU / 128 x 128 two per CU with 64 channels per barrier): fc1 618 / 617 / 558 / 550, fc2 628 / 731 /
+  // 536 / 708, qkv 468 / 503 / 419 / 453, out_proj 182 / 212 / 146 / 189, proj 116 / 143 / 100 / 125 -- 128 x 128 tiles, three
+  // workgroups per CU (three waves per SIMD, 768 slots: every HuBERT shape fills whole rounds) win everywhere but on the
+  // largest grid of short K loops, where the 64-channel stages of the two-per-CU form are 1.5 % ahead.
   int mode = opts().lin128;
   if (mode == 1) {
     const long long ct = (long long)((Lmax_out + 127) / 128) * B;  // column tiles (an upper bound for ragged batches)
-    const long long m1 = (ct * ((a.M + 127) / 128) + 255) / 256, m2 = (ct * ((a.M + 255) / 256) + 255) / 256;
-    mode = (2 * m2 <= m1) ? 2 : ((m1 <= 3 && a.CIN < 2048) ? 3 : 5);
+    const long long m1 = (ct * ((a.M + 127) / 128) + 255) / 256;   // 128-row tiles per CU
+    mode = (m1 >= 12 && a.CIN <= 1024) ? 5 : 3;
   }
   switch (mode) {
     case 2: return launch_lin128_t<2, 32, 2>(a, B, Lmax_out, stream);  // 256 x 128 tiles, two workgroups per CU
     case 3: return launch_lin128_t<1, 32, 3>(a, B, Lmax_out, stream);  // 128 x 128 tiles, three workgroups per CU
     default: return launch_lin128_t<1, 64, 2>(a, B, Lmax_out, stream); // 128 x 128 tiles, two per CU, 64 channels per barrier
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv2s128_kernel: HuBERT's stride-2, k = 3 feature convs (512 -> 512, valid, GELU; conv1 .. conv4 = 43 % of the encoder) on the
+// same 256 x 128 tiles, two workgroups per CU.  out[m][t] = sum_c sum_j W[m][c][j] x[c][2 t + j].
+//   * B operand: with column l of block ni = frame 4 l + ni, a lane's four columns of tap j read x[c][8 l + 2 ni + j]: ALL twelve B
+//     operands of one channel (3 taps x 4 blocks) are the nine consecutive floats w[0 .. 8] = x[c][8 l .. 8 l + 8] of the raw window:
+//     two ds_read_b128 + one ds_read_b32 per 24 MFMAs (the 256 x 64 kernel: 2 strided ds_read_b32 per 4), no data movement -- tap j,
+//     block ni is register w[2 ni + j].
+//   * K order: chunk (16 channels) -> channel pair -> tap (conv_mfma32_kernel: chunk -> tap -> channel pair, which would keep eight
+//     windows = 72 registers live across the taps).  Same products, same fp32 MFMA chain length, another summation order: NOT
+//     bit-identical to the 256 x 64 kernel (feature error against the float64 / HF goldens unchanged, tests/test_gpu_hubert.py).  The
+//     weights are packed for this order (pack_s2_weights128): [32-row subtile][chunk][group g][lane][4], k-step 4 g + e = 3 ks + j.
+//   * window in LDS: per channel 64 float4 = frames [2 t0, 2 t0 + 256) in a main block [KCB][256] plus ONE more float4 (the 257th
+//     float, w[8] of lane 31) in a tail block [KCB][4]: rows of a power-of-two length (DMA slot -> (row, float4) by shifts), and lane
+//     31 reads its w[8] from the tail instead of from its neighbour's w[0].
+// DBG (option "lin128_dbg", diagnostics): bit 0: no A loads in the loop, 1: no window DMA, 2: no window reads, 3: no epilogue, 4: no wait +
+// barrier per stage, 5: timeline stamps into a.acc (as lin128_kernel)
+// ASM: loads and waits through vm_load16 / vm_dma16 / vm_wait (hand-counted vmcnt); false: compiler-scheduled builtins
+template <int KCB, int WGPC, int DBG = 0, bool ASM = true>
+__global__ void __launch_bounds__(256, WGPC) conv2s128_kernel(const ConvArgs a) {
+  constexpr int BN = 128, NT = 256, MI = 2, NI = 4, KS = 3;
+  constexpr int CH = KCB / KC;          // 16-channel chunks per barrier
+  constexpr int G = KC / 2 * KS / 4;    // float4 groups of four k-steps per chunk and 32-row subtile (6)
+  constexpr int ND = KCB * 64 / NT;     // main-block DMA instructions per thread and stage
+  constexpr int STAGE_F = KCB * 256 + KCB * 4;  // floats per stage buffer (main + tail)
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x STAGE_F
+  static_assert(G == 6 && KCB % 16 == 0, "k = 3 only");
+
+  int b, bx, by;
+  if (!tile128_of(a, b, bx, by)) return;
+  unsigned long long* tl = nullptr;
+  if constexpr ((DBG & 32) != 0) {
+    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (id < 4096 && a.acc) tl = reinterpret_cast<unsigned long long*>(a.acc) + (size_t)id * 8;
+    if (tl && threadIdx.x == 0) {
+      tl[0] = __builtin_amdgcn_s_memrealtime();
+      tl[4] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      tl[1] = tl[2] = tl[3] = tl[5] = 0;
+    }
+  }
+  const int olen = a.lengths_out ? a.lengths_out[b] : a.olen_default;
+  const int t0 = bx * BN;
+  if (t0 >= olen) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int ms0 = by * (MI * 4) + wave * MI;
+  const float* xb = a.x + (size_t)b * a.x_bstride;
+  const int tin0 = 2 * t0;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+
+  // DMA, main block: slot e = tid + 256 i -> row (tid >> 6) + 4 i, float4 tid & 63; tail block: thread r < KCB moves row r's 65th float4.
+  // Positions beyond the row are clamped into it: they feed columns >= olen only (a valid conv's last output reads x[2 olen] < ldx).
+  int tm = tin0 + 4 * (tid & 63);
+  tm = tm > a.ldx - 4 ? a.ldx - 4 : tm;
+  int tt = tin0 + 256;
+  tt = tt > a.ldx - 4 ? a.ldx - 4 : tt;
+  // tail: wave w moves rows w KCB/4 .. + KCB/4 - 1 with its first KCB/4 lanes: EVERY wave issues ND + 1 DMA instructions per stage
+  // (the hand-counted waits need one count for all waves).  Addresses: wave-uniform row base + the lane's byte offset.
+  constexpr int TR = KCB / 4;
+  const float* xw = xb + (size_t)wave_s * a.ldx;            // main block: this wave's row of every group of four (uniform)
+  const unsigned vm_off = (unsigned)tm * 4u;                // ... and the lane's float4 in it
+  const float* xt = xb + (size_t)(wave_s * TR) * a.ldx + tt;  // tail block: rows wave TR + lane (lane < TR)
+  const unsigned vt_off = (unsigned)((lane < TR ? lane : 0) * a.ldx) * 4u;
+  const size_t row4 = (size_t)4 * a.ldx;
+  const unsigned xs_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)xs);
+  auto stage_dma = [&](int bufi, int s) __attribute__((always_inline)) {
+    const float* p = xw + (size_t)s * KCB * a.ldx;
+    float* buf = xs + bufi * STAGE_F;
+    const unsigned baddr = xs_addr + bufi * (STAGE_F * 4);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      if constexpr (ASM) vm_dma16(p + i * row4, vm_off, baddr + (i * NT + wave_s * 64) * 16);
+      else
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(p + i * row4 + tm),
+                                         (void __attribute__((address_space(3)))*)(buf + (i * NT + wave_s * 64) * 4), 16, 0, 0);
+    }
+    if (lane < TR) {
+      const float* q = xt + (size_t)s * KCB * a.ldx;
+      if constexpr (ASM) vm_dma16(q, vt_off, baddr + (KCB * 256 + wave_s * TR * 4) * 4);
+      else
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(reinterpret_cast<const char*>(q) + vt_off),
+                                         (void __attribute__((address_space(3)))*)(buf + KCB * 256 + wave_s * TR * 4), 16, 0, 0);
+    }
+  };
+  constexpr int D = ND + 1;  // DMA instructions per wave and stage
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  // A fragments: groups of four k-steps, THREE register sets taking turns (group g in set g % 3; G = 6), loaded two groups ahead
+  const int ngrp = a.nchunk * G;
+  const unsigned lane16 = lane * 16u;
+  const f32x4* wp[MI];
+  f32x4 av[3][MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    // wave-uniform base (SGPR pair) + the lane's 32-bit byte offset: the saddr form of global_load, no 64-bit VALU address math
+    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack2) + (size_t)(by * (MI * 4) + wave_s * MI + mi) * ngrp * 64;
+    av[0][mi] = ASM ? vm_load16(wp[mi], lane16) : *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(wp[mi]) + lane16);
+    av[1][mi] = ASM ? vm_load16(wp[mi] + 64, lane16)
+                    : *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(wp[mi] + 64) + lane16);
+  }
+  stage_dma(0, 0);
+  if constexpr (ASM) {
+    vm_wait<0>(av[0][0], av[0][1]);
+    vm_wait<0>(av[1][0], av[1][1]);
+  } else {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  }
+  __syncthreads();
+
+  if constexpr ((DBG & 32) != 0) {
+    if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
+  }
+  // per-lane LDS offsets (floats) inside a stage buffer: w[0 .. 7] at row * 256 + 8 l31; w[8] = the next lane's w[0], or (lane 31) the
+  // row's tail float4 -- two affine sequences in the channel pair with different strides
+  const int off_w = h * 256 + 8 * l31;
+  const int off_8 = l31 < 31 ? off_w + 8 : KCB * 256 + h * 4;
+  const int str_8 = l31 < 31 ? 2 * 256 : 2 * 4;
+  const int nstage = a.CIN / KCB;
+  f32x4 wa[2], wb[2];
+  float wc[2];
+  auto stage = [&](int s, auto last_tag) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const float* blk = xs + (s & 1) * STAGE_F;
+    wa[0] = *reinterpret_cast<const f32x4*>(blk + off_w);
+    wb[0] = *reinterpret_cast<const f32x4*>(blk + off_w + 4);
+    wc[0] = blk[off_8];
+#pragma unroll
+    for (int pr = 0; pr < CH * 8; ++pr) {  // channel pairs of the stage
+      const int cur = pr & 1, nxt = cur ^ 1;
+      if (pr + 1 < CH * 8 && !(DBG & 4)) {  // the next pair's window, behind this pair's 24 MFMAs
+        const float* nw = blk + (pr + 1) * (2 * 256);
+        wa[nxt] = *reinterpret_cast<const f32x4*>(nw + off_w);
+        wb[nxt] = *reinterpret_cast<const f32x4*>(nw + off_w + 4);
+        wc[nxt] = blk[off_8 + (pr + 1) * str_8];
+      }
+      const float w9[9] = {wa[cur][0], wa[cur][1], wa[cur][2], wa[cur][3], wb[cur][0], wb[cur][1], wb[cur][2], wb[cur][3], wc[cur]};
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        const int kk = pr * KS + j;            // k-step inside the stage
+        const int g = kk >> 2, e = kk & 3;     // group (of this stage) and component
+        if (e == 0) {
+          // two groups ahead into the set that group g - 1 has just released; in the stage's first group then the next stage's window
+          const int gi = s * (CH * G) + g + 2;
+          const int gl = gi < ngrp ? gi : ngrp - 1;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            if (!(DBG & 1))
+              av[(g + 2) % 3][mi] = ASM ? vm_load16(wp[mi] + (size_t)gl * 64, lane16)
+                                        : *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(wp[mi] + (size_t)gl * 64) + lane16);
+          if (!LAST && g == 0 && !(DBG & 2)) stage_dma((s + 1) & 1, s + 1);
+          if constexpr (ASM && !(DBG & 3)) {
+            // group g's fragments: younger and possibly in flight are groups g + 1, g + 2 (4 loads) and, for the groups loaded before
+            // this stage's DMA was issued (g <= 2), its D instructions: the window has three groups (96 MFMAs) to land
+            if (!LAST && g <= 2) vm_wait<4 + D>(av[g % 3][0], av[g % 3][1]);
+            else vm_wait<4>(av[g % 3][0], av[g % 3][1]);
+          } else if constexpr (ASM) {
+            vm_wait<0>(av[g % 3][0], av[g % 3][1]);  // knock-outs change the counts: drain
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g % 3][mi][e], w9[2 * ni + j], acc[mi][ni], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!LAST && !(DBG & 16)) {
+      // ASM: this wave's DMA instructions were retired by group 3's wait (they are older than that group's fragments); the barrier
+      // makes every wave's part of the window visible.  Compiler-scheduled form: vmcnt(0) here.
+      if constexpr (!ASM) __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
+  };
+  static_assert(CH * G >= 4, "the DMA is retired by the wait of the stage's fourth group");
+  static_assert((CH * G) % 3 == 0, "the A register sets must be in the same roles at every stage's start");
+#pragma unroll 1
+  for (int s = 0; s + 1 < nstage; ++s) stage(s, std::false_type{});
+  stage(nstage - 1, std::true_type{});
+  if constexpr (ASM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped prefetches beyond the last group
+  if constexpr ((DBG & 32) != 0) {
+    if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (DBG & 8) {
+    float sum = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += acc[mi][ni][e];
+    if (sum == 12345.678f) a.out[0] = sum;
+    return;
+  }
+  lin128_store<MI>(a, acc, ms0, h, b, t0 + 4 * l31, olen);
+  if constexpr ((DBG & 32) != 0) {
+    if (tl && threadIdx.x == 0) {
+      tl[3] = __builtin_amdgcn_s_memrealtime();
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      tl[5] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+}
+
+// w: [Cout][Cin][3] -> [32-row subtile][chunk][group g][lane][4]: lane l, component e of group g = k-step kk = 4 g + e of the chunk =
+// (channel pair ks = kk / 3, tap j = kk % 3) -> W[32 ms + (l & 31)][16 c + 2 ks + (l >> 5)][j]
+void pack_s2_weights128(const float* w, int Cout, int Cin, std::vector<float>& packed) {
+  const int nsub = Cout / 32, nchunk = Cin / KC, G = 6;
+  packed.assign((size_t)nsub * nchunk * G * 64 * 4, 0.f);
+  for (int ms = 0; ms < nsub; ++ms)
+    for (int c = 0; c < nchunk; ++c)
+      for (int g = 0; g < G; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 4; ++e) {
+            const int kk = 4 * g + e, ks = kk / 3, j = kk % 3;
+            const int co = ms * 32 + (lane & 31), ci = c * KC + 2 * ks + (lane >> 5);
+            packed[((((size_t)ms * nchunk + c) * G + g) * 64 + lane) * 4 + e] = w[((size_t)co * Cin + ci) * 3 + j];
+          }
+}
+
+bool conv2s128_shape(int Cout, int Cin, int KS, int stride, int groups) {
+  return stride == 2 && KS == 3 && groups == 1 && Cout % 256 == 0 && Cin % 32 == 0;
+}
+
+// option "conv2s128" (Options::conv2s128, default 1): stride-2 k = 3 convs on conv2s128_kernel (0: conv_mfma32_kernel; 2: 32 channels per barrier)
+bool conv2s128_supported(const ConvArgs& a) {
+  return a.wpack2 && a.KS == 3 && a.dil == 1 && a.groups == 1 && a.up == 1 && a.slope == 1.0f && a.pad_left == 0 && a.prec == 0 &&
+         a.epi == EPI_STORE && a.M % 256 == 0 && a.CIN % 32 == 0 && a.ldx >= 4 && a.ldx % 4 == 0 && a.ldo % 4 == 0 &&
+         (a.lengths_out || a.olen_default >= 0);
+}
+
+template <int KCB, int WGPC, int DBG = 0, bool ASM = true>
+static int launch_conv2s128_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
+  constexpr int BM = 256, BN = 128;
+  a.mt_per_group = a.M / BM;
+  dim3 grid((Lmax_out + BN - 1) / BN, a.mt_per_group, B);
+  a.mfast = 0;
+  a.stagger = 0;
+  a.ragged_enum = (opts().ragged_enum && a.lengths_out && B > 1) ? 1 : 0;
+  const int mt = a.mt_per_group;
+  const long long tt_pad = ((long long)grid.x * B + 7) / 8 * 8;
+  a.xcd = ((opts().xcd_order & 2) && mt >= 2) ? 1 : 0;
+  if (a.xcd) {
+    const double slab = (double)BM * a.CIN * a.KS * sizeof(float);
+    int mg = (int)(3.2 * 1024 * 1024 / slab);
+    if (mg < 2 || mg > mt) mg = mt;
+    while (mt % mg) --mg;
+    if (opts().xcd_mg > 0) mg = opts().xcd_mg < mt ? opts().xcd_mg : mt;
+    if (tt_pad * mg * ((mt + mg - 1) / mg) > 0x7fffffffLL) {
+      a.xcd = 0;
+    } else {
+      a.xcd_ntile = (int)grid.x;
+      a.xcd_nb = B;
+      a.xcd_mg = mg;
+      a.xcd_span = (int)(tt_pad * mg);
+      grid = dim3((unsigned)(tt_pad * mg * ((mt + mg - 1) / mg)), 1, 1);
+    }
+  }
+  const size_t lds = (size_t)2 * (KCB * 256 + KCB * 4) * sizeof(float);
+  static DeviceOnce attr_once;
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&conv2s128_kernel<KCB, WGPC, DBG, ASM>), 160 * 1024));
+  hipLaunchKernelGGL((conv2s128_kernel<KCB, WGPC, DBG, ASM>), grid, dim3(256), lds, stream, a);
+  DISSC_HIP_CHECK(hipGetLastError());
+  return DISSC_OK;
+}
+
+int launch_conv2s128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream) {
+  switch (opts().lin128_dbg) {
+    case 1: return launch_conv2s128_t<32, 2, 1>(a, B, Lmax_out, stream);
+    case 2: return launch_conv2s128_t<32, 2, 2>(a, B, Lmax_out, stream);
+    case 4: return launch_conv2s128_t<32, 2, 4>(a, B, Lmax_out, stream);
+    case 8: return launch_conv2s128_t<32, 2, 8>(a, B, Lmax_out, stream);
+    case 16: return launch_conv2s128_t<32, 2, 16>(a, B, Lmax_out, stream);
+    case 23: return launch_conv2s128_t<32, 2, 23>(a, B, Lmax_out, stream);
+    case 31: return launch_conv2s128_t<32, 2, 31>(a, B, Lmax_out, stream);
+    case 32: return launch_conv2s128_t<32, 2, 32>(a, B, Lmax_out, stream);
+    default: break;
+  }
+  switch (opts().conv2s128) {
+    case 2: return launch_conv2s128_t<32, 2, 0, false>(a, B, Lmax_out, stream);  // compiler-scheduled loads (the gate's reference)
+    case 3: return launch_conv2s128_t<16, 2, 0, true>(a, B, Lmax_out, stream);
+    default: return launch_conv2s128_t<32, 2, 0, true>(a, B, Lmax_out, stream);
   }
 }
 
