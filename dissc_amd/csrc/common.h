@@ -161,6 +161,26 @@ __device__ __forceinline__ float erf_1ulp(float a) {
 }
 #endif
 
+#ifdef __HIPCC__
+// Packed-weight (A fragment) loads through a buffer descriptor: a wave-uniform base in four SGPRs + the lane's 32-bit byte offset
+// (+ a scalar byte offset for the walk over blocks).  The plain `wp[block * 64]` form on a per-lane 64-bit pointer costs one
+// v_lshl_add_u64 per load and a VGPR-pair address: vector-ALU work that is paid in matrix-pipe time on this part, next to every
+// MFMA group (round 6: conv1 6.24 -> 5.70 ms, fc1 618 -> 550 us with scalar-base loads; profiles/r06).  The compiler counts these
+// loads like plain ones (its s_waitcnt vmcnt bookkeeping stays exact).  `base` and `bytes` must be PROVABLY wave-uniform (kernel
+// arguments, blockIdx, readfirstlane results): a descriptor the compiler believes divergent becomes a waterfall loop per load.
+typedef unsigned dissc_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(const void* base, unsigned bytes) {
+  // uniformity made explicit (readfirstlane of the descriptor's inputs): whatever the compiler believes about `base`
+  const unsigned long long pa = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pa), hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ f32x4 rsrc_load16(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned scalar_bytes) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_bytes, (int)scalar_bytes, 0));
+}
+#endif
+
 // Channels staged per LDS chunk of the implicit-GEMM conv (= 4 MFMA k-steps of 4).
 constexpr int KC = 16;
 

@@ -111,14 +111,14 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const f32x4* wp[MI];
   f32x4 av[MI], avn[MI];
+  // scalar-base loads (common.h: wave_rsrc): this wave's MI subtiles are one contiguous slab [mi][block][lane]
+  const int slab = __builtin_amdgcn_readfirstlane(grp * a.nsub_group + ms0);
+  const __amdgpu_buffer_rsrc_t wrs = wave_rsrc(reinterpret_cast<const f32x4*>(a.wpack) + (size_t)slab * nq * 64, (unsigned)(MI * nq) * 1024u);
+  const unsigned lane16 = lane * 16u;
+  auto a_load = [&](int mi, int bl) __attribute__((always_inline)) { return rsrc_load16(wrs, lane16, (unsigned)(mi * nq + bl) * 1024u); };
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) +
-             ((size_t)grp * a.nsub_group + ms0 + mi) * nq * 64 + lane;
-    av[mi] = wp[mi][0];
-  }
+  for (int mi = 0; mi < MI; ++mi) av[mi] = a_load(mi, 0);
 
   stage_load(0);
   stage_store(xs, 0);
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvAr
       for (int j = 0; j < a.KS; ++j, ++q) {
         const int qn = (q + 1 < nq) ? q + 1 : q;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][(size_t)qn * 64];
+        for (int mi = 0; mi < MI; ++mi) avn[mi] = a_load(mi, qn);
         if (j == 0 && sc == 0 && more) stage_load(cb + 1);  // in flight behind this block's MFMAs
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetches ahead of the MFMAs
 #pragma unroll

@@ -204,14 +204,18 @@ __global__ void __launch_bounds__(64 * WM * WN, DMA ? DISSC_LB32_DMA : DISSC_LB3
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
   // A fragments: 8 k-steps (16 channels) of one tap = two float4 per lane: [q][half][lane]
-  const f32x4* wp[MI];
   f32x4 av[MI][2], avn[MI][2];
+  // scalar-base loads (common.h: wave_rsrc): this wave's MI subtiles are one contiguous slab [mi][block][half][lane]
+  const int slab = __builtin_amdgcn_readfirstlane(grp * a.nsub_group + ms0);
+  const __amdgpu_buffer_rsrc_t wrs = wave_rsrc(reinterpret_cast<const f32x4*>(a.wpack) + (size_t)slab * nq * 128, (unsigned)(MI * nq) * 2048u);
+  const unsigned lane16 = lane * 16u;
+  auto a_load = [&](int mi, int bl, int hf) __attribute__((always_inline)) {
+    return rsrc_load16(wrs, lane16, (unsigned)((mi * nq + bl) * 2 + hf) * 1024u);
+  };
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) +
-             ((size_t)grp * a.nsub_group + ms0 + mi) * nq * 128 + lane;
-    av[mi][0] = wp[mi][0];
-    av[mi][1] = wp[mi][64];
+    av[mi][0] = a_load(mi, 0, 0);
+    av[mi][1] = a_load(mi, 0, 1);
   }
 
   if constexpr (DMA) {
@@ -252,8 +256,8 @@ __global__ void __launch_bounds__(64 * WM * WN, DMA ? DISSC_LB32_DMA : DISSC_LB3
           const int qn = (q + 1 < nq) ? q + 1 : q;
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
-            avn[mi][0] = wp[mi][(size_t)qn * 128];
-            avn[mi][1] = wp[mi][(size_t)qn * 128 + 64];
+            avn[mi][0] = a_load(mi, qn, 0);
+            avn[mi][1] = a_load(mi, qn, 1);
           }
           if (j == 0 && sc == 0 && more) {  // in flight behind this block's MFMAs
             if constexpr (DMA) stage_dma(xs + ((cb + 1) & 1) * (KCB * XW), cb + 1);

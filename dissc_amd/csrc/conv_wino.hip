@@ -248,13 +248,14 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
   // the loop walks them: [point][32-row subtile][block][lane] -- one pointer step per tap
   const int nsub = a.C / 32;
   const int nblk = a.nchunk * NS * 2;
-  const f32x4* wp[MI];
   f32x4 av[MI], avn[MI];
+  // scalar-base loads (common.h: wave_rsrc): this wave's MI subtiles are one contiguous slab [mi][block][lane]
+  const int slab = __builtin_amdgcn_readfirstlane(p * nsub + mt * (MI * RH) + mh * MI);
+  const __amdgpu_buffer_rsrc_t wrs = wave_rsrc(reinterpret_cast<const f32x4*>(a.wpack) + (size_t)slab * nblk * 64, (unsigned)(MI * nblk) * 1024u);
+  const unsigned lane16 = lane * 16u;
+  auto a_load = [&](int mi, int bl) __attribute__((always_inline)) { return rsrc_load16(wrs, lane16, (unsigned)(mi * nblk + bl) * 1024u); };
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-    wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * (MI * RH) + mh * MI + mi) * nblk * 64 + lane;
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) av[mi] = wp[mi][0];
+  for (int mi = 0; mi < MI; ++mi) av[mi] = a_load(mi, 0);
   stage_load(0);
   stage_store(lds);
   if (nround > 1) stage_load(1);  // the staging registers always hold the round after the newest one in LDS
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(768, DISSC_WINO_LB) conv_wino_kernel(const Win
         for (int j = 0; j < NS; ++j, ++blk) {
           const int bn = (blk + 1 < nblk) ? blk + 1 : nblk - 1;
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][(size_t)bn * 64];
+          for (int mi = 0; mi < MI; ++mi) avn[mi] = a_load(mi, bn);
 #pragma unroll
           for (int s = 1; s < 4; ++s)
 #pragma unroll

@@ -323,13 +323,25 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
   // loop walks them: [point][32-row subtile][block][lane]
   const int nsub = a.C / 32;
   const int nblk = a.nchunk * NS * 2;
-  const f32x4* wp[MI];
   f32x4 av[MI], avn[MI];
+#ifndef DISSC_WINO8_BUF
+#define DISSC_WINO8_BUF 1
+#endif
+#if DISSC_WINO8_BUF
+  // scalar-base loads (common.h: wave_rsrc): this wave's MI subtiles are one contiguous slab [mi][block][lane]
+  const __amdgpu_buffer_rsrc_t wrs = wave_rsrc(reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * MI) * nblk * 64,
+                                               (unsigned)(MI * nblk) * 1024u);
+  const unsigned lane16 = lane * 16u;
+  auto a_load = [&](int mi, int bl) __attribute__((always_inline)) { return rsrc_load16(wrs, lane16, (unsigned)(mi * nblk + bl) * 1024u); };
+#else
+  const f32x4* wp[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
     wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * MI + mi) * nblk * 64 + lane;
+  auto a_load = [&](int mi, int bl) __attribute__((always_inline)) { return wp[mi][(size_t)bl * 64]; };
+#endif
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) av[mi] = wp[mi][0];
+  for (int mi = 0; mi < MI; ++mi) av[mi] = a_load(mi, 0);
   stage_load(0);
   stage_store(lds);
   if (nround > 1) stage_load(1);
@@ -348,7 +360,7 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
     for (int j = 0; j < NS; ++j, ++blk) {
       const int bn = (blk + 1 < nblk) ? blk + 1 : nblk - 1;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) avn[mi] = wp[mi][(size_t)bn * 64];
+      for (int mi = 0; mi < MI; ++mi) avn[mi] = a_load(mi, bn);
       float bk[4][NI];
 #pragma unroll
       for (int s = 0; s < 4; ++s)

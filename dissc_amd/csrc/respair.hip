@@ -148,9 +148,9 @@ __global__ void __launch_bounds__(256) respair16_kernel(const PairArgs a) {
 
   f32x4 wa[KS];
   {
-    const f32x4* w1p = reinterpret_cast<const f32x4*>(a.w1) + lane;
+    const __amdgpu_buffer_rsrc_t w1r = wave_rsrc(a.w1, 0x7ffffff0u);  // scalar-base loads (common.h)
 #pragma unroll
-    for (int j = 0; j < KS; ++j) wa[j] = w1p[j * 64];
+    for (int j = 0; j < KS; ++j) wa[j] = rsrc_load16(w1r, lane * 16u, j * 1024u);
   }
   const f32x4 bias1 = *reinterpret_cast<const f32x4*>(a.b1 + 4 * g);
 
@@ -204,9 +204,9 @@ __global__ void __launch_bounds__(256) respair16_kernel(const PairArgs a) {
   // conv_1's weights take over the registers of conv_d's: fetched behind its last MFMAs / the barrier
   f32x4 wb[KS];
   {
-    const f32x4* w2p = reinterpret_cast<const f32x4*>(a.w2) + lane;
+    const __amdgpu_buffer_rsrc_t w2r = wave_rsrc(a.w2, 0x7ffffff0u);
 #pragma unroll
-    for (int j = 0; j < KS; ++j) wb[j] = w2p[j * 64];
+    for (int j = 0; j < KS; ++j) wb[j] = rsrc_load16(w2r, lane * 16u, j * 1024u);
   }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -304,13 +304,14 @@ __global__ void __launch_bounds__(256) respair32_kernel(const PairArgs a) {
   const int tb = tin0 & ~3, sh = tin0 - tb;
   const float slope = a.slope;
   const float* xb = a.x + (size_t)b * a.bstride;
-  const f32x4* w1p = reinterpret_cast<const f32x4*>(a.w1) + lane;
-  const f32x4* w2p = reinterpret_cast<const f32x4*>(a.w2) + lane;
+  // scalar-base loads (common.h: wave_rsrc): the weights are the same for every wave, offsets are compile-time constants
+  const __amdgpu_buffer_rsrc_t w1p = wave_rsrc(a.w1, 0x7ffffff0u), w2p = wave_rsrc(a.w2, 0x7ffffff0u);
+  const unsigned lane16 = lane * 16u;
   // step q = c*KS + j (chunk outer, tap inner: the order of conv_mfma32_kernel) = 8 k-steps = 2 float4:
   // wp[(q*2 + hf)*64]
   f32x4 av[2], avn[2];
-  av[0] = w1p[0];
-  av[1] = w1p[64];
+  av[0] = rsrc_load16(w1p, lane16, 0);
+  av[1] = rsrc_load16(w1p, lane16, 1024u);
 
   {
     int rr = tid / NV, vv = tid - (tid / NV) * NV;
@@ -355,11 +356,11 @@ __global__ void __launch_bounds__(256) respair32_kernel(const PairArgs a) {
 #define DISSC_PAIR32_TAPS(WP, BASE, XW, STEP, NEXT_WP)                                                     \
   _Pragma("unroll") for (int q = 0; q < 2 * KS; ++q) {                                                     \
     if (q + 1 < 2 * KS) {                                                                                  \
-      avn[0] = WP[((q + 1) * 2 + 0) * 64];                                                                 \
-      avn[1] = WP[((q + 1) * 2 + 1) * 64];                                                                 \
+      avn[0] = rsrc_load16(WP, lane16, ((q + 1) * 2 + 0) * 1024u);                                         \
+      avn[1] = rsrc_load16(WP, lane16, ((q + 1) * 2 + 1) * 1024u);                                         \
     } else {                                                                                               \
-      avn[0] = NEXT_WP[0];                                                                                 \
-      avn[1] = NEXT_WP[64];                                                                                \
+      avn[0] = rsrc_load16(NEXT_WP, lane16, 0);                                                            \
+      avn[1] = rsrc_load16(NEXT_WP, lane16, 1024u);                                                        \
     }                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                     \
     _Pragma("unroll") for (int hf = 0; hf < 2; ++hf)                                                       \

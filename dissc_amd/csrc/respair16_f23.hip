@@ -92,12 +92,12 @@ __global__ void __launch_bounds__(256, 3) respair16_f23_kernel(const PairFArgs a
   // one conv: 4 sub-filters x 4 k-steps x 4 column tiles x 4 points = 256 MFMAs fed by 256 fragment reads and 256 additions;
   // the conv's 16 weight fragments [sub-filter][point] (one float4 = the 4 k-steps) stay in registers
   auto taps = [&](const float* wq, const float* src, const int (&base)[NI], int off0, int dstep, int dunit) __attribute__((always_inline)) {
-    const f32x4* wp = reinterpret_cast<const f32x4*>(wq) + lane;
+    const __amdgpu_buffer_rsrc_t wr = wave_rsrc(wq, 0x7ffffff0u);  // scalar-base loads (common.h), constant offsets
     f32x4 u[NS][4];
 #pragma unroll
     for (int j = 0; j < NS; ++j)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) u[j][p] = wp[(j * 4 + p) * 64];
+      for (int p = 0; p < 4; ++p) u[j][p] = rsrc_load16(wr, lane * 16u, (j * 4 + p) * 1024u);
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
 #pragma unroll

@@ -113,20 +113,21 @@ __global__ void __launch_bounds__(256, 2) respair32_f23_kernel(const PairFArgs a
   // one conv: chunks of 16 channels x 4 sub-filters; per (chunk, sub-filter) 8 k-steps x 2 column tiles x 4 points = 64 MFMAs fed
   // by 64 fragment reads and 64 additions
   auto taps = [&](const float* wq, const float* src, const int (&base)[2], int off0, int dstep, int dunit) __attribute__((always_inline)) {
-    const f32x4* wp = reinterpret_cast<const f32x4*>(wq) + lane;
+    const __amdgpu_buffer_rsrc_t wr = wave_rsrc(wq, 0x7ffffff0u);  // scalar-base loads (common.h), constant offsets
+    const unsigned lane16 = lane * 16u;
     f32x4 av[4][2], avn[4][2];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      av[p][0] = wp[(p * 2 + 0) * 64];
-      av[p][1] = wp[(p * 2 + 1) * 64];
+      av[p][0] = rsrc_load16(wr, lane16, (p * 2 + 0) * 1024u);
+      av[p][1] = rsrc_load16(wr, lane16, (p * 2 + 1) * 1024u);
     }
 #pragma unroll
     for (int s = 0; s < 2 * NS; ++s) {  // s = chunk * NS + sub-filter
       const int sn = s + 1 < 2 * NS ? s + 1 : s;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        avn[p][0] = wp[((sn * 4 + p) * 2 + 0) * 64];
-        avn[p][1] = wp[((sn * 4 + p) * 2 + 1) * 64];
+        avn[p][0] = rsrc_load16(wr, lane16, ((sn * 4 + p) * 2 + 0) * 1024u);
+        avn[p][1] = rsrc_load16(wr, lane16, ((sn * 4 + p) * 2 + 1) * 1024u);
       }
       __builtin_amdgcn_sched_barrier(0);
       const int chunk = s / NS, j = s % NS;
