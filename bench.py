@@ -58,7 +58,7 @@ PARITY_TOL_REL = 1e-3   # ... and <= 1e-3 of the reference waveform's RMS
 PARITY_GUARD_RMS = 2e-6  # regression guard of the exact-fp32 path (<= 10x the measured 4e-7 ... 6e-7, below split-bf16's ~4e-6;
                          # the same figure as tests/test_gpu_generator.py FP32_GUARD_RMS): beyond it the run exits 3 like a miss
                          # of the bar -- a noisier kernel must be a decision, not an accident
-SCHEMA = 5              # bench line layout version (round number of the last change of workloads / fields)
+SCHEMA = 6              # bench line layout version (round number of the last change of workloads / fields)
 
 
 def parity_vs(ref_waves, y_host):
@@ -535,6 +535,34 @@ def strong_leg(synth, g, dev, rank, world, dist, fake=False, reps=3):
     return out
 
 
+def latency_leg(synth, g, dev, frames=(100, 500), reps=50):
+    """The reference's own operating point (B = 1, one utterance at a time: sr/inference.py:67-76,178; infer.py:24-45): latency of
+    one generator forward, T in `frames`, the median of `reps` forwards timed one by one (HIP events) after the main loop has warmed
+    the chip up -- 20-launch cold runs read 10 % slow.  Small grids step down to smaller tiles with the same bits (conv32_pick_cfg,
+    launch_wino_t, run_wino8: DISSC_W8_SMALL), so these waveforms are bitwise the B = 32 ones."""
+    out = {}
+    for T in frames:
+        code, f0, spkr, _ = synth.synth_generator_inputs(1, T, seed=1234)
+        c, f, s = (torch.from_numpy(v).to(dev) for v in (code, f0, spkr))
+        for _ in range(10):
+            g(code=c, f0=f, spkr=s)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g(code=c, f0=f, spkr=s)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        med = ts[len(ts) // 2]
+        out[f"T{T}"] = {"ms": round(med, 3), "p10_ms": round(ts[len(ts) // 10], 3), "p90_ms": round(ts[(9 * len(ts)) // 10], 3),
+                        "x_realtime": round(T * 0.02 / med * 1e3, 1), "tflops_algorithmic": round(g.flops(T) / med / 1e9, 1)}
+    out["note"] = f"B = 1, median of {reps} forwards timed one at a time (launch + kernels, inputs resident), exact fp32"
+    return out
+
+
 def split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y_fp32, steps, audio_sec_per_step, flops_step):
     """The opt-in split-bf16 ("bf16x3") arithmetic mode of the same generator, timed on the same
     batch right after the fp32 run and checked against the fp32 waveform (north_star bar: 1e-4 RMS).
@@ -616,6 +644,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the full-pipeline leg (N=1 only)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (fixed 1 024-job list)")
     ap.add_argument("--no-d2h", action="store_true", help="skip the D2H-inclusive figure (N=1 only)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 latency leg (N=1 only)")
     ap.add_argument("--strong-only", action="store_true",
                     help="only the strong-scaling leg (tools/strong_rehearsal.py): prints {'strong': ...} and exits")
     a = ap.parse_args()
@@ -801,6 +830,11 @@ def main():
                 out["d2h_inclusive"] = d2h_leg(g, d_code, d_f0, d_spkr, a.steps, audio_sec_per_step)
             except Exception as e:  # noqa: BLE001
                 out["d2h_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
+        if n_gpus == 1 and not fake and not a.no_latency:
+            try:
+                out["latency"] = latency_leg(synth, g, dev)
+            except Exception as e:  # noqa: BLE001
+                out["latency"] = {"error": f"{type(e).__name__}: {e}"}
         if not a.no_split_bf16 and n_gpus == 1 and not fake:
             try:
                 out["split_bf16"] = split_bf16_leg(synth, sd, dev, d_code, d_f0, d_spkr, y, a.steps,

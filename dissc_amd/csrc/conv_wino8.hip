@@ -678,9 +678,17 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
   // F(5,4) -- on 64 x 64 tiles built for two workgroups per CU (4 = the round's earlier policy: k = 7 wide in both forms)
   const int c64_mode = opts().wino8_c64_wide == 3 ? ((dc.KS == 7 && R == 3) ? 1 : 2) : opts().wino8_c64_wide == 4 ? (dc.KS == 7 ? 1 : 2) : opts().wino8_c64_wide;
   // wave tile = workgroup tile: 128 rows x 64 columns for C >= 128, 64 x 128 ("wino8_c64_wide", default) or 64 x 64 for C = 64
+  // Small grids (a short or single utterance: the reference's one-at-a-time mode): the 128-row tiles of C >= 128 give a 10 s utterance
+  // 16-32 workgroups on 256 CUs, each walking the whole K loop (B = 1: 240 us per k = 11 launch of the first stage); below one
+  // workgroup per two CUs the launch steps down to 64-row tiles on two workgroups per CU.  Same column tiles (NI), so the same unit
+  // grid and the same MFMA and transform sequence per output: bit-identical, an utterance's samples stay independent of its batch.
+#define DISSC_W8_SMALL(R_, NS_, D_)                                                                  \
+  (opts().small_grid &&                                                                              \
+   (long long)((Lmax + Wino8Geo<NS_, D_, 4, 2, 2, R_>::OT - 1) / Wino8Geo<NS_, D_, 4, 2, 2, R_>::OT) * (dc.M / 128) * B < 128)
 #define DISSC_W8(R_, NS_, D_)                                                                        \
   if (R == R_ && ns == NS_ && dc.dil == D_)                                                          \
-    return dc.M >= 128 ? launch_wino8_t<NS_, D_, 4, 2, 2, R_>(a, B, Lmax, stream)                   \
+    return dc.M >= 128 ? (DISSC_W8_SMALL(R_, NS_, D_) ? launch_wino8_t<NS_, D_, 2, 2, 4, R_>(a, B, Lmax, stream)  \
+                                                      : launch_wino8_t<NS_, D_, 4, 2, 2, R_>(a, B, Lmax, stream)) \
                        : (c64_mode == 1 ? launch_wino8_t<NS_, D_, 2, 4, 2, R_>(a, B, Lmax, stream)  \
                           : c64_mode == 2 ? launch_wino8_t<NS_, D_, 2, 2, 4, R_>(a, B, Lmax, stream) \
                                           : launch_wino8_t<NS_, D_, 2, 2, 2, R_>(a, B, Lmax, stream));
@@ -697,6 +705,7 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
   DISSC_W8(3, 4, 1) DISSC_W8(3, 4, 3) DISSC_W8(3, 4, 5)
   DISSC_W8(4, 2, 1) DISSC_W8(4, 2, 3) DISSC_W8(4, 2, 5) DISSC_W8(4, 3, 1) DISSC_W8(4, 3, 3) DISSC_W8(4, 3, 5)
 #undef DISSC_W8
+#undef DISSC_W8_SMALL
   set_error("run_wino8: k = %d, dilation %d unsupported", dc.KS, dc.dil);
   return DISSC_EINVAL;
 }
