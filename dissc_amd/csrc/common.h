@@ -28,61 +28,71 @@ void set_error(const char* fmt, ...);
 // OptScope of that snapshot, so a forward never reads process-wide state ("re-entrant per handle, no global state"):
 // two handles created under different options keep their own behaviour whatever is set in between.  Code without a handle (the
 // stand-alone test / bench entries) sees the defaults.  X(field, default, "key of dissc_set_option").
-#define DISSC_OPTION_LIST(X) \
+#define DISSC_OPTION_LIST_DEFAULT(X) \
   X(multistream, 1, "multistream") \
-  X(stream_prio, 1, "stream_prio") \
-  X(par_ups, 1, "par_ups") \
-  X(graphs, 0, "graphs") \
-  X(graph_frames, 2048, "graph_frames") \
   X(pair_dma, 1, "pair_dma") \
   X(precision, 0, "precision") \
   X(use_mfma32, 1, "mfma32") \
   X(ragged_enum, 1, "ragged_enum") \
-  X(pos48, 1, "pos48") \
-  X(lin_tile, 2, "lin_tile") \
-  X(cpb2, 0, "cpb2") \
-  X(lin_dma, 1, "lin_dma") \
   X(lin128, 1, "lin128") \
-  X(lin128_dbg, 0, "lin128_dbg") \
   X(conv2s128, 1, "conv2s128") \
-  X(lin128_stagger, 0, "lin128_stagger") \
-  X(conv_pad_lds, 0, "conv_pad_lds") \
-  X(c64_wide, 1, "c64_wide") \
-  X(conv2_dma, 1, "conv2_dma") \
-  X(mfast, 0, "mfast") \
   X(xcd_order, 3, "xcd_order") \
   X(xcd_mg, 0, "xcd_mg") \
   X(small_grid, 1, "small_grid") \
-  X(enc_tc, 0, "enc_tc") \
-  X(s2tc_xmode, 0, "s2tc_xmode") \
-  X(s2tc_dbg, 0, "s2tc_dbg") \
-  X(wino_min_c, 64, "wino_min_c") \
-  X(wino_c64_kmin, 3, "wino_c64_kmin") \
-  X(wino_small, 96, "wino_small") \
-  X(wino_dbg, 0, "wino_dbg") \
-  X(wino_cpr, 32, "wino_cpr") \
+  X(kernel_dbg, 0, "kernel_dbg") \
   X(wino_sv, 1, "wino_sv") \
-  X(wino8_dbg, 0, "wino8_dbg") \
   X(wino8_c64_wide, 3, "wino8_c64_wide") \
   X(wino8_mask, 0770770771, "wino8_mask") \
   X(wino8_r4_mask, 0770770010, "wino8_r4_mask") \
   X(wino8_r4, 1, "wino8_r4") \
   X(wino8, 1, "wino8") \
   X(wino, 1, "wino") \
-  X(attn_fused, 1, "attn_fused") \
   X(hubert_split, 1, "hubert_split") \
-  X(bf3_variant, 0, "fused_variant") \
-  X(bf3_pairs, -1, "bf3_pairs") \
-  X(pair_lds_mode, 1, "pair_lds") \
-  X(pair_pad_lds, 0, "pair_pad_lds") \
   X(pair_max_c, 32, "pair_max_c") \
-  X(pair_f23, 3, "pair_f23") \
+  X(pair_f23, 3, "pair_f23")
+// options of the kernels that only DISSC_EXPERIMENTAL=1 builds carry (experimental/csrc: gates failed, kept for the record)
+#define DISSC_OPTION_LIST_EXPERIMENTAL(X) \
+  X(graphs, 0, "graphs") \
+  X(graph_frames, 2048, "graph_frames") \
+  X(enc_tc, 0, "enc_tc") \
+  X(s2tc_xmode, 0, "s2tc_xmode") \
   X(pair_wino, 0, "pair_wino") \
   X(pairw_chv, 2, "pairw_chv")
+#if DISSC_EXPERIMENTAL
+#define DISSC_OPTION_LIST(X) DISSC_OPTION_LIST_DEFAULT(X) DISSC_OPTION_LIST_EXPERIMENTAL(X)
+#else
+#define DISSC_OPTION_LIST(X) DISSC_OPTION_LIST_DEFAULT(X)
+#endif
 struct Options {
 #define DISSC_OPT_FIELD(f, d, k) int f = d;
   DISSC_OPTION_LIST(DISSC_OPT_FIELD)
 #undef DISSC_OPT_FIELD
+#if !DISSC_EXPERIMENTAL
+#define DISSC_OPT_CONST(f, d, k) static constexpr int f = d;
+  DISSC_OPTION_LIST_EXPERIMENTAL(DISSC_OPT_CONST)
+#undef DISSC_OPT_CONST
+#endif
+  // Settled choices that were run-time options through round 5 (every one measured, the records are under profiles/): constants now,
+  // so that code paths stay readable where they are used (`opts().x`) without being part of the tuning surface.
+  static constexpr int stream_prio = 1;  // generator streams of the k = 7 / 11 chains at higher priority
+  static constexpr int par_ups = 1;  // the phase groups of a ConvTranspose on parallel streams
+  static constexpr int pos48 = 1;  // HuBERT's positional conv (48 rows per group) as three 16-row tiles of the 16x16x4 kernel
+  static constexpr int lin_tile = 2;  // channels per barrier / 16 of the register-staged 1x1 convs
+  static constexpr int cpb2 = 0;  // two chunks per barrier for short kernels
+  static constexpr int lin_dma = 1;  // 1x1 convs of the 256 x 64 kernel stage their window with global_load_lds
+  static constexpr int conv_pad_lds = 0;  // extra LDS bytes per workgroup (occupancy experiments)
+  static constexpr int c64_wide = 1;  // 64 x 256 tile for the DMA-staged second convs of the C = 64 stage
+  static constexpr int conv2_dma = 1;  // stride-2 valid convs of the 256 x 64 kernel stage by global_load_lds
+  static constexpr int mfast = 0;  // blockIdx.x walks the M tiles (measured neutral)
+  static constexpr int wino_min_c = 64;  // narrowest stage on the transform-domain kernels
+  static constexpr int wino_c64_kmin = 3;  // smallest kernel size of the C = 64 stage on them
+  static constexpr int wino_small = 96;  // workgroups below which conv_wino steps down to 32 x 32 wave tiles
+  static constexpr int wino_cpr = 32;  // channels per barrier round of conv_wino
+  static constexpr int attn_fused = 1;  // one fused attention kernel per layer
+  static constexpr int bf3_variant = 0;  // split-bf16 fused-block variant
+  static constexpr int bf3_pairs = -1;  // split-bf16 blocks as pair launches (-1: by shape)
+  static constexpr int pair_lds_mode = 1;  // LDS layout of the direct pair kernels
+  static constexpr int pair_pad_lds = 0;  // extra LDS bytes per pair workgroup (occupancy experiments)
   int cfg_for_bm[5] = {6, 5, 7, 1, 0};  // conv_mfma.hip: index log2(BM / 16) -> tile shape id ("conv_cfg_bm{16..256}")
   int cfg32_for_bm[4] = {3, 2, 1, 0};   // conv_mfma32.hip: BM class 32, 64, 128, 256 -> tile shape id ("conv32_cfg_bm{32..256}")
 };
@@ -239,7 +249,6 @@ struct ConvArgs {
   int epi;
   int up;               // 1 = conv; s = ConvTranspose stride
   int up_np, up_p0;     // ConvTranspose phase group: row = co*up_np + pi, phase = up_p0 + pi
-  int stagger = 0;      // lin128_kernel: the second workgroup of every CU starts this many 1024-cycle ticks late (set by its launcher)
 };
 
 constexpr int MAX_TAP_SPAN = 60;    // (KS-1)*dil of the default instances (staging register budget)
@@ -363,6 +372,11 @@ bool pair_f23_supported(int C, int KS, int dil);
 int pack_pair_f23(const float* w, float** dev, int C, int KS);
 int launch_pair_f23(const DevPairW& pw, const float* x, float* out, float* acc, const int32_t* lengths, int len_default,
                     int len_mul, int B, int Lmax, int ld, float slope, int epi, float mrf_div, hipStream_t stream);
+// the F(4,3) form: experimental/csrc/respair_wino.hip in DISSC_EXPERIMENTAL=1 builds, experimental_stubs.hip otherwise
+bool pairw43_built();
+int pack_pairw43(const float* w, int C, int KS, float** dev);
+int launch_pairw43(const DevPairW& pw, const float* x, float* out, float* acc, const int32_t* lengths, int len_default, int len_mul,
+                   int B, int Lmax, int ld, float slope, int epi, float mrf_div, hipStream_t stream);
 bool pairw_supported(int C, int KS, int dil);
 bool pairw_wanted(int C, int KS, int dil);  // the generator's policy ("pair_wino" option)
 int make_pairw(const float* w1, const float* b1, const float* w2, const float* b2, int C, int KS, int dil, DevPairW& pw);

@@ -44,7 +44,7 @@ namespace dissc {
 // option "wino_c64_kmin" (Options::wino_c64_kmin, default 3): "wino_c64_kmin" option: smallest kernel size that uses it in a 64-channel stage (in the generator k = 3 /
                          // 7 gain 2 % per forward there; in isolation they are break-even against the DMA-staged direct pair)
 // option "wino_small" (Options::wino_small, default 96): "wino_small" option: launches with fewer 64 x 64-tile workgroups than this use 32 x 32 wave tiles
-// option "wino_dbg" (Options::wino_dbg, default 0): "wino_dbg" option (diagnostics): knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue, 3 staging
+// option "kernel_dbg": diagnostics: knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue, 3 staging
 
 struct WinoArgs {
   const float* x;
@@ -736,7 +736,7 @@ int run_wino(const DevConv& dc, const float* x, float* out, const float* res, fl
   a.C = dc.M; a.nchunk = dc.nchunk; a.pad = (dc.KS - 1) * dc.dil / 2;
   a.ldx = ldx; a.ldo = ldo;
   a.x_bstride = (long long)dc.M * ldx; a.o_bstride = (long long)dc.M * ldo;
-  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = opts().wino_dbg;
+  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = opts().kernel_dbg;
   // the window staging, the residual / accumulator reads and the stores are 16-byte accesses
   auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
   if (ldx < 4 || ldx % 4 || ldo % 4 || misaligned(x) || misaligned(out) || misaligned(res) || misaligned(acc)) {

@@ -42,7 +42,7 @@ namespace dissc {
                       // = 3.4 rounds of 256 CUs where the F(4,3) tiles make exactly 5.0): the default mask leaves that stage alone.
                       // Whole forward, same box, two runs each: 35.17 / 35.27 -> 34.84 / 34.91 ms (1.0 %), executed-FLOP utilisation
                       // 0.62 -> 0.60 (11 % fewer products on those layers in 1 % less time), in-run parity rms 5.5e-7 -> 6.5e-7.
-// option "wino8_dbg" (Options::wino8_dbg, default 0): diagnostics: knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue
+// option "kernel_dbg": diagnostics: knock-outs, bit 0 transform, 1 MFMAs, 2 epilogue
 // option "wino8_c64_wide" (Options::wino8_c64_wide, default 3): "wino8_c64_wide" option, C = 64 instances: 1 = 64 x 128 tiles (768 outputs), 0 = 64 x 64, 2 = 64 x 64 built for TWO
                            // workgroups per CU (<= 128 registers, <= 80 KB LDS: their phases overlap; +3-9 % on k = 11, mixed on
                            // k = 7 as F(6,3), +2-8 % on k = 7 as F(5,4)), 3 (default) = 1 for k = 7 as F(6,3), 2 otherwise (run_wino8)
@@ -661,7 +661,7 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
   a.C = dc.M; a.nchunk = dc.nchunk; a.pad = (dc.KS - 1) * dc.dil / 2;
   a.ldx = ldx; a.ldo = ldo;
   a.x_bstride = (long long)dc.M * ldx; a.o_bstride = (long long)dc.M * ldo;
-  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = opts().wino8_dbg;
+  a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = opts().kernel_dbg;
   a.gx = a.gy = a.B = 0;
   auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
   if (ldx < 4 || ldx % 4 || ldo % 4 || misaligned(x) || misaligned(out) || misaligned(res) || misaligned(acc)) {

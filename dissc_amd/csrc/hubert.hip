@@ -1118,3 +1118,138 @@ static int hubert_forward_part(dissc_hubert_t m, const float* wav, const int32_t
 }
 
 }  // extern "C"
+
+// ---- stand-alone test / gate surface of the stride-2 feature convs (moved here from conv_s2tc.hip in round 6) ----
+namespace dissc {
+__global__ void s2_out_lengths_kernel(const int32_t* __restrict__ lin, int B, int k, int32_t* __restrict__ lout) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) lout[b] = lin[b] >= k ? (lin[b] - k) / 2 + 1 : 0;
+}
+}  // namespace dissc
+
+extern "C" {
+
+// Stand-alone stride-2 VALID conv (tests / gates): x f32 [B,Cin,ldx] -> y f32 [B,Cout,ldo], output length (len - k) / 2 + 1,
+// w HOST [Cout,Cin,k], optional exact-erf GELU.  form 0 = the direct implicit GEMM (conv_mfma32.hip), 1 = the polyphase Toom-Cook form
+// (k = 3 only; experimental/csrc/conv_s2tc.hip: DISSC_EXPERIMENTAL=1 builds, an error otherwise).  Synchronous.
+int dissc_conv1d_s2(const float* x, const float* w_host, const float* bias_host, float* y, const int32_t* lengths_in, int B,
+                    int Cin, int Cout, int k, int ldx, int ldo, int Lmax_in, int act, int form, void* stream_) {
+  if (!x || !w_host || !y || B <= 0 || Lmax_in < k || (form != 0 && form != 1)) {
+    set_error("dissc_conv1d_s2: bad argument");
+    return DISSC_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream_;
+  const int Lmax_out = (Lmax_in - k) / 2 + 1;
+  int32_t* lout = nullptr;
+  if (lengths_in) {
+    DISSC_HIP_CHECK(hipMalloc((void**)&lout, (size_t)B * 4));
+    hipLaunchKernelGGL(s2_out_lengths_kernel, dim3((B + 63) / 64), dim3(64), 0, st, lengths_in, B, k, lout);
+  }
+  int rc;
+  if (form == 1) {
+    DevS2tc dc;
+    if (k != 3) {
+      set_error("dissc_conv1d_s2: the polyphase form is k = 3 only");
+      rc = DISSC_EINVAL;
+    } else if (!(rc = make_s2tc(w_host, bias_host, Cout, Cin, dc))) {
+      dc.act = act;
+      rc = run_s2tc(dc, x, y, lengths_in, lout, Lmax_in, Lmax_out, B, ldx, ldo, Lmax_out, st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    free_s2tc(dc);
+    if (!rc && e != hipSuccess) {
+      set_error("dissc_conv1d_s2: %s", hipGetErrorString(e));
+      rc = DISSC_EHIP;
+    }
+  } else {
+    DevConv dc;
+    if (!(rc = make_conv(w_host, bias_host, Cout, Cin, k, 1, dc, 1, 2, 0))) {
+      dc.act = act;
+      ConvIO io;
+      io.lengths_in = lengths_in; io.lengths_out = lout; io.len_default = Lmax_in; io.olen_default = Lmax_out;
+      rc = run_conv_ex(dc, x, y, nullptr, io, B, Cin, ldx, ldo, Lmax_out, 1.0f, EPI_STORE, st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    free_conv(dc);
+    if (!rc && e != hipSuccess) {
+      set_error("dissc_conv1d_s2: %s", hipGetErrorString(e));
+      rc = DISSC_EHIP;
+    }
+  }
+  if (lout) (void)hipFree(lout);
+  return rc;
+}
+
+// Diagnostics: average ms of `iters` launches of one stride-2, k = 3 conv (C -> C channels, L input samples per utterance,
+// GELU fused) on synthetic data; form as above.
+int dissc_conv_s2_bench(int B, int C, int L, int form, int iters, float* ms_out) {
+  if (!ms_out || B <= 0 || L < 3 || iters <= 0 || (form != 0 && form != 1)) {
+    set_error("dissc_conv_s2_bench: bad argument");
+    return DISSC_EINVAL;
+  }
+  std::vector<float> w((size_t)C * C * 3);
+  uint32_t s = 12345u;
+  for (auto& v : w) {
+    s = s * 1664525u + 1013904223u;
+    v = ((s >> 8) / 16777216.0f - 0.5f) * 0.1f;
+  }
+  const int Lo = (L - 3) / 2 + 1;
+  const int ldx = (L + 3) / 4 * 4, ldo = (Lo + 3) / 4 * 4;
+  const size_t nx = (size_t)B * C * ldx, no = (size_t)B * C * ldo;
+  std::vector<float> hx(nx);
+  for (auto& v : hx) {
+    s = s * 1664525u + 1013904223u;
+    v = ((s >> 8) / 16777216.0f - 0.3f) * 2.f;
+  }
+  float *x = nullptr, *y = nullptr;
+  DISSC_HIP_CHECK(hipMalloc((void**)&x, nx * 4));
+  DISSC_HIP_CHECK(hipMalloc((void**)&y, no * 4));
+  DISSC_HIP_CHECK(hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice));
+  DevS2tc tc;
+  DevConv dc;
+  int rc = form == 1 ? make_s2tc(w.data(), nullptr, C, C, tc) : make_conv(w.data(), nullptr, C, C, 3, 1, dc, 1, 2, 0);
+  tc.act = 1;
+  dc.act = 1;
+  ConvIO io;
+  io.len_default = L; io.olen_default = Lo;
+  float* tlbuf = nullptr;  // diagnostics (DISSC_TIMELINE): a kernel's timeline stamps, handed over as the accumulator pointer
+  const char* tlp = getenv("DISSC_TIMELINE");
+  if (tlp) {
+    DISSC_HIP_CHECK(hipMalloc((void**)&tlbuf, (size_t)4096 * 64));
+    DISSC_HIP_CHECK(hipMemset(tlbuf, 0, (size_t)4096 * 64));
+  }
+  auto once = [&]() {
+    return form == 1 ? run_s2tc(tc, x, y, nullptr, nullptr, L, Lo, B, ldx, ldo, Lo, nullptr)
+                     : run_conv_ex(dc, x, y, nullptr, tlbuf, io, B, C, ldx, ldo, Lo, 1.0f, EPI_STORE, 1.f, nullptr);
+  };
+  hipEvent_t e0, e1;
+  DISSC_HIP_CHECK(hipEventCreate(&e0));
+  DISSC_HIP_CHECK(hipEventCreate(&e1));
+  for (int it = 0; it < 2 && !rc; ++it) rc = once();
+  DISSC_HIP_CHECK(hipEventRecord(e0, nullptr));
+  for (int it = 0; it < iters && !rc; ++it) rc = once();
+  DISSC_HIP_CHECK(hipEventRecord(e1, nullptr));
+  hipError_t e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (tlbuf) {
+    std::vector<char> hb((size_t)4096 * 64);
+    if (hipMemcpy(hb.data(), tlbuf, hb.size(), hipMemcpyDeviceToHost) == hipSuccess)
+      if (FILE* f = fopen(tlp, "wb")) {
+        fwrite(hb.data(), 1, hb.size(), f);
+        fclose(f);
+      }
+    (void)hipFree(tlbuf);
+  }
+  (void)hipFree(x); (void)hipFree(y);
+  free_s2tc(tc);
+  free_conv(dc);
+  if (rc) return rc;
+  DISSC_HIP_CHECK(e);
+  return DISSC_OK;
+}
+
+}  // extern "C"

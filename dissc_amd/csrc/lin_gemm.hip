@@ -109,7 +109,7 @@ __device__ __forceinline__ void lin128_epilogue(const ConvArgs& a, f32x16 (&acc)
 template <int MI>
 __device__ __forceinline__ void lin128_store(const ConvArgs& a, f32x16 (&acc)[MI][4], int ms0, int h, int b, int tcol, int olen) {
   if (tcol >= olen) return;
-  const int fl = (a.act == 1 ? 1 : 0) | (a.epi == EPI_RES ? 2 : 0) | (a.scale ? 4 : 0);
+  const int fl = (a.act == 1 ? 1 : 0) | (a.epi == EPI_RES ? 2 : 0);  // (layers with a per-row affine stay on conv_mfma32_kernel)
   const size_t o0 = (size_t)b * a.o_bstride + tcol;
   const int nv = olen - tcol;
   const bool full = __builtin_amdgcn_ballot_w64(nv < 4) == 0;
@@ -121,11 +121,7 @@ __device__ __forceinline__ void lin128_store(const ConvArgs& a, f32x16 (&acc)[MI
     case 0: DISSC_LIN128_EPI(false, false, false)
     case 1: DISSC_LIN128_EPI(true, false, false)
     case 2: DISSC_LIN128_EPI(false, true, false)
-    case 3: DISSC_LIN128_EPI(true, true, false)
-    case 4: DISSC_LIN128_EPI(false, false, true)
-    case 5: DISSC_LIN128_EPI(true, false, true)
-    case 6: DISSC_LIN128_EPI(false, true, true)
-    default: DISSC_LIN128_EPI(true, true, true)
+    default: DISSC_LIN128_EPI(true, true, false)
   }
 #undef DISSC_LIN128_EPI
 }
@@ -185,7 +181,7 @@ __device__ __forceinline__ bool tile128_of(const ConvArgs& a, int& b, int& bx, i
   return true;
 }
 
-// DBG (diagnostics, option "lin128_dbg"): bit 3: no epilogue, bit 5: timeline stamps into a.acc (the knock-outs of the first,
+// DBG (diagnostics, option "kernel_dbg"): bit 3: no epilogue, bit 5: timeline stamps into a.acc (the knock-outs of the first,
 // compiler-scheduled form -- A loads 5.7 %, epilogue 8 %, barrier 3 % of fc1 -- are on record in profiles/r06/lin128_gate_v3.txt)
 template <int MI, int KCB, int WGPC, int DBG = 0>
 __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
@@ -195,15 +191,6 @@ __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // 2 x [KCB][128]
 
   int b, bx, by;
-  if (a.stagger) {
-    // The dispatcher deals workgroup ids round-robin over the 8 XCDs and, inside an XCD, breadth-first over its 32 CUs: ids 0 .. 255
-    // take the first slot of every CU, ids 256 .. 511 the second.  Those start late, so that the two workgroups of a CU are
-    // never in their epilogues (an HBM write burst with the matrix pipe idle) or prologues at the same time; every later
-    // workgroup starts when a slot frees up and inherits the offset.
-    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (id >= 256u && id < 512u)
-      for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles
-  }
   if (!tile128_of(a, b, bx, by)) return;
   unsigned long long* tl = nullptr;  // DBG bit 5: 100 MHz wall-clock stamps of wave 0 (start, loop start, loop end, stores issued) + placement
   if constexpr ((DBG & 32) != 0) {
@@ -215,7 +202,7 @@ __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
       tl[1] = tl[2] = tl[3] = 0;
     }
   }
-  if (a.stagger >= 0) __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(3);
   const int len = (a.lengths ? a.lengths[b] * a.len_mul : a.len_default);
   const int olen = a.lengths_out ? a.lengths_out[b] : (a.olen_default >= 0 ? a.olen_default : len);
   const int t0 = bx * BN;
@@ -354,7 +341,7 @@ __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
   }
   // The epilogue (and the prologue) at raised priority: next to a wave that issues MFMAs back to back, this wave's ~500 VALU / store
   // instructions otherwise get an issue slot every 2-3 MFMAs (17-35 us instead of 3.5 alone, profiles/r06/lin128_timeline*.txt)
-  if (a.stagger >= 0) __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(3);
   lin128_store<MI>(a, acc, ms0, h, b, t0 + 4 * l31, olen);
   if constexpr ((DBG & 32) != 0) {
     if (threadIdx.x == 0) {
@@ -368,7 +355,7 @@ __global__ void __launch_bounds__(256, WGPC) lin128_kernel(const ConvArgs a) {
 // option "lin128" (Options::lin128, default 1): HuBERT's linears on lin128_kernel (0: conv_mfma32_kernel's 256 x 64 instances)
 bool lin128_supported(const ConvArgs& a) {
   return a.KS == 1 && a.groups == 1 && a.up == 1 && a.slope == 1.0f && a.pad_left == 0 && a.prec == 0 && a.m32 == 1 &&
-         (a.epi == EPI_STORE || a.epi == EPI_RES) && a.M >= 256 && a.M % 256 == 0 && a.CIN % 64 == 0 && a.ldx >= 4 && a.ldx % 4 == 0 &&
+         (a.epi == EPI_STORE || a.epi == EPI_RES) && !a.scale && a.M >= 256 && a.M % 256 == 0 && a.CIN % 64 == 0 && a.ldx >= 4 && a.ldx % 4 == 0 &&
          a.ldo % 4 == 0;
 }
 
@@ -378,7 +365,6 @@ static int launch_lin128_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) 
   a.mt_per_group = (a.M + BM - 1) / BM;
   dim3 grid((Lmax_out + BN - 1) / BN, a.mt_per_group, B);
   a.mfast = 0;
-  a.stagger = opts().lin128_stagger;
   a.ragged_enum = (opts().ragged_enum && (a.lengths || a.lengths_out) && B > 1) ? 1 : 0;
   const int mt = a.mt_per_group;
   const long long tt_pad = ((long long)grid.x * B + 7) / 8 * 8;
@@ -400,7 +386,7 @@ static int launch_lin128_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) 
     }
   }
   size_t lds = (size_t)2 * KCB * BN * sizeof(float);
-  if (opts().lin128_dbg == 64 || getenv("DISSC_LIN128_ONE")) lds = 100 * 1024;  // diagnostics: ONE workgroup per CU (one wave per SIMD)
+  if (opts().kernel_dbg == 64 || getenv("DISSC_LIN128_ONE")) lds = 100 * 1024;  // diagnostics: ONE workgroup per CU (one wave per SIMD)
   static DeviceOnce attr_once;
   DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&lin128_kernel<MI, KCB, WGPC, DBG>), 160 * 1024));
   hipLaunchKernelGGL((lin128_kernel<MI, KCB, WGPC, DBG>), grid, dim3(256), lds, stream, a);
@@ -409,7 +395,7 @@ static int launch_lin128_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) 
 }
 
 int launch_lin128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream) {
-  if (opts().lin128_dbg == 32) return launch_lin128_t<2, 32, 2, 32>(a, B, Lmax_out, stream);  // timeline stamps (tools/lin128_timeline.py)
+  if (opts().kernel_dbg == 32) return launch_lin128_t<2, 32, 2, 32>(a, B, Lmax_out, stream);  // timeline stamps (tools/lin128_timeline.py)
   // Tile shape per launch (option "lin128": 1 = this policy; 2 / 3 / 5 force a shape, for the gate records).  All shapes give the same
   // bits.  With scalar-base loads and hand-counted waits (profiles/r06/lin128_gate_v8.txt; B = 32 x T = 499, us: old kernel / 256 x 128
   // two per CU / 128 x 128 three per CU / 128 x 128 two per CU with 64 channels per barrier): fc1 618 / 617 / 558 / 550, fc2 628 / 731 /
@@ -443,7 +429,7 @@ int launch_lin128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream) {
 //   * window in LDS: per channel 64 float4 = frames [2 t0, 2 t0 + 256) in a main block [KCB][256] plus ONE more float4 (the 257th
 //     float, w[8] of lane 31) in a tail block [KCB][4]: rows of a power-of-two length (DMA slot -> (row, float4) by shifts), and lane
 //     31 reads its w[8] from the tail instead of from its neighbour's w[0].
-// DBG (option "lin128_dbg", diagnostics): bit 0: no A loads in the loop, 1: no window DMA, 2: no window reads, 3: no epilogue, 4: no wait +
+// DBG (option "kernel_dbg", diagnostics): bit 0: no A loads in the loop, 1: no window DMA, 2: no window reads, 3: no epilogue, 4: no wait +
 // barrier per stage, 5: timeline stamps into a.acc (as lin128_kernel)
 // ASM: loads and waits through vm_load16 / vm_dma16 / vm_wait (hand-counted vmcnt); false: compiler-scheduled builtins
 template <int KCB, int WGPC, int DBG = 0, bool ASM = true>
@@ -664,7 +650,7 @@ bool conv2s128_shape(int Cout, int Cin, int KS, int stride, int groups) {
 // option "conv2s128" (Options::conv2s128, default 1): stride-2 k = 3 convs on conv2s128_kernel (0: conv_mfma32_kernel; 2: 32 channels per barrier)
 bool conv2s128_supported(const ConvArgs& a) {
   return a.wpack2 && a.KS == 3 && a.dil == 1 && a.groups == 1 && a.up == 1 && a.slope == 1.0f && a.pad_left == 0 && a.prec == 0 &&
-         a.epi == EPI_STORE && a.M % 256 == 0 && a.CIN % 32 == 0 && a.ldx >= 4 && a.ldx % 4 == 0 && a.ldo % 4 == 0 &&
+         a.epi == EPI_STORE && !a.scale && a.M % 256 == 0 && a.CIN % 32 == 0 && a.ldx >= 4 && a.ldx % 4 == 0 && a.ldo % 4 == 0 &&
          (a.lengths_out || a.olen_default >= 0);
 }
 
@@ -674,7 +660,6 @@ static int launch_conv2s128_t(ConvArgs a, int B, int Lmax_out, hipStream_t strea
   a.mt_per_group = a.M / BM;
   dim3 grid((Lmax_out + BN - 1) / BN, a.mt_per_group, B);
   a.mfast = 0;
-  a.stagger = 0;
   a.ragged_enum = (opts().ragged_enum && a.lengths_out && B > 1) ? 1 : 0;
   const int mt = a.mt_per_group;
   const long long tt_pad = ((long long)grid.x * B + 7) / 8 * 8;
@@ -704,19 +689,10 @@ static int launch_conv2s128_t(ConvArgs a, int B, int Lmax_out, hipStream_t strea
 }
 
 int launch_conv2s128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream) {
-  switch (opts().lin128_dbg) {
-    case 1: return launch_conv2s128_t<32, 2, 1>(a, B, Lmax_out, stream);
-    case 2: return launch_conv2s128_t<32, 2, 2>(a, B, Lmax_out, stream);
-    case 4: return launch_conv2s128_t<32, 2, 4>(a, B, Lmax_out, stream);
-    case 8: return launch_conv2s128_t<32, 2, 8>(a, B, Lmax_out, stream);
-    case 16: return launch_conv2s128_t<32, 2, 16>(a, B, Lmax_out, stream);
-    case 23: return launch_conv2s128_t<32, 2, 23>(a, B, Lmax_out, stream);
-    case 31: return launch_conv2s128_t<32, 2, 31>(a, B, Lmax_out, stream);
-    case 32: return launch_conv2s128_t<32, 2, 32>(a, B, Lmax_out, stream);
-    default: break;
-  }
+  if (opts().kernel_dbg == 32) return launch_conv2s128_t<32, 2, 32>(a, B, Lmax_out, stream);  // timeline stamps (tools/conv2s128_gate.py)
   switch (opts().conv2s128) {
-    case 2: return launch_conv2s128_t<32, 2, 0, false>(a, B, Lmax_out, stream);  // compiler-scheduled loads (the gate's reference)
+    // (2, the compiler-scheduled form with per-lane 64-bit addresses -- conv1 6 146 us where this one takes 5 715 -- is on record in
+    //  profiles/r06/conv2s128_gate_v3.txt and no longer instantiated)
     case 3: return launch_conv2s128_t<16, 2, 0, true>(a, B, Lmax_out, stream);
     default: return launch_conv2s128_t<32, 2, 0, true>(a, B, Lmax_out, stream);
   }

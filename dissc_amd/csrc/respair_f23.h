@@ -18,7 +18,7 @@ struct PairFArgs {
   long long bstride;
   float slope, mrf_div;
   int epi;
-  int dbg;  // diagnostics ("wino_dbg" option): knock-outs -- bit 0 the tap loops, 1 the T epilogue, 2 the output epilogue
+  int dbg;  // diagnostics ("kernel_dbg" option): knock-outs -- bit 0 the tap loops, 1 the T epilogue, 2 the output epilogue
 };
 
 constexpr int f23_round32_16(int n) { return (n - 16 + 31) / 32 * 32 + 16; }  // smallest v >= n with v % 32 == 16

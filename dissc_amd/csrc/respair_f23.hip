@@ -329,7 +329,7 @@ int launch_pair_f23(const DevPairW& pw, const float* x, float* out, float* acc, 
   PairFArgs a;
   a.x = x; a.out = out; a.acc = acc; a.w1 = pw.w1; a.w2 = pw.w2; a.b1 = pw.b1; a.b2 = pw.b2;
   a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul; a.ld = ld;
-  a.bstride = (long long)pw.C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = opts().wino_dbg;
+  a.bstride = (long long)pw.C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.dbg = opts().kernel_dbg;
   if (pw.C == 16) return launch_pair16_f23(a, pw.KS, pw.dil, B, Lmax, stream);
 #define DISSC_F23(K_, D_) \
   if (pw.KS == K_ && pw.dil == D_) return launch_f23_t<K_, D_>(a, B, Lmax, stream);

@@ -39,7 +39,6 @@ namespace dissc {
                       // shapes are 6-15 % faster, in the whole forward (three chains overlapping on their streams) that
                       // is 35.36 against 35.42 ms, while the executed-FLOP utilisation falls from 0.619 to 0.602.
 
-#if DISSC_EXPERIMENTAL  // the F(4,3) pair kernel failed its gate (above): built with DISSC_EXPERIMENTAL=1 only
 struct PairWArgs {
   const float* x;     // [B][C][ld] pair input x_k
   float* out;         // EPI_RES: x_k' (may not alias x: neighbouring workgroups still read x's halo)
@@ -55,7 +54,7 @@ struct PairWArgs {
   float slope, mrf_div;
   int epi;
   int gx, B;
-  int dbg;  // diagnostics ("wino_dbg" option): knock-outs, bit 0 transforms, 1 MFMAs, 2 the A^T passes of the exchanges
+  int dbg;  // diagnostics ("kernel_dbg" option): knock-outs, bit 0 transforms, 1 MFMAs, 2 the A^T passes of the exchanges
 };
 
 constexpr int pw_rup4(int n) { return (n + 3) / 4 * 4; }
@@ -569,40 +568,13 @@ __global__ void __launch_bounds__(384 * CHV, 3) respair_wino_kernel(const PairWA
   pass_d(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
 }
 
-#endif  // DISSC_EXPERIMENTAL
 
 // ---------------------------------------------------------------------------------------------
-// host side
+// host side of the F(4,3) pair kernel (the dispatch that is shared with the register-only F(2,3) pairs is dissc_amd/csrc/pair_host.hip)
 // ---------------------------------------------------------------------------------------------
-// shapes that have an instance: a point's weights must fit 64 registers per lane (C^2 NS / 64 <= 64)
-bool pairw_supported(int C, int KS, int dil) {
-  if (!DISSC_EXPERIMENTAL) return false;  // (the kernel is not in this build)
-  if (!(dil == 1 || dil == 3 || dil == 5)) return false;
-  if (C == 32) return KS == 7 || KS == 11;
-  if (C == 64) return KS == 3;
-  return false;
-}
+bool pairw43_built() { return true; }
 
-// ... and the ones the generator uses it for with "pair_wino" = 1: where it measured faster than what it replaces
-// (tools/pair_gate.py, B = 32 x 10 s, one MI355X: C = 32, k = 11: 895 / 988 us against 1 042 / 1 047 for the direct fused
-// pair at d = 1 / 3, break-even at d = 5 and slower with the MRF epilogue that pair always has; C = 64, k = 3, d = 1:
-// 624 against 658 for two conv_wino launches, break-even at d = 3 / 5; C = 32, k = 7: 884-963 against 732: never).
-// The verdict's gates (C = 32, k = 11, d = 1 pair <= 720 us where the direct pair takes 921; C = 64, k = 3 pair <= 520 us)
-// were NOT met: knock-outs (tools/pair_ko.py) put a k = 11 tile at MFMAs 476 + input transforms 100 + the two A^T
-// exchanges 125 + skeleton (staging, barriers, weight loads, launch) 197 us, nothing overlapping -- one workgroup fills
-// the CU and fp32 VALU work shares the MFMA datapath.  "pair_wino" = 2 takes every supported shape (tests).
-bool pairw_wanted(int C, int KS, int dil) {
-  if (opts().pair_f23 && pair_f23_supported(C, KS, dil)) return true;  // (make_pairw then builds the register-only F(2,3) form)
-  if (!opts().pair_wino || !pairw_supported(C, KS, dil)) return false;
-  if (opts().pair_wino >= 2) return true;
-  if (C == 32) return KS == 11 && dil <= 3;
-  return C == 64 && KS == 3 && dil == 1;
-}
-
-// w: [C][C][KS] -> U[p][co][ci][j] = sum_i G[p][i] w[co][ci][j + NS i] in the order the kernel's lanes hold them:
-// [point][mi][tap j][8-channel sub-chunk][lane][k-step e] = U_p[32 mi + (lane & 31)][8 ksub + 2 e + (lane >> 5)][j]
-#if DISSC_EXPERIMENTAL
-static int pack_pairw(const float* w, int C, int KS, float** dev) {
+int pack_pairw43(const float* w, int C, int KS, float** dev) {
   const int NS = (KS + 2) / 3, MI = C / 32, NK = C / 8;
   std::vector<float> packed((size_t)6 * MI * NS * NK * 64 * 4);
   size_t o = 0;
@@ -622,42 +594,7 @@ static int pack_pairw(const float* w, int C, int KS, float** dev) {
             }
   return upload(packed, dev);
 }
-#else
-static int pack_pairw(const float*, int, int, float**) {
-  set_error("make_pairw: the F(4,3) pair kernel is only in DISSC_EXPERIMENTAL=1 builds");
-  return DISSC_EINVAL;
-}
-#endif
 
-int make_pairw(const float* w1, const float* b1, const float* w2, const float* b2, int C, int KS, int dil, DevPairW& pw) {
-  pw.form = (opts().pair_f23 && pair_f23_supported(C, KS, dil)) ? 1 : 0;
-  if (!pw.form && !pairw_supported(C, KS, dil)) {
-    set_error("make_pairw: no instance for C = %d, k = %d, dilation %d", C, KS, dil);
-    return DISSC_EINVAL;
-  }
-  pw.C = C; pw.KS = KS; pw.dil = dil;
-  int rc = pw.form ? pack_pair_f23(w1, &pw.w1, C, KS) : pack_pairw(w1, C, KS, &pw.w1);
-  if (!rc) rc = pw.form ? pack_pair_f23(w2, &pw.w2, C, KS) : pack_pairw(w2, C, KS, &pw.w2);
-  std::vector<float> bb(C, 0.f);
-  if (b1) memcpy(bb.data(), b1, C * sizeof(float));
-  if (!rc) rc = upload(bb, &pw.b1);
-  std::fill(bb.begin(), bb.end(), 0.f);
-  if (b2) memcpy(bb.data(), b2, C * sizeof(float));
-  if (!rc) rc = upload(bb, &pw.b2);
-  return rc;
-}
-
-void free_pairw(DevPairW& pw) {
-  for (float** q : {&pw.w1, &pw.w2, &pw.b1, &pw.b2}) {
-    if (*q) (void)hipFree(*q);
-    *q = nullptr;
-  }
-}
-
-// option "pairw_chv" (Options::pairw_chv, default 2): "pairw_chv" option: column halves per workgroup of respair_wino_kernel (2: one 12-wave workgroup per CU;
-                      // 1: two 6-wave workgroups with half the tile each -- measured 5-30 % slower, kept for the tests)
-
-#if DISSC_EXPERIMENTAL
 template <int C, int KS, int DIL, int CHV>
 static int launch_pairw_t(PairWArgs a, int B, int Lmax, hipStream_t stream) {
   using G = PairWGeo<C, KS, DIL, CHV>;
@@ -671,22 +608,13 @@ static int launch_pairw_t(PairWArgs a, int B, int Lmax, hipStream_t stream) {
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
-#endif
 
-int launch_respair_wino(const DevPairW& pw, const float* x, float* out, float* acc, const int32_t* lengths, int len_default,
-                        int len_mul, int B, int Lmax, int ld, float slope, int epi, float mrf_div, hipStream_t stream) {
-  auto misaligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) != 0; };
-  if (!pw.w1 || epi == EPI_STORE || x == out || ld < 4 || ld % 4 || misaligned(x) || misaligned(out) || misaligned(acc) ||
-      B <= 0 || Lmax <= 0) {
-    set_error("launch_respair_wino: bad argument (C=%d k=%d d=%d ld=%d epi=%d)", pw.C, pw.KS, pw.dil, ld, epi);
-    return DISSC_EINVAL;
-  }
-  if (pw.form == 1) return launch_pair_f23(pw, x, out, acc, lengths, len_default, len_mul, B, Lmax, ld, slope, epi, mrf_div, stream);
-#if DISSC_EXPERIMENTAL
+int launch_pairw43(const DevPairW& pw, const float* x, float* out, float* acc, const int32_t* lengths, int len_default,
+                   int len_mul, int B, int Lmax, int ld, float slope, int epi, float mrf_div, hipStream_t stream) {
   PairWArgs a;
   a.x = x; a.out = out; a.acc = acc; a.w1 = pw.w1; a.w2 = pw.w2; a.b1 = pw.b1; a.b2 = pw.b2;
   a.lengths = lengths; a.len_default = len_default; a.len_mul = len_mul; a.ld = ld;
-  a.bstride = (long long)pw.C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.gx = 0; a.B = B; a.dbg = opts().wino_dbg;
+  a.bstride = (long long)pw.C * ld; a.slope = slope; a.mrf_div = mrf_div; a.epi = epi; a.gx = 0; a.B = B; a.dbg = opts().kernel_dbg;
 #define DISSC_PAIRW(C_, K_, D_)                                                                       \
   if (pw.C == C_ && pw.KS == K_ && pw.dil == D_)                                                      \
     return opts().pairw_chv == 2 ? launch_pairw_t<C_, K_, D_, 2>(a, B, Lmax, stream) : launch_pairw_t<C_, K_, D_, 1>(a, B, Lmax, stream);
@@ -694,8 +622,7 @@ int launch_respair_wino(const DevPairW& pw, const float* x, float* out, float* a
   DISSC_PAIRW(32, 11, 1) DISSC_PAIRW(32, 11, 3) DISSC_PAIRW(32, 11, 5)
   DISSC_PAIRW(64, 3, 1) DISSC_PAIRW(64, 3, 3) DISSC_PAIRW(64, 3, 5)
 #undef DISSC_PAIRW
-#endif
-  set_error("launch_respair_wino: no instance%s", DISSC_EXPERIMENTAL ? "" : " (the F(4,3) pair kernel is only in DISSC_EXPERIMENTAL=1 builds)");
+  set_error("launch_pairw43: no instance for C = %d, k = %d, dilation %d", pw.C, pw.KS, pw.dil);
   return DISSC_EINVAL;
 }
 

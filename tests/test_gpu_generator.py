@@ -469,32 +469,6 @@ def test_f23_pairs_agree_with_the_direct_pairs(env):
         assert torch.equal(one, y[0])
 
 
-def test_transform_domain_pairs_agree_with_the_unfused_generator(env, experimental):
-    """respair_wino.hip (opt-in, "pair_wino" = 1: the k = 11, d = 1 / 3 pairs of the 32-channel stage and the first k = 3
-    pair of the 64-channel stage as ONE transform-domain launch each; = 2: every shape with an instance) against the
-    default instance: same waveform to fp32 rounding, ragged and at the BASELINE size; fewer executed FLOPs are
-    reported for them."""
-    lib, synth = env["lib"], env["synth"]
-    # (without the forms that took those shapes over since: the register-only F(2,3) pairs and the k = 3 layers on conv_wino8)
-    base = dict(pair_f23=0, wino8_mask=0o770770770)
-    gd = _generator_with(lib, synth, pair_wino=0, **base)
-    g1 = _generator_with(lib, synth, pair_wino=1, **base)   # the shapes that measured faster per launch
-    ga = _generator_with(lib, synth, pair_wino=2, **base)   # every shape that has an instance
-    assert g1.flops_executed(1000) < gd.flops_executed(1000) and g1.flops(1000) == gd.flops(1000)
-    assert ga.flops_executed(1000) < g1.flops_executed(1000)
-    for g, (code, f0, spkr, lengths) in [(g_, c) for g_ in (g1, ga) for c in _pair_cases(synth)]:
-        kw = dict(code=torch.from_numpy(code), f0=torch.from_numpy(f0), spkr=torch.from_numpy(spkr),
-                  lengths=torch.from_numpy(lengths))
-        yw, yd = g(**kw).cpu(), gd(**kw).cpu()
-        assert torch.isfinite(yw).all() and not torch.equal(yw, yd)
-        e = (yw - yd).double()
-        rms = float(e.pow(2).mean().sqrt())
-        print(f"B={code.shape[0]} T={code.shape[1]}: fused transform-domain pairs vs pair_wino=0: rms {rms:.2e}, max {float(e.abs().max()):.2e}")
-        assert rms <= 5e-6 and float(e.abs().max()) <= 1e-4
-        one = g(code=kw["code"][:1], f0=kw["f0"][:1], spkr=kw["spkr"][:1], lengths=kw["lengths"][:1]).cpu()[0]
-        assert torch.equal(one, yw[0])  # an utterance's samples do not depend on the batch it runs in
-
-
 @pytest.mark.parametrize("C,k,d", [(64, 7, 1), (64, 11, 5), (128, 7, 3), (128, 11, 1), (256, 7, 5), (256, 11, 3), (64, 11, 3), (128, 7, 5)])
 def test_f63_f54_conv_matches_torch_and_the_f43_form(env, C, k, d):
     """conv_wino8.hip (the eight Toom-Cook points on 8-wave workgroups as F(6,3), "wino8" = 2, and as F(5,4) with 4-tap

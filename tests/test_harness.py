@@ -316,3 +316,89 @@ def test_limit_host_threads_env_rules(monkeypatch):
         assert harness.limit_host_threads(local_world=10 ** 6) == 1
     finally:
         torch.set_num_threads(before)
+
+
+def _sweep_frames():
+    """BASELINE configs[4]: 108 speakers x 24 utterances x 4 targets = 10 368 jobs of 2-5 s (100-250 frames)"""
+    rs = np.random.RandomState(5)
+    return np.repeat(rs.randint(100, 251, size=108 * 24), 4).tolist()
+
+
+def test_eight_rank_plan_of_the_vctk_sweep():
+    """The plan every rank derives for the 8-GPU run of the full sweep (SURVEY 8(e), round 5 verdict item 6c), computed here for all
+    eight ranks: LPT shares within 2 % of each other in frames, the tapered overlap rounds cover every job once, and what a rank SENDS
+    over all rounds (ragged buffers sized by the fullest rank of each round) stays within 1.05x of the samples the fullest rank
+    holds -- the exchange carries payload, not padding."""
+    frames = _sweep_frames()
+    parts = harness.lpt_shard(frames, 8)
+    assert sorted(i for p in parts for i in p) == list(range(len(frames)))
+    assert 1.0 <= harness.imbalance(frames, parts) <= 1.02
+    share = [sum(frames[i] for i in p) for p in parts]
+    assert max(share) <= 1.02 * min(share)
+    budget = harness.overlap_budget(frames, parts, harness.ROUND_FLOATS // 320, cap=harness.OVERLAP_CAP_FLOATS // 320)
+    rounds = harness.plan_rounds(frames, parts, budget)
+    assert 2 <= len(rounds) <= harness.OVERLAP_MAX_ROUNDS
+    for r in range(8):
+        assert sorted(i for rd in rounds for i in rd[r]) == sorted(parts[r])
+    sent = 0
+    for rd in rounds:
+        n_cap, data_cap = harness.pack_geometry(frames, rd, 320)
+        sent += harness.buffer_floats(n_cap, data_cap)
+    payload = max(share) * 320
+    assert sent <= 1.05 * payload, (sent, payload)
+    # the exposed (last) round is the smallest: the taper
+    per_round = [max(sum(frames[i] for i in rd[r]) for r in range(8)) for rd in rounds]
+    assert per_round[-1] == min(per_round)
+
+
+def _sweep_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = _sweep_frames()
+    rs = np.random.RandomState(11)
+    codes = rs.randint(0, 100, size=max(frames))
+    f0 = np.zeros(max(frames), np.float32)
+    jobs = [dict(code=codes[:T], f0=f0[:T], spkr=j % 9) for j, T in enumerate(frames)]
+    got, st = {}, {}
+
+    def sink(w):
+        for k, v in w.items():
+            got[k] = (len(v), float(v[0]) if len(v) else 0.0)
+    n = harness.run_resynthesis(_FakeGenerator(), jobs, rank, world, "cpu", dist, max_batch=128, sink=sink, own_rows=True,
+                                overlap=True, stats=st)
+    q.put((rank, n, sorted(got), st.get("rounds"), st.get("collectives"), st.get("rows_all_ranks"), st.get("sent_floats"),
+           st.get("payload_floats")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_run_of_the_vctk_sweep():
+    """... and the same plan EXECUTED by eight gloo ranks with the CPU stand-in generator (4 samples per frame): the CLIs' N > 1
+    default (every rank delivers the rows it decoded, the round's collective carries the row tables), 10 368 jobs, every job
+    delivered exactly once, by the rank LPT gave it to, in the planned number of rounds, one collective per round."""
+    frames = _sweep_frames()
+    parts = harness.lpt_shard(frames, 8)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(8))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    seen = []
+    for rank, n, ids, rounds, coll, rows_all, sent, payload in res:
+        assert ids == sorted(parts[rank]) and n == len(ids)
+        assert 2 <= rounds <= harness.OVERLAP_MAX_ROUNDS and coll == rounds
+        assert rows_all == len(frames)          # every rank saw all 10 368 rows accounted for in the gathered tables
+        assert sent < payload                   # own rows: tables travel, samples do not
+        seen += ids
+    assert sorted(seen) == list(range(len(frames)))

@@ -246,7 +246,7 @@ def test_pin_script_route_with_stub_libraries(tmp_path):
     r = subprocess.run([sys.executable, script, "--out", str(out)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert sorted(os.listdir(out)) == ["hubert_fairseq.npz", "resample_resampy.npz", "yaapt_amfm.npz"]
-    assert "3 passed, 1 skipped" in r.stdout, r.stdout[-2000:]
+    assert "4 passed, 1 skipped" in r.stdout, r.stdout[-2000:]  # (3 pin parities + the --check test)
     g = np.load(out / "yaapt_amfm.npz")
     assert {"s1_1", "s1_2", "flat120"} <= set(_keys(g, "f0/")) and len(g["f0/s1_1"]) == 400
     g = np.load(out / "resample_resampy.npz")
@@ -258,3 +258,17 @@ def test_pin_script_route_with_stub_libraries(tmp_path):
 def _importable(name):
     import importlib.util
     return importlib.util.find_spec(name) is not None
+
+
+def test_pin_script_check_mode_names_the_reference_pins(capsys):
+    """`tools/pin_third_party.py --check` (round 5 verdict, item 8): a dry run that says, per stage, what imports here, the exact install
+    line the reference names (README.md:30-34: textlesslib, fairseq @ dd106d95...), the file a run would write and the tests it un-skips"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pin_third_party as pin
+    assert pin.main(["--check"]) == 0
+    out = capsys.readouterr().out
+    assert "fairseq.git@dd106d9534b22e7db859a6b87ffd7780c38341f8" in out and "textlesslib" in out
+    for f in ("hubert_fairseq.npz", "yaapt_amfm.npz", "resample_resampy.npz", "hubert_textless_real.npz"):
+        assert f in out
+    assert "test_hip_hubert_matches_fairseq" in out and "ready here:" in out
+

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Gate of conv2s128_kernel (csrc/lin_gemm.hip): HuBERT's stride-2, k = 3 feature convs (conv1 .. conv4, B = 32 x 10 s) through
-dissc_conv_s2_bench under conv2s128 = 0 (conv_mfma32_kernel, 256 x 64 tiles) / 1 / 2, sustained, alternating -- and the error of both
+dissc_conv_s2_bench under conv2s128 = 0 (conv_mfma32_kernel, 256 x 64 tiles) / 1 (32 channels per barrier) / 3 (16), sustained, alternating -- and the error of both
 kernels against a float64 convolution (ragged lengths, NaN-poisoned padding; another K order: not bit-identical, same error level).
-   python tools/conv2s128_gate.py [variants ...]      (default: 0 1 2)"""
+   python tools/conv2s128_gate.py [variants ...]      (default: 0 1 3)"""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -10,7 +10,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dissc_amd._lib import lib, check
 
-vals = [int(v) for v in sys.argv[1:]] or [0, 1, 2]
+vals = [int(v) for v in sys.argv[1:]] or [0, 1, 3]
 
 
 def conv(x, w, bias, lengths, v, act):
@@ -74,20 +74,11 @@ if __name__ == "__main__":
         print(f"{name} L_in {lin:5d}: " + " | ".join(f"conv2s128={v}: {best[v]:7.1f} us {gf / best[v] * 1e3:6.1f} TFLOP/s" for v in vals),
               flush=True)
     print("conv1..4: " + " | ".join(f"conv2s128={v}: {tot[v] / 1e3:.3f} ms" for v in vals))
-    if os.environ.get("CONV2S_KO"):
-        base = bench(31999, 2, 100)
-        out = []
-        for ko in (1, 2, 4, 8, 16, 23, 31):
-            check(lib.dissc_set_option(b"lin128_dbg", ko), "set")
-            out.append(f"{ko}: {bench(31999, 2, 100):.0f}")
-        check(lib.dissc_set_option(b"lin128_dbg", 0), "set")
-        print(f"conv1 knock-outs of conv2s128=2 (us; full {base:.0f}; 1 no A loads, 2 no DMA, 4 no window reads, 8 no epilogue, 16 no barrier): "
-              + ", ".join(out), flush=True)
     if os.environ.get("CONV2S_TL"):
         os.environ["DISSC_TIMELINE"] = "/tmp/c2s_tl.bin"
-        check(lib.dissc_set_option(b"lin128_dbg", 32), "set")
-        us = bench(31999, 2, 50)
-        check(lib.dissc_set_option(b"lin128_dbg", 0), "set")
+        check(lib.dissc_set_option(b"kernel_dbg", 32), "set")
+        us = bench(31999, 1, 50)
+        check(lib.dissc_set_option(b"kernel_dbg", 0), "set")
         raw = np.fromfile("/tmp/c2s_tl.bin", dtype=np.uint64).reshape(-1, 8)
         raw = raw[raw[:, 2] != 0]
         t0 = raw[:, 0].min()

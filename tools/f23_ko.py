@@ -10,8 +10,8 @@ K = int(os.environ.get("F23_K", "11"))
 for d, epi in ((1, 1), (5, 3)):
     row = []
     for dbg in (0, 1, 2, 4, 3, 7):
-        assert lib.dissc_set_option(b"wino_dbg", dbg) == 0
+        assert lib.dissc_set_option(b"kernel_dbg", dbg) == 0
         check(lib.dissc_pair_bench(32, C, K, d, 80000 * 32 // C, epi, 20, int(os.environ.get("F23_MODE", "3")), ctypes.byref(ms)), "pair_bench")
         row.append(f"dbg={dbg}: {ms.value * 1e3:6.0f}")
-    lib.dissc_set_option(b"wino_dbg", 0)
+    lib.dissc_set_option(b"kernel_dbg", 0)
     print(f"C={C} k={K} d={d} epi={epi} (us):  " + "  ".join(row), flush=True)

@@ -62,30 +62,7 @@ if __name__ == "__main__":
             for v in vals:
                 best[v] = min(best[v], bench(cin, cout, epi, v))
         gf = 2.0 * cin * cout * T * B / 1e9
-        if os.environ.get("LIN128_KO") and name.startswith(("fc1", "fc2")):
-            kos = {}
-            for ko in (1, 2, 4, 8, 16, 18, 23, 31):
-                check(lib.dissc_set_option(b"lin128_dbg", ko), "set")
-                kos[ko] = bench(cin, cout, epi, 2)
-            check(lib.dissc_set_option(b"lin128_dbg", 0), "set")
-            print(f"{name:20s} knock-outs of lin128=2 (us; 1 no A loads, 2 no DMA, 4 no B reads, 8 no epilogue, 16 no barrier): "
-                  + ", ".join(f"{k}: {v:.1f}" for k, v in kos.items()), flush=True)
         print(f"{name:20s} " + " | ".join(f"lin128={v}: {best[v]:6.1f} us {gf / best[v] * 1e3:6.1f} TFLOP/s" for v in vals), flush=True)
-    if os.environ.get("LIN128_STAGGER"):
-        for name, cin, cout, epi in SHAPES[:3]:
-            out = []
-            for st in [0] + [int(v) for v in os.environ["LIN128_STAGGER"].split(",")] + [0]:
-                check(lib.dissc_set_option(b"lin128_stagger", st), "set")
-                out.append(f"{st}: {bench(cin, cout, epi, 2):.1f}")
-            check(lib.dissc_set_option(b"lin128_stagger", 0), "set")
-            print(f"{name:20s} lin128=2, stagger (1024-cycle ticks): us " + ", ".join(out), flush=True)
-    if os.environ.get("LIN128_ONE"):
-        for v in vals[1:]:
-            two = bench(768, 3072, 0, v)
-            check(lib.dissc_set_option(b"lin128_dbg", 64), "set")
-            one = bench(768, 3072, 0, v)
-            check(lib.dissc_set_option(b"lin128_dbg", 0), "set")
-            print(f"fc1, lin128={v}: two workgroups per CU {two:.1f} us, ONE (one wave per SIMD) {one:.1f} us", flush=True)
     if os.environ.get("LIN128_ZERO"):
         for v in vals:
             r, z = bench(768, 3072, 0, v), bench(768, 3072, 0, v, flags=1 | 0x20)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Timeline of one lin128_kernel launch (option lin128_dbg=32: wave 0 of every workgroup stamps the 100 MHz wall clock at its start,
+"""Timeline of one lin128_kernel launch (option kernel_dbg=32: wave 0 of every workgroup stamps the 100 MHz wall clock at its start,
 loop start, loop end, after issuing its stores and after their acknowledgement, plus XCC_ID / HW_ID): how the rounds line up
 on a CU, what a workgroup's prologue / main loop / epilogue take, and when slots are re-filled.
    python tools/lin128_timeline.py [cin cout [stagger]]"""
@@ -16,8 +16,7 @@ ms = ctypes.c_float()
 check(lib.dissc_set_option(b"lin128", 2), "set")
 check(lib.dissc_conv_bench(B, cin, cout, 1, 1, T, 0, 1500, 1, ctypes.byref(ms)), "warm")
 print(f"{cin}->{cout}: {ms.value * 1e3:.1f} us per launch (sustained, no stamps)")
-check(lib.dissc_set_option(b"lin128_dbg", 32), "set")
-check(lib.dissc_set_option(b"lin128_stagger", stagger), "set")
+check(lib.dissc_set_option(b"kernel_dbg", 32), "set")
 os.environ["DISSC_TIMELINE"] = "/tmp/lin128_tl.bin"
 check(lib.dissc_conv_bench(B, cin, cout, 1, 1, T, 0, 200, 1, ctypes.byref(ms)), "stamped")
 print(f"with stamps: {ms.value * 1e3:.1f} us per launch")

@@ -2,6 +2,7 @@
 """Pin the three stages whose arithmetic lives in un-vendored third parties -- in ONE command, wherever those
 libraries can be imported (they cannot in the build container: no network).
 
+    python tools/pin_third_party.py --check          # what is importable here, the pins the reference names, what would be written
     python tools/pin_third_party.py [--only hubert,yaapt,resample] [--out tests/golden] [--no-tests] [--gpu]
                                     [--real-encoder] [--checkpoint-dir DIR]
 
@@ -216,8 +217,56 @@ def pin_real_encoder(out_dir, golden_dir):
     return path
 
 
+# stage -> (libraries, how the reference installs them, the file the stage writes, the tests of tests/test_third_party_pins.py it un-skips,
+#           the SURVEY rows that stop being "parity unpinned")
+PLAN = {
+    "hubert": (["fairseq", "sklearn"],
+               "pip install git+https://github.com/facebookresearch/fairseq.git@dd106d9534b22e7db859a6b87ffd7780c38341f8   "
+               "(reference README.md:34; scikit-learn: any, comes with textlesslib)",
+               "hubert_fairseq.npz", ["test_oracle_hubert_matches_fairseq", "test_hip_hubert_matches_fairseq (-m gpu)"], "a2, a3, a4"),
+    "yaapt": (["amfm_decompy"],
+              "pip install AMFM-decompy   (unpinned by the reference: a dependency of textlesslib, imported at sr/dataset.py:14-15, "
+              "eval.py:11-12; the file records the version used)",
+              "yaapt_amfm.npz", ["test_oracle_yaapt_matches_amfm_decompy", "test_hip_yaapt_matches_amfm_decompy (-m gpu)"], "a5, N2"),
+    "resample": (["resampy", "librosa"],
+                 "pip install resampy librosa   (unpinned by the reference: data/preprocess.py:13,15, sr/dataset.py:226, "
+                 "sr/inference.py:20; the file records the versions used)",
+                 "resample_resampy.npz", ["test_oracle_resampler_and_trim_match_resampy_librosa", "test_hip_resampler_matches_resampy (-m gpu)"], "N3"),
+    "real-encoder": (["textless", "fairseq"],
+                     "git clone https://github.com/facebookresearch/textlesslib.git && cd textlesslib && pip install -e .   (reference "
+                     "README.md:30-33) + the fairseq pin above; needs the hubert-base-ls960 / km100 downloads (--checkpoint-dir)",
+                     "hubert_textless_real.npz", ["test_hip_encoder_matches_textless_with_the_real_checkpoints (-m gpu, $DISSC_CHECKPOINT_DIR)"],
+                     "a2-a4 against the reference's literal call (data/encode.py:21-22,32)"),
+}
+
+
+def check(out_dir):
+    """--check: nothing is written.  Per stage: is every library importable here (and which version), the exact install line the
+    reference names, the file a run would write, whether it already exists, and the tests / SURVEY rows it un-skips."""
+    ready = []
+    for stage, (libs, pin, fname, tests, rows) in PLAN.items():
+        print(f"[{stage}]" + (" (only with --real-encoder)" if stage == "real-encoder" else ""))
+        ok = True
+        for lib in libs:
+            m = _try(lib)
+            if m is None:
+                ok = False
+            else:
+                print(f"  {lib} {_version(m)} imports")
+        path = os.path.join(out_dir, fname)
+        print(f"  reference install: {pin}")
+        print(f"  writes: {path}" + ("   (exists: would be overwritten)" if os.path.exists(path) else "   (absent: its tests skip today)"))
+        print(f"  un-skips: {'; '.join(tests)}  -> SURVEY rows {rows}")
+        print(f"  => {'READY: run without --check' if ok else 'not possible here (library absent): nothing would be written for this stage'}")
+        if ok:
+            ready.append(stage)
+    print(f"ready here: {ready or 'none'}; commit the files written into tests/golden/ to turn the rows into pinned ones")
+    return 0
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--check", action="store_true", help="dry run: per library, what imports here, the reference's pin, the file and tests")
     ap.add_argument("--only", default="hubert,yaapt,resample")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--no-tests", action="store_true", help="write the files only")
@@ -225,6 +274,8 @@ def main(argv=None):
     ap.add_argument("--real-encoder", action="store_true", help="also pin textless' SpeechEncoder with the real checkpoints")
     ap.add_argument("--checkpoint-dir", default=os.environ.get("DISSC_CHECKPOINT_DIR"))
     a = ap.parse_args(argv)
+    if a.check:
+        return check(a.out)
     golden = os.path.join(ROOT, "tests", "golden")
     os.makedirs(a.out, exist_ok=True)
     want = [w.strip() for w in a.only.split(",") if w.strip()]

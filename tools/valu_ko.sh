@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 for d in 1 4 5; do
-  EXTRA_OPTS=wino8_dbg=$d bash tools/valu_share.sh valu_gen_dbg$d gen
+  EXTRA_OPTS=kernel_dbg=$d bash tools/valu_share.sh valu_gen_dbg$d gen
 done

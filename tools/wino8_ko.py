@@ -11,9 +11,9 @@ shapes = ((256, 2500, 11, 1, 0, 4), (256, 2500, 11, 5, 0, 4), (128, 10000, 7, 1,
 for C, L, k, d, epi, flag in shapes:  # flag 4: F(6,3), 12: F(5,4)
     row = []
     for dbg in (0, 1, 2, 4, 3, 6, 7):
-        assert lib.dissc_set_option(b"wino8_dbg", dbg) == 0
+        assert lib.dissc_set_option(b"kernel_dbg", dbg) == 0
         check(lib.dissc_conv_bench(32, C, C, k, d, L, epi, 10, flag, ctypes.byref(ms)), "conv_bench")
         row.append(f"dbg={dbg}: {ms.value * 1e3:6.0f}")
-    lib.dissc_set_option(b"wino8_dbg", 0)
+    lib.dissc_set_option(b"kernel_dbg", 0)
     check(lib.dissc_conv_bench(32, C, C, k, d, L, epi, 10, 2, ctypes.byref(ms)), "conv_bench")
     print(f"C={C} L={L} k={k} d={d} epi={epi} {'F(5,4)' if flag == 12 else 'F(6,3)'} (us):  " + "  ".join(row) + f"   | F(4,3): {ms.value * 1e3:6.0f}", flush=True)

@@ -13,7 +13,7 @@ for C, k, d, Ln in shapes:
     check(L.dissc_set_option(b"wino_cpr", cpr), "opt")
     out = [f"cpr{cpr}"]
     for dbg in [int(x) for x in os.environ.get('WINO_DBGS', '0,1,2,4,8,13,6,15').split(',')]:
-        check(L.dissc_set_option(b"wino_dbg", dbg), "opt")
+        check(L.dissc_set_option(b"kernel_dbg", dbg), "opt")
         ms = ctypes.c_float()
         best = 1e9
         for rep in range(2):
