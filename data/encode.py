@@ -108,7 +108,7 @@ def partial_fingerprint(args):
 
 
 def partial_header(args):
-    return (json.dumps({"dissc_encode_partial": 1, "fingerprint": partial_fingerprint(args)}) + "\n").encode()
+    return (json.dumps({"dissc_encode_partial": 2, "fingerprint": partial_fingerprint(args)}) + "\n").encode()
 
 
 def main(argv=None):
@@ -159,9 +159,18 @@ def main(argv=None):
     partial = str(args.out_file) + '.partial'
     commit = partial + '.commit'  # exists while the ordered lines are being appended to out_file: {"out_size_before": N}
     if os.path.exists(commit):
-        # the previous run died INSIDE the final append: undo the torn append, so that the rerun cannot duplicate lines
+        # the previous run died INSIDE the final append: undo the torn append, so that the rerun cannot duplicate lines -- unless the
+        # append had been completed and fsynced (commit says "done": only the clean-up was missing; rolling that back would
+        # re-encode the whole directory for nothing)
         try:
-            before = int(json.load(open(commit))["out_size_before"])
+            cj = json.load(open(commit))
+            before = int(cj["out_size_before"])
+            if cj.get("done") and os.path.exists(args.out_file) and os.path.getsize(args.out_file) == int(cj.get("out_size_after", -1)):
+                for leftover in (partial, commit):
+                    if os.path.exists(leftover):
+                        os.remove(leftover)
+                print(f"{args.out_file}: the previous run had finished its append ({cj['out_size_after']} bytes); cleaned up, nothing to do")
+                return
             if os.path.exists(args.out_file) and os.path.getsize(args.out_file) > before:
                 with open(args.out_file, 'r+b') as fo:
                     fo.truncate(before)
@@ -184,16 +193,20 @@ def main(argv=None):
                     off, raw = fi.tell(), fi.readline()
                     if not raw:
                         break
+                    # a .partial line is "<decoded sample count>\t<manifest line>": the count the batch was really encoded from (a
+                    # header that disagrees with its data must not make the line look foreign on every resume)
                     try:
-                        d = json.loads(raw) if raw.endswith(b"\n") else None
+                        head, _, body = raw.partition(b"\t")
+                        n_dec = int(head)
+                        d = json.loads(body) if body.endswith(b"\n") else None
                         name = d["audio"] if d is not None else None
                     except (ValueError, KeyError, TypeError):
                         name = None
                     if name is None:  # a torn last line: cut it off
                         break
-                    # (a line whose unit count does not fit this file's sample count is not this file's: encode it again)
-                    if name in lengths and len(d.get("units", ())) == _lib.dissc_hubert_frames(int(lengths[name])):
-                        where[name] = (off, len(raw))
+                    # (a line whose unit count does not fit the samples it was encoded from is not a whole line: encode the file again)
+                    if name in lengths and len(d.get("units", ())) == _lib.dissc_hubert_frames(n_dec):
+                        where[name] = (off + len(head) + 1, len(body))
                     good = off + len(raw)
         if good == 0:
             os.remove(partial)
@@ -232,8 +245,9 @@ def main(argv=None):
                 u = units[k, :T].tolist()
                 f0 = f0s[k] if f0s is not None else [0.0] * T
                 raw = (json.dumps({"units": u, "f0": f0, "durations": [1] * T, "audio": f}) + "\n").encode()
-                where[f] = (fo.tell(), len(raw))
-                fo.write(raw)
+                pre = b"%d\t" % int(ns[k])
+                where[f] = (fo.tell() + len(pre), len(raw))
+                fo.write(pre + raw)
         tm.add('json_lines')
     if where:
         # appended like the reference's per-line 'a+' -- but a crash inside this phase must not leave half an append that the
@@ -250,6 +264,10 @@ def main(argv=None):
                     fo.write(fi.read(where[f][1]))
             fo.flush()
             os.fsync(fo.fileno())
+        with open(commit, 'w') as fc:  # the append is complete and on disk: a crash from here on must not roll it back
+            json.dump({"out_size_before": before, "done": True, "out_size_after": os.path.getsize(args.out_file)}, fc)
+            fc.flush()
+            os.fsync(fc.fileno())
     if os.path.exists(partial):
         os.remove(partial)
     if os.path.exists(commit):

@@ -438,12 +438,16 @@ static int launch32_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
     while (mt % mg) --mg;  // whole sweeps only: a short last sweep would add a partly filled round of workgroups (qkv, 9 M tiles
                            // in sweeps of 4 + 4 + 1: 467 -> 609 us)
     if (opts().xcd_mg > 0) mg = opts().xcd_mg < mt ? opts().xcd_mg : mt;
-    a.xcd_ntile = (int)grid.x;
-    a.xcd_nb = B;
-    a.xcd_mg = mg;
     const long long tt_pad = ((long long)grid.x * B + 7) / 8 * 8;
-    a.xcd_span = (int)(tt_pad * mg);
-    grid = dim3((unsigned)(tt_pad * mg * ((mt + mg - 1) / mg)), 1, 1);
+    if (tt_pad * mg * ((mt + mg - 1) / mg) > 0x7fffffffLL) {
+      a.xcd = 0;  // beyond a 1-D grid (the 2^31-element probes): keep the 3-D grid, B on z
+    } else {
+      a.xcd_ntile = (int)grid.x;
+      a.xcd_nb = B;
+      a.xcd_mg = mg;
+      a.xcd_span = (int)(tt_pad * mg);
+      grid = dim3((unsigned)(tt_pad * mg * ((mt + mg - 1) / mg)), 1, 1);
+    }
   }
   size_t lds_f = (size_t)2 * KC * CPB * a.XW;
   if (lds_f < (size_t)NW * 8 * CW) lds_f = (size_t)NW * 8 * CW;

@@ -695,7 +695,9 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
 #if DISSC_EXPERIMENTAL  // k = 3 through this kernel: only the C = 64, d = 1 shape on two-per-CU tiles is a default (wino8_mask); the rest
   DISSC_W8(3, 1, 1) DISSC_W8(3, 1, 3) DISSC_W8(3, 1, 5)  // measured neutral and is only in DISSC_EXPERIMENTAL=1 builds
 #else
-  if (R == 3 && ns == 1 && dc.dil == 1 && dc.M == 64 && c64_mode == 2) return launch_wino8_t<1, 1, 2, 2, 4, 3>(a, B, Lmax, stream);
+  // (the default build carries ONE k = 3 instance -- C = 64, d = 1 on the two-per-CU tiles: "wino8_c64_wide" does not apply to it,
+  //  a handle created under another tile mode runs this instance instead of failing every forward: ADVICE r05)
+  if (R == 3 && ns == 1 && dc.dil == 1 && dc.M == 64) return launch_wino8_t<1, 1, 2, 2, 4, 3>(a, B, Lmax, stream);
   if (R == 3 && ns == 1) {
     set_error("run_wino8: k = 3 with C = %d, dilation %d, tile mode %d is only in DISSC_EXPERIMENTAL=1 builds", dc.M, dc.dil, c64_mode);
     return DISSC_EINVAL;

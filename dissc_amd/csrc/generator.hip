@@ -218,10 +218,32 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
   // pre-sized slot of the handle; a worker carries the creating thread's device, options snapshot and packing precision.
   std::vector<std::function<int()>> tasks;
   auto run_pack_tasks = [&]() -> int {
+    // default: min(8, the CPUs this process may really use / ranks on the node) -- hardware_concurrency() knows neither the cgroup
+    // CPU quota (the GPU boxes: 16 of 256 logical CPUs) nor that 8 ranks create handles at once
     int nthr = 8;
-    if (const char* e = getenv("DISSC_PACK_THREADS")) nthr = atoi(e);
-    const unsigned hc = std::thread::hardware_concurrency();
-    if (hc && nthr > (int)hc) nthr = (int)hc;
+    {
+      double cpus = (double)std::thread::hardware_concurrency();
+      if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        long long per = 0;
+        if (fscanf(f, "%31s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+          const double quota = atof(q) / (double)per;
+          if (quota >= 1.0 && (cpus <= 0 || quota < cpus)) cpus = quota;
+        }
+        fclose(f);
+      }
+      int ranks = 1;
+      if (const char* e = getenv("LOCAL_WORLD_SIZE")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 1024) ranks = (int)v;
+      }
+      if (cpus >= 1.0 && nthr > (int)(cpus / ranks)) nthr = (int)(cpus / ranks) > 1 ? (int)(cpus / ranks) : 1;
+    }
+    if (const char* e = getenv("DISSC_PACK_THREADS")) {  // explicit override, validated
+      char* end = nullptr;
+      const long v = strtol(e, &end, 10);
+      if (end != e && *end == 0 && v >= 1 && v <= 256) nthr = (int)v;
+    }
     if (nthr > (int)tasks.size()) nthr = (int)tasks.size();
     if (nthr <= 1) {
       for (auto& t : tasks)
@@ -247,6 +269,9 @@ int dissc_gen_create_ex(const DisscGenConfig* cfg, const DisscTensor* weights, s
           r = tasks[i]();
         } catch (const std::exception& e) {  // (an exception leaving a std::thread would terminate the process)
           set_error("dissc_gen_create: packing a layer failed: %s", e.what());
+          r = DISSC_ENOMEM;
+        } catch (...) {
+          set_error("dissc_gen_create: packing a layer failed (unknown exception)");
           r = DISSC_ENOMEM;
         }
         if (r != DISSC_OK) {

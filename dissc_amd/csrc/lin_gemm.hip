@@ -690,12 +690,12 @@ static int launch_conv2s128_t(ConvArgs a, int B, int Lmax_out, hipStream_t strea
 
 int launch_conv2s128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream) {
   if (opts().kernel_dbg == 32) return launch_conv2s128_t<32, 2, 32>(a, B, Lmax_out, stream);  // timeline stamps (tools/conv2s128_gate.py)
-  switch (opts().conv2s128) {
-    // (2, the compiler-scheduled form with per-lane 64-bit addresses -- conv1 6 146 us where this one takes 5 715 -- is on record in
-    //  profiles/r06/conv2s128_gate_v3.txt and no longer instantiated)
-    case 3: return launch_conv2s128_t<16, 2, 0, true>(a, B, Lmax_out, stream);
-    default: return launch_conv2s128_t<32, 2, 0, true>(a, B, Lmax_out, stream);
-  }
+  // "conv2s128": 1 = 16 channels per barrier (default: conv1..4 10.76 ms against 10.80 with 32, profiles/r06/conv2s128_gate_v3.txt), 3 = 32.
+  // (2, the compiler-scheduled form with per-lane 64-bit addresses -- conv1 6 146 us where this one takes 5 715 -- is on record in
+  //  the same file and no longer instantiated)
+  if (opts().conv2s128 == 3) return launch_conv2s128_t<32, 2, 0, true>(a, B, Lmax_out, stream);
+  return launch_conv2s128_t<16, 2, 0, true>(a, B, Lmax_out, stream);
+}
 }
 
 }  // namespace dissc

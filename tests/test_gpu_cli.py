@@ -218,7 +218,7 @@ def test_encode_cli_roundtrip(gpu, golden_dir, tmp_path):
     ns = argparse.Namespace(base_dir=f"{td}/wav", model_name="hubert-base-ls960", quantizer_name="kmeans", vocab_size=100,
                             f0="yaapt", checkpoint_dir=f"{td}/ckpt")
     with open(f"{td}/out/enc2.txt.partial", "wb") as f:
-        f.write(cli.partial_header(ns) + (json.dumps(marked) + "\n" + '{"units": [1, 2').encode())
+        f.write(cli.partial_header(ns) + ("32000\t" + json.dumps(marked) + "\n" + '32000\t{"units": [1, 2').encode())  # "<samples>\t<line>"
     cli.main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/out/enc2.txt", "--checkpoint_dir", f"{td}/ckpt"])
     again = [json.loads(x) for x in open(f"{td}/out/enc2.txt").read().strip().split("\n")]
     assert [d["audio"] for d in again] == [d["audio"] for d in lines]
@@ -228,12 +228,12 @@ def test_encode_cli_roundtrip(gpu, golden_dir, tmp_path):
     # unit count) is not spliced in; and an append that was interrupted is rolled back instead of repeated
     stale = dict(first, durations=[9] * 99)
     with open(f"{td}/out/enc3.txt.partial", "wb") as f:
-        f.write(cli.partial_header(argparse.Namespace(**dict(vars(ns), f0="zeros"))) + (json.dumps(stale) + "\n").encode())
+        f.write(cli.partial_header(argparse.Namespace(**dict(vars(ns), f0="zeros"))) + ("32000\t" + json.dumps(stale) + "\n").encode())
     cli.main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/out/enc3.txt", "--checkpoint_dir", f"{td}/ckpt"])
     assert [json.loads(x) for x in open(f"{td}/out/enc3.txt").read().strip().split("\n")] == lines
     short = dict(first, units=first["units"][:50])
     with open(f"{td}/out/enc4.txt.partial", "wb") as f:
-        f.write(cli.partial_header(ns) + (json.dumps(short) + "\n").encode())
+        f.write(cli.partial_header(ns) + ("32000\t" + json.dumps(short) + "\n").encode())
     with open(f"{td}/out/enc4.txt", "w") as f:
         f.write("kept\n" + json.dumps(first)[:40])      # a torn append of a dead run ...
     with open(f"{td}/out/enc4.txt.partial.commit", "w") as f:
@@ -242,6 +242,23 @@ def test_encode_cli_roundtrip(gpu, golden_dir, tmp_path):
     got = open(f"{td}/out/enc4.txt").read().strip().split("\n")
     assert got[0] == "kept" and [json.loads(x) for x in got[1:]] == lines
     assert not os.path.exists(f"{td}/out/enc4.txt.partial.commit")
+    # (a) the line is validated against the DECODED sample count it was encoded from, stored in front of it -- a wav whose
+    # header disagrees with its data is accepted on resume; (b) a run that died after its append was complete and fsynced (commit
+    # says "done") is cleaned up, not rolled back and re-encoded
+    lying = dict(first, units=first["units"][:50], f0=first["f0"][:50], durations=[3] * 50)   # encoded from 16 320 samples, says the line
+    with open(f"{td}/out/enc5.txt.partial", "wb") as f:
+        f.write(cli.partial_header(ns) + ("16320\t" + json.dumps(lying) + "\n").encode())
+    cli.main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/out/enc5.txt", "--checkpoint_dir", f"{td}/ckpt"])
+    got5 = [json.loads(x) for x in open(f"{td}/out/enc5.txt").read().strip().split("\n")]
+    assert got5[0] == lying and got5[1] == lines[1]
+    done_text = open(f"{td}/out/enc5.txt").read()
+    with open(f"{td}/out/enc5.txt.partial", "wb") as f:
+        f.write(cli.partial_header(ns))
+    with open(f"{td}/out/enc5.txt.partial.commit", "w") as f:
+        json.dump({"out_size_before": 0, "done": True, "out_size_after": len(done_text.encode())}, f)
+    cli.main(["--base_dir", f"{td}/wav", "--out_file", f"{td}/out/enc5.txt", "--checkpoint_dir", f"{td}/ckpt"])
+    assert open(f"{td}/out/enc5.txt").read() == done_text
+    assert not os.path.exists(f"{td}/out/enc5.txt.partial") and not os.path.exists(f"{td}/out/enc5.txt.partial.commit")
 
 
 def test_in_memory_converter_equals_file_pipeline(gpu, golden_dir, tmp_path):

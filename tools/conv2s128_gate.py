@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Gate of conv2s128_kernel (csrc/lin_gemm.hip): HuBERT's stride-2, k = 3 feature convs (conv1 .. conv4, B = 32 x 10 s) through
-dissc_conv_s2_bench under conv2s128 = 0 (conv_mfma32_kernel, 256 x 64 tiles) / 1 (32 channels per barrier) / 3 (16), sustained, alternating -- and the error of both
+dissc_conv_s2_bench under conv2s128 = 0 (conv_mfma32_kernel, 256 x 64 tiles) / 1 (16 channels per barrier) / 3 (32), sustained, alternating -- and the error of both
 kernels against a float64 convolution (ragged lengths, NaN-poisoned padding; another K order: not bit-identical, same error level).
    python tools/conv2s128_gate.py [variants ...]      (default: 0 1 3)"""
 import ctypes, os, sys
