@@ -696,6 +696,5 @@ int launch_conv2s128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream)
   if (opts().conv2s128 == 3) return launch_conv2s128_t<32, 2, 0, true>(a, B, Lmax_out, stream);
   return launch_conv2s128_t<16, 2, 0, true>(a, B, Lmax_out, stream);
 }
-}
 
 }  // namespace dissc
