@@ -13,5 +13,5 @@ run() {  # name, command...
   echo "$name rc=$?"
 }
 run yaapt python $ROOT/tools/yaapt_bench.py
-run pipeline python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split-bf16 --no-strong --no-d2h
+run pipeline python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split-bf16 --no-strong --no-d2h --no-latency
 find "$OUT" -name "*kernel_stats.csv"

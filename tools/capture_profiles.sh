@@ -9,9 +9,9 @@ OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/$1
 WHAT=$2
 mkdir -p "$OUT"
 if [ "$WHAT" = gen ]; then
-  CMD="python ${GRAFT_REPO_ROOT:-$PWD}/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-split-bf16 --no-pipeline --no-strong --no-d2h"
+  CMD="python ${GRAFT_REPO_ROOT:-$PWD}/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-split-bf16 --no-pipeline --no-strong --no-d2h --no-latency"
 else
-  CMD="python ${GRAFT_REPO_ROOT:-$PWD}/tools/encode_bench.py --iters 3"
+  CMD="python ${GRAFT_REPO_ROOT:-$PWD}/tools/encode_bench.py --iters 8"
 fi
 cd /tmp && export TMPDIR=/tmp
 export DISSC_OPTIONS=multistream=0${EXTRA_OPTS:+,$EXTRA_OPTS}
@@ -21,6 +21,10 @@ run() {  # name, rocprof args...
   echo "$name rc=$?"
 }
 run trace --kernel-trace --stats
+# the BENCHED schedule (multistream=1: parallel streams), kernel trace only: its wall span per forward closes the check "kernel time
+# per step <= ms_per_step" from files alone (tools/trace_span.py; round 5 verdict, item 5)
+DISSC_OPTIONS=${EXTRA_OPTS:-} run trace_ms --kernel-trace
+export DISSC_OPTIONS=multistream=0${EXTRA_OPTS:+,$EXTRA_OPTS}
 run sq --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 run fetch --kernel-trace --pmc FETCH_SIZE
 run write --kernel-trace --pmc WRITE_SIZE
