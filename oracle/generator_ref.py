@@ -58,13 +58,20 @@ def embed_concat(w, code, f0, spkr):
     Channel order [code-emb 128 | f0 1 | spkr-emb 128]
     (reference sr/models.py:189,207-215)."""
     x = F.embedding(code, w["dict.weight"]).transpose(1, 2)
+
+    def upsample(sig, n):
+        # reference _upsample (sr/models.py:158-177): integer repeat along time only
+        if n % sig.shape[-1] != 0:
+            raise NotImplementedError("Padding condition signal - misalignment between condition features.")
+        return sig.repeat_interleave(n // sig.shape[-1], dim=-1)
+
+    # reference sr/models.py:206-210: the SHORTER of the two streams is repeated up to the longer one -- the embedded code stream when
+    # it is shorter than f0 (a coarser unit rate), else f0
+    if x.shape[-1] < f0.shape[-1]:
+        x = upsample(x, f0.shape[-1])
+    elif f0.shape[-1] != x.shape[-1]:
+        f0 = upsample(f0, x.shape[-1])
     T = x.shape[-1]
-    if f0.shape[-1] != T:
-        # reference _upsample (sr/models.py:158-177): integer repeat only
-        if T % f0.shape[-1] != 0:
-            raise NotImplementedError(
-                "Padding condition signal - misalignment between condition features.")
-        f0 = f0.repeat_interleave(T // f0.shape[-1], dim=-1)
     x = torch.cat([x, f0], dim=1)
     s = F.embedding(spkr, w["spkr.weight"]).transpose(1, 2)  # [1,128,1]
     x = torch.cat([x, s.expand(-1, -1, T)], dim=1)

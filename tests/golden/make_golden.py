@@ -641,7 +641,27 @@ def make_train():
     print("train.npz", len(out), "arrays")
 
 
-TARGETS = {"train": make_train, "prep_dataset": make_prep_dataset, "hubert": make_hubert, "sr_inference": make_sr_inference,
+def make_upsample():
+    """CodeGenerator.forward's `_upsample` branches (reference sr/models.py:206-210): the code stream shorter than f0 and f0 shorter
+    than the code stream, by integer factors -> gen_upsample.npz (inputs + the reference's waveforms)"""
+    ref_models, ref_utils = _import_ref_sr()
+    h = ref_utils.AttrDict(json.load(open(os.path.join(REF, "sr/configs/VCTK/hubert100_lut.json"))))
+    g = ref_models.CodeGenerator(h)
+    g.load_state_dict(synth.synth_generator_state_dict(seed=0), strict=True)
+    g.eval()
+    g.remove_weight_norm()
+    out = {}
+    code, f0, spkr, _ = synth.synth_generator_inputs(1, 24, seed=4242)
+    cases = {"code_short": (code[:, :12], f0[:, :, :24]), "f0_short": (code[:, :24], f0[:, :, :8]), "code_short3": (code[:, :5], f0[:, :, :15])}
+    for name, (c, f) in cases.items():
+        with torch.no_grad():
+            y = g(code=torch.from_numpy(np.ascontiguousarray(c)), f0=torch.from_numpy(np.ascontiguousarray(f)), spkr=torch.from_numpy(spkr))
+        out[f"{name}/code"], out[f"{name}/f0"], out[f"{name}/spkr"], out[f"{name}/wav"] = c, f, spkr, y.numpy()
+    np.savez_compressed(os.path.join(OUT, "gen_upsample.npz"), **out)
+    print("gen_upsample.npz", {k: v.shape for k, v in out.items() if k.endswith("wav")})
+
+
+TARGETS = {"upsample": make_upsample, "train": make_train, "prep_dataset": make_prep_dataset, "hubert": make_hubert, "sr_inference": make_sr_inference,
            "generator": make_generator, "predictors": make_predictors}
 
 if __name__ == "__main__":

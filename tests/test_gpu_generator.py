@@ -252,6 +252,17 @@ def test_generator_matches_reference_golden(env, golden_dir, T):
     assert np.abs(err).max() <= 1e-3
 
 
+@pytest.mark.parametrize("case", ["code_short", "f0_short", "code_short3"])
+def test_generator_upsample_branches_match_reference_golden(env, golden_dir, case):
+    """`_upsample` of the shorter stream (code OR f0; reference sr/models.py:206-210) in the HIP path's front end"""
+    gold = np.load(os.path.join(golden_dir, "gen_upsample.npz"))
+    y = env["g"](code=torch.from_numpy(gold[f"{case}/code"]), f0=torch.from_numpy(gold[f"{case}/f0"]),
+                 spkr=torch.from_numpy(gold[f"{case}/spkr"])).cpu().numpy()
+    ref = gold[f"{case}/wav"]
+    assert y.shape == ref.shape
+    assert _rms(y - ref) <= FP32_GUARD_RMS, _rms(y - ref)
+
+
 def test_generator_ragged_batch_matches_reference_golden(env, golden_dir):
     gold = np.load(os.path.join(golden_dir, "gen_vctk.npz"))
     code, f0, spkr, _ = env["synth"].synth_generator_inputs(4, 40, seed=777)
