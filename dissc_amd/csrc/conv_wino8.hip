@@ -682,13 +682,20 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
   // 16-32 workgroups on 256 CUs, each walking the whole K loop (B = 1: 240 us per k = 11 launch of the first stage); below one
   // workgroup per two CUs the launch steps down to 64-row tiles on two workgroups per CU.  Same column tiles (NI), so the same unit
   // grid and the same MFMA and transform sequence per output: bit-identical, an utterance's samples stay independent of its batch.
-#define DISSC_W8_SMALL(R_, NS_, D_)                                                                  \
-  (opts().small_grid &&                                                                              \
-   (long long)((Lmax + Wino8Geo<NS_, D_, 4, 2, 2, R_>::OT - 1) / Wino8Geo<NS_, D_, 4, 2, 2, R_>::OT) * (dc.M / 128) * B < 128)
+#define DISSC_W8_NWG(R_, NS_, D_) \
+  ((long long)((Lmax + Wino8Geo<NS_, D_, 4, 2, 2, R_>::OT - 1) / Wino8Geo<NS_, D_, 4, 2, 2, R_>::OT) * (dc.M / 128) * B)
+  // ... below one workgroup per four CUs to 64 rows x 32 columns (NI = 1), below one per eight to 32 x 32: every tile still starts
+  // on a multiple of the unit width MO D, so the global unit grid -- and with it every output's arithmetic -- is unchanged.
+  // B = 1 x 10 s (tools/batch_scaling.py): 3.78 ms (128-row tiles only) -> 3.35 -> 2.60 (NI = 1) -> see NOTES round 6.
 #define DISSC_W8(R_, NS_, D_)                                                                        \
   if (R == R_ && ns == NS_ && dc.dil == D_)                                                          \
-    return dc.M >= 128 ? (DISSC_W8_SMALL(R_, NS_, D_) ? launch_wino8_t<NS_, D_, 2, 2, 4, R_>(a, B, Lmax, stream)  \
-                                                      : launch_wino8_t<NS_, D_, 4, 2, 2, R_>(a, B, Lmax, stream)) \
+    return dc.M >= 128 ? ((opts().small_grid && DISSC_W8_NWG(R_, NS_, D_) < 32)                      \
+                              ? launch_wino8_t<NS_, D_, 1, 1, 4, R_>(a, B, Lmax, stream)             \
+                          : (opts().small_grid && DISSC_W8_NWG(R_, NS_, D_) < 64)                    \
+                              ? launch_wino8_t<NS_, D_, 2, 1, 4, R_>(a, B, Lmax, stream)             \
+                          : (opts().small_grid && DISSC_W8_NWG(R_, NS_, D_) < 128)                   \
+                              ? launch_wino8_t<NS_, D_, 2, 2, 4, R_>(a, B, Lmax, stream)             \
+                              : launch_wino8_t<NS_, D_, 4, 2, 2, R_>(a, B, Lmax, stream))            \
                        : (c64_mode == 1 ? launch_wino8_t<NS_, D_, 2, 4, 2, R_>(a, B, Lmax, stream)  \
                           : c64_mode == 2 ? launch_wino8_t<NS_, D_, 2, 2, 4, R_>(a, B, Lmax, stream) \
                                           : launch_wino8_t<NS_, D_, 2, 2, 2, R_>(a, B, Lmax, stream));
@@ -707,7 +714,7 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
   DISSC_W8(3, 4, 1) DISSC_W8(3, 4, 3) DISSC_W8(3, 4, 5)
   DISSC_W8(4, 2, 1) DISSC_W8(4, 2, 3) DISSC_W8(4, 2, 5) DISSC_W8(4, 3, 1) DISSC_W8(4, 3, 3) DISSC_W8(4, 3, 5)
 #undef DISSC_W8
-#undef DISSC_W8_SMALL
+#undef DISSC_W8_NWG
   set_error("run_wino8: k = %d, dilation %d unsupported", dc.KS, dc.dil);
   return DISSC_EINVAL;
 }
