@@ -687,6 +687,8 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
   // ... below one workgroup per four CUs to 64 rows x 32 columns (NI = 1), below one per eight to 32 x 32: every tile still starts
   // on a multiple of the unit width MO D, so the global unit grid -- and with it every output's arithmetic -- is unchanged.
   // B = 1 x 10 s (tools/batch_scaling.py): 3.78 ms (128-row tiles only) -> 3.35 -> 2.60 (NI = 1) -> see NOTES round 6.
+#define DISSC_W8_NWG64(R_, NS_, D_) \
+  ((long long)((Lmax + Wino8Geo<NS_, D_, 2, 2, 4, R_>::OT - 1) / Wino8Geo<NS_, D_, 2, 2, 4, R_>::OT) * (dc.M / 64) * B)
 #define DISSC_W8(R_, NS_, D_)                                                                        \
   if (R == R_ && ns == NS_ && dc.dil == D_)                                                          \
     return dc.M >= 128 ? ((opts().small_grid && DISSC_W8_NWG(R_, NS_, D_) < 32)                      \
@@ -696,6 +698,8 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
                           : (opts().small_grid && DISSC_W8_NWG(R_, NS_, D_) < 128)                   \
                               ? launch_wino8_t<NS_, D_, 2, 2, 4, R_>(a, B, Lmax, stream)             \
                               : launch_wino8_t<NS_, D_, 4, 2, 2, R_>(a, B, Lmax, stream))            \
+                       : (opts().small_grid && DISSC_W8_NWG64(R_, NS_, D_) < 192)                     \
+                          ? launch_wino8_t<NS_, D_, 1, 1, 4, R_>(a, B, Lmax, stream)                 \
                        : (c64_mode == 1 ? launch_wino8_t<NS_, D_, 2, 4, 2, R_>(a, B, Lmax, stream)  \
                           : c64_mode == 2 ? launch_wino8_t<NS_, D_, 2, 2, 4, R_>(a, B, Lmax, stream) \
                                           : launch_wino8_t<NS_, D_, 2, 2, 2, R_>(a, B, Lmax, stream));
@@ -704,7 +708,7 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
 #else
   // (the default build carries ONE k = 3 instance -- C = 64, d = 1 on the two-per-CU tiles: "wino8_c64_wide" does not apply to it,
   //  a handle created under another tile mode runs this instance instead of failing every forward: ADVICE r05)
-  if (R == 3 && ns == 1 && dc.dil == 1 && dc.M == 64) return launch_wino8_t<1, 1, 2, 2, 4, 3>(a, B, Lmax, stream);
+  if (R == 3 && ns == 1 && dc.dil == 1 && dc.M == 64) return launch_wino8_t<1, 1, 2, 2, 4, 3>(a, B, Lmax, stream);  // (no small-grid tier: 36 us at B = 1)
   if (R == 3 && ns == 1) {
     set_error("run_wino8: k = 3 with C = %d, dilation %d, tile mode %d is only in DISSC_EXPERIMENTAL=1 builds", dc.M, dc.dil, c64_mode);
     return DISSC_EINVAL;
@@ -715,6 +719,7 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
   DISSC_W8(4, 2, 1) DISSC_W8(4, 2, 3) DISSC_W8(4, 2, 5) DISSC_W8(4, 3, 1) DISSC_W8(4, 3, 3) DISSC_W8(4, 3, 5)
 #undef DISSC_W8
 #undef DISSC_W8_NWG
+#undef DISSC_W8_NWG64
   set_error("run_wino8: k = %d, dilation %d unsupported", dc.KS, dc.dil);
   return DISSC_EINVAL;
 }
