@@ -46,6 +46,10 @@ template <int N>
 __device__ __forceinline__ void vm_wait(f32x4& r0, f32x4& r1) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(N));
 }
+template <int N>
+__device__ __forceinline__ void vm_wait(f32x4& r0) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0) : "n"(N));
+}
 
 // The epilogue of one wave: rows (ms0 + mi) * 32 + 8 j + 4 h + i (register r = 4 j + i of block mi), four consecutive frames per lane.
 // Every load is issued before anything depends on it: the 32 bias values (and the affine pair) as float4s -- rows 8 j + 4 h .. + 3 are
@@ -432,9 +436,9 @@ int launch_lin128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream) {
 // DBG (option "kernel_dbg", diagnostics): bit 0: no A loads in the loop, 1: no window DMA, 2: no window reads, 3: no epilogue, 4: no wait +
 // barrier per stage, 5: timeline stamps into a.acc (as lin128_kernel)
 // ASM: loads and waits through vm_load16 / vm_dma16 / vm_wait (hand-counted vmcnt); false: compiler-scheduled builtins
-template <int KCB, int WGPC, int DBG = 0, bool ASM = true>
+template <int KCB, int WGPC, int DBG = 0, bool ASM = true, int MI = 2>
 __global__ void __launch_bounds__(256, WGPC) conv2s128_kernel(const ConvArgs a) {
-  constexpr int BN = 128, NT = 256, MI = 2, NI = 4, KS = 3;
+  constexpr int BN = 128, NT = 256, NI = 4, KS = 3;
   constexpr int CH = KCB / KC;          // 16-channel chunks per barrier
   constexpr int G = KC / 2 * KS / 4;    // float4 groups of four k-steps per chunk and 32-row subtile (6)
   constexpr int ND = KCB * 64 / NT;     // main-block DMA instructions per thread and stage
@@ -524,8 +528,11 @@ __global__ void __launch_bounds__(256, WGPC) conv2s128_kernel(const ConvArgs a) 
   }
   stage_dma(0, 0);
   if constexpr (ASM) {
-    vm_wait<0>(av[0][0], av[0][1]);
-    vm_wait<0>(av[1][0], av[1][1]);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      vm_wait<0>(av[0][mi]);
+      vm_wait<0>(av[1][mi]);
+    }
   } else {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   }
@@ -575,10 +582,15 @@ __global__ void __launch_bounds__(256, WGPC) conv2s128_kernel(const ConvArgs a) 
           if constexpr (ASM && !(DBG & 3)) {
             // group g's fragments: younger and possibly in flight are groups g + 1, g + 2 (4 loads) and, for the groups loaded before
             // this stage's DMA was issued (g <= 2), its D instructions: the window has three groups (96 MFMAs) to land
-            if (!LAST && g <= 2) vm_wait<4 + D>(av[g % 3][0], av[g % 3][1]);
-            else vm_wait<4>(av[g % 3][0], av[g % 3][1]);
+            if constexpr (MI == 2) {
+              if (!LAST && g <= 2) vm_wait<4 + D>(av[g % 3][0], av[g % 3][1]);
+              else vm_wait<4>(av[g % 3][0], av[g % 3][1]);
+            } else {
+              if (!LAST && g <= 2) vm_wait<2 + D>(av[g % 3][0]);
+              else vm_wait<2>(av[g % 3][0]);
+            }
           } else if constexpr (ASM) {
-            vm_wait<0>(av[g % 3][0], av[g % 3][1]);  // knock-outs change the counts: drain
+            vm_wait<0>(av[g % 3][0]);  // knock-outs change the counts: drain
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -654,9 +666,9 @@ bool conv2s128_supported(const ConvArgs& a) {
          (a.lengths_out || a.olen_default >= 0);
 }
 
-template <int KCB, int WGPC, int DBG = 0, bool ASM = true>
+template <int KCB, int WGPC, int DBG = 0, bool ASM = true, int MI = 2>
 static int launch_conv2s128_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) {
-  constexpr int BM = 256, BN = 128;
+  constexpr int BM = 128 * MI, BN = 128;
   a.mt_per_group = a.M / BM;
   dim3 grid((Lmax_out + BN - 1) / BN, a.mt_per_group, B);
   a.mfast = 0;
@@ -682,8 +694,8 @@ static int launch_conv2s128_t(ConvArgs a, int B, int Lmax_out, hipStream_t strea
   }
   const size_t lds = (size_t)2 * (KCB * 256 + KCB * 4) * sizeof(float);
   static DeviceOnce attr_once;
-  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&conv2s128_kernel<KCB, WGPC, DBG, ASM>), 160 * 1024));
-  hipLaunchKernelGGL((conv2s128_kernel<KCB, WGPC, DBG, ASM>), grid, dim3(256), lds, stream, a);
+  DISSC_HIP_CHECK(attr_once.max_lds(reinterpret_cast<const void*>(&conv2s128_kernel<KCB, WGPC, DBG, ASM, MI>), 160 * 1024));
+  hipLaunchKernelGGL((conv2s128_kernel<KCB, WGPC, DBG, ASM, MI>), grid, dim3(256), lds, stream, a);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
 }
@@ -694,6 +706,8 @@ int launch_conv2s128(const ConvArgs& a, int B, int Lmax_out, hipStream_t stream)
   // (2, the compiler-scheduled form with per-lane 64-bit addresses -- conv1 6 146 us where this one takes 5 715 -- is on record in
   //  the same file and no longer instantiated)
   if (opts().conv2s128 == 3) return launch_conv2s128_t<32, 2, 0, true>(a, B, Lmax_out, stream);
+  // (128 x 128 tiles on three workgroups per CU -- launch_conv2s128_t<16, 3, 0, true, 1>, the shape that won for the linears -- is a tie
+  //  here: conv1..4 10.82 ms against 10.78, profiles/r06/conv2s128_mi1.txt; not instantiated)
   return launch_conv2s128_t<16, 2, 0, true>(a, B, Lmax_out, stream);
 }
 
