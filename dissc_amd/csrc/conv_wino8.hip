@@ -138,24 +138,28 @@ struct Wino8Geo {
   static constexpr int RL_MIN = w8_rup(((XRW - 1 + OFF * D) / D + 1) > (MO * NTU + OFF + 10) ? ((XRW - 1 + OFF * D) / D + 1) : (MO * NTU + OFF + 10), 2);
   static constexpr int RL = w8_row_len(D, NTU, RL_MIN, MO);  // bumped so that the 8-byte transform reads of a half wave spread over the banks
   static constexpr int CHF = D * RL;
-  static constexpr int CPR = (NI == 4 || WPS == 4) ? 8 : 16;   // channels of the window per round (LDS budget)
+  // Latency form (NI = 1: the small-grid tiers -- one workgroup per CU at most, two waves per SIMD, so nothing hides a wave's
+  // chains): see the kernel's `if constexpr (LAT)` main loop.
+  static constexpr bool LAT = NI == 1;
+  static constexpr int CPR = LAT ? 16 : (NI == 4 || WPS == 4) ? 8 : 16;   // channels of the window per round (LDS budget)
   static constexpr int RPP = (NI == 4 || WPS == 4) ? 16 : 32;  // rows per epilogue pass (likewise)
   static constexpr int CG = NCW / 64 > 0 ? NCW / 64 : 1;  // 64-column groups a lane transforms
   static constexpr int XV = NTU * W <= 112 ? 112 : 240; // V row stride (% 32 == 16: the two k halves of a fragment read hit different banks)
   static constexpr int YS = NCW + 4;
   static constexpr int WIN_FLOATS = 2 * CPR * CHF;
-  static constexpr int V_FLOATS = 8 * 8 * XV;
+  static constexpr int V_FLOATS = 8 * 8 * XV * (LAT ? 2 : 1);  // (latency form: two V tiles per wave)
   static constexpr int Y_FLOATS = 8 * RPP * YS;
   static constexpr int OS = w8_rup(OT, 4) + 4;          // row stride of the epilogue's output tile (16-byte aligned rows)
   static constexpr int EPI_FLOATS = Y_FLOATS + RPP * OS;
   static constexpr int LDS_FLOATS = (WIN_FLOATS + V_FLOATS) > EPI_FLOATS ? (WIN_FLOATS + V_FLOATS) : EPI_FLOATS;
   static_assert(NTU >= 1 && NTU * W <= XV && RL % 2 == 0, "tile geometry");
-  static_assert(LDS_FLOATS * 4 <= (WPS == 4 ? 80 : 160) * 1024, "LDS");
+  static_assert(LDS_FLOATS * 4 <= ((WPS == 4 && !LAT) ? 80 : 160) * 1024, "LDS");
 };
 
 template <int NS, int DIL, int MI, int NI, int WPS = 2, int R = 3>
-__global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a) {
+__global__ void __launch_bounds__(512, (NI == 1 ? 2 : WPS)) conv_wino8_kernel(const Wino8Args a) {
   using G = Wino8Geo<NS, DIL, MI, NI, WPS, R>;
+  constexpr bool LAT = G::LAT;
   constexpr int NTH = G::NTH, D = G::D, W = G::W, NCOL = G::NCOL, OT = G::OT, NV = G::NV, RL = G::RL, MO = G::MO,
                 CHF = G::CHF, CPR = G::CPR, XV = G::XV, YS = G::YS, OFF = G::OFF, RPP = G::RPP, CG = G::CG;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -340,12 +344,126 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
     wp[mi] = reinterpret_cast<const f32x4*>(a.wpack) + ((size_t)p * nsub + mt * MI + mi) * nblk * 64 + lane;
   auto a_load = [&](int mi, int bl) __attribute__((always_inline)) { return wp[mi][(size_t)bl * 64]; };
 #endif
+  if constexpr (!LAT) {
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) av[mi] = a_load(mi, 0);
+    for (int mi = 0; mi < MI; ++mi) av[mi] = a_load(mi, 0);
+  }
   stage_load(0);
   stage_store(lds);
   if (nround > 1) stage_load(1);
   __syncthreads();
+
+  if constexpr (LAT) {
+    // ---- latency form.  On a small grid a CU holds ONE workgroup: two waves per SIMD, in step from barrier to barrier, so the
+    // loop below runs its phases back to back (B = 1, C = 256, k = 11, 136 workgroups: 66.7 us = 15 fixed + 29 transform + 24 MFMAs,
+    // tools/wino8_b1_ko.py on the round-5 form) and a 32 x 32 tile gives its one-block weight prefetch 4 MFMAs = 0.1 us to cover
+    // an L2 / MALL miss.  Here
+    //  * both half waves work on the tile's 32 columns: half h transforms channels 4h .. 4h + 3 of the sub-chunk (the other
+    //    form leaves lanes 32-63 repeating the last column): half the transform's instructions per wave -- 66.7 -> 47.6 us;
+    //  * the transform of sub-chunk s + 1 goes into the wave's OTHER V tile while sub-chunk s multiplies (no LDS round trip
+    //    between a sub-chunk's transform and its first MFMA);
+    //  * the weight fragments of a whole round are in flight: slot (sub-chunk, tap block), refilled for the next round right
+    //    after its MFMAs;
+    //  * the round's barrier moves before its last sub-chunk (whose companion transform reads the NEXT round's window).
+    // Same w8_bt arithmetic per value and the same MFMA sequence per accumulator: bit-identical to the other form.
+    // (Knock-outs `kernel_dbg` bits 0 / 1 do not apply here.)
+    constexpr int SCR = CPR / 8;
+    static_assert(SCR == 2, "latency form: two sub-chunks per round");
+    const int tcol = l31 < NCOL ? l31 : NCOL - 1;
+    const int toffl = (tcol % D) * RL + MO * (tcol / D) + OFF + 4 * h * CHF;
+    const int e0l = (tcol / D) * W + tcol % D + 4 * h * XV;
+    const bool ok1l = tcol % D + D < W;
+    const int e1l = ok1l ? e0l + D : e0l;
+    float* const vt[2] = {vbuf + p * (8 * XV), vbuf + 8 * 8 * XV + p * (8 * XV)};
+    float q[4][9];
+    auto tr_read = [&](const float* raw8) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const float* rw = raw8 + ii * CHF + toffl;
+        if constexpr (MO % 2 == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const f32x2a t = *reinterpret_cast<const f32x2a*>(rw + e);
+            q[ii][e] = t[0];
+            q[ii][e + 1] = t[1];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) q[ii][e] = rw[e];
+        }
+        q[ii][8] = NS > 1 ? rw[8] : 0.f;
+      }
+    };
+    auto tr_piece = [&](auto pc, float* vdst, int ii) __attribute__((always_inline)) {  // channel ii of this half wave's four
+      constexpr int P = decltype(pc)::value;
+      const float v0 = w8_bt<P>(q[ii][0], q[ii][1], q[ii][2], q[ii][3], q[ii][4], q[ii][5], q[ii][6], q[ii][7]);
+      vdst[ii * XV + e0l] = v0;
+      if constexpr (NS > 1) {
+        const float v1 = w8_bt<P>(q[ii][1], q[ii][2], q[ii][3], q[ii][4], q[ii][5], q[ii][6], q[ii][7], q[ii][8]);
+        vdst[ii * XV + e1l] = ok1l ? v1 : v0;
+      }
+    };
+    f32x4 aq[SCR][NS][MI];
+#pragma unroll
+    for (int sc = 0; sc < SCR; ++sc)
+#pragma unroll
+      for (int j = 0; j < NS; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) aq[sc][j][mi] = a_load(mi, sc * NS + j);
+    int blk = 0;
+    // One sub-chunk: the MFMAs of sub-chunk SC (V tile SC & 1) and the transform of the next one (from raw_next into the other
+    // V tile).  The order inside does not matter (measured, C = 256, k = 11, B = 1: 47.6 us as written; 46.8 with the SIMD's two
+    // waves -- points P and P + 4, tools/ubench/wave_simd.hip -- in opposite phase order; 49.4 with one channel's transform
+    // pinned between the chain's MFMAs; 48.8 with the MFMA operands read before the window): a SIMD issues the transform's
+    // VALU / LDS instructions and the MFMAs' passes from one budget, the two times add (knock-outs: 20 us of MFMAs = the
+    // tile's floor at two chains per SIMD, 17 us of transform, 11 us fixed).  What helped was fewer instructions per wave.
+    auto slot = [&](auto pc, auto scc, const float* raw_next) __attribute__((always_inline)) {
+      constexpr int SC = decltype(scc)::value;
+      tr_read(raw_next);
+      const float* bj = vt[SC & 1] + voff[0];
+#pragma unroll
+      for (int j = 0; j < NS; ++j, ++blk) {
+        float bk[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bk[s] = bj[s * 2 * XV + j * DIL];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[SC][j][mi][s], bk[s], acc[mi][0], 0, 0, 0);
+        const int bn = blk + SCR * NS < nblk ? blk + SCR * NS : nblk - 1;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) aq[SC][j][mi] = a_load(mi, bn);
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) tr_piece(pc, vt[(SC + 1) & 1], ii);
+    };
+    auto body = [&](auto pc) __attribute__((always_inline)) {
+      tr_read(lds);
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) tr_piece(pc, vt[0], ii);
+      for (int rd = 0; rd < nround; ++rd) {
+        const float* raw = lds + (rd & 1) * (CPR * CHF);
+        float* rawn = lds + ((rd + 1) & 1) * (CPR * CHF);
+        if (rd + 1 < nround) stage_store(rawn);
+        if (rd + 2 < nround) stage_load(rd + 2);
+        slot(pc, std::integral_constant<int, 0>{}, raw + 8 * CHF);
+        __syncthreads();  // every wave is done reading this round's window; the next one is complete
+        slot(pc, std::integral_constant<int, 1>{}, rawn);  // (after the last round: a transform nobody reads)
+      }
+    };
+    switch (p) {  // uniform per wave
+      case 0: body(std::integral_constant<int, 0>{}); break;
+      case 1: body(std::integral_constant<int, 1>{}); break;
+      case 2: body(std::integral_constant<int, 2>{}); break;
+      case 3: body(std::integral_constant<int, 3>{}); break;
+      case 4: body(std::integral_constant<int, 4>{}); break;
+      case 5: body(std::integral_constant<int, 5>{}); break;
+      case 6: body(std::integral_constant<int, 6>{}); break;
+      default: body(std::integral_constant<int, 7>{}); break;
+    }
+    __syncthreads();
+  }
 
   int blk = 0;
   auto run_taps = [&]() __attribute__((always_inline)) {
@@ -382,7 +500,7 @@ __global__ void __launch_bounds__(512, WPS) conv_wino8_kernel(const Wino8Args a)
 
   // One barrier per round: at the top of round rd the window of round rd + 1 goes into the other buffer (every wave finished
   // reading it before the barrier that closed round rd - 1) and the loads of round rd + 2 are issued
-  for (int rd = 0; rd < nround; ++rd) {
+  for (int rd = 0; rd < (LAT ? 0 : nround); ++rd) {
     const float* raw = lds + (rd & 1) * (CPR * CHF);
     if (rd + 1 < nround) stage_store(lds + ((rd + 1) & 1) * (CPR * CHF));
     if (rd + 2 < nround) stage_load(rd + 2);
@@ -647,6 +765,10 @@ static int launch_wino8_t(const Wino8Args& a, int B, int Lmax, hipStream_t strea
   }
   const int per = 8 / aa.gy;
   dim3 grid(8 * ((aa.gx * B + per - 1) / per));
+  if (a.C % G::CPR != 0) {
+    set_error("launch_wino8: %d channels are not a multiple of the %d a round stages", a.C, G::CPR);
+    return DISSC_EINVAL;
+  }
   hipLaunchKernelGGL((conv_wino8_kernel<NS, DIL, MI, NI, WPS, R>), grid, dim3(512), (size_t)G::LDS_FLOATS * sizeof(float), stream, aa);
   DISSC_HIP_CHECK(hipGetLastError());
   return DISSC_OK;
