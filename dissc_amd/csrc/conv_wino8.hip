@@ -142,9 +142,9 @@ struct Wino8Geo {
   // chains): see the kernel's `if constexpr (LAT)` main loop.
   static constexpr bool LAT = NI == 1;
   static constexpr int CPR = LAT ? 16 : (NI == 4 || WPS == 4) ? 8 : 16;   // channels of the window per round (LDS budget)
-  static constexpr int RPP = (NI == 4 || WPS == 4) ? 16 : 32;  // rows per epilogue pass (likewise)
+  static constexpr int RPP = (!LAT && (NI == 4 || WPS == 4)) ? 16 : 32;  // rows per epilogue pass (likewise)
   static constexpr int CG = NCW / 64 > 0 ? NCW / 64 : 1;  // 64-column groups a lane transforms
-  static constexpr int XV = NTU * W <= 112 ? 112 : 240; // V row stride (% 32 == 16: the two k halves of a fragment read hit different banks)
+  static constexpr int XV = (LAT && NTU * W <= 80) ? 80 : NTU * W <= 112 ? 112 : 240; // V row stride (% 32 == 16: the two k halves of a fragment read hit different banks)
   static constexpr int YS = NCW + 4;
   static constexpr int WIN_FLOATS = 2 * CPR * CHF;
   static constexpr int V_FLOATS = 8 * 8 * XV * (LAT ? 2 : 1);  // (latency form: two V tiles per wave)
@@ -821,7 +821,7 @@ int run_wino8(const DevConv& dc, const float* x, float* out, const float* res, f
                               ? launch_wino8_t<NS_, D_, 2, 2, 4, R_>(a, B, Lmax, stream)             \
                               : launch_wino8_t<NS_, D_, 4, 2, 2, R_>(a, B, Lmax, stream))            \
                        : (opts().small_grid && DISSC_W8_NWG64(R_, NS_, D_) < 192)                     \
-                          ? launch_wino8_t<NS_, D_, 1, 1, 4, R_>(a, B, Lmax, stream)                 \
+                          ? launch_wino8_t<NS_, D_, 2, 1, 4, R_>(a, B, Lmax, stream)                 \
                        : (c64_mode == 1 ? launch_wino8_t<NS_, D_, 2, 4, 2, R_>(a, B, Lmax, stream)  \
                           : c64_mode == 2 ? launch_wino8_t<NS_, D_, 2, 2, 4, R_>(a, B, Lmax, stream) \
                                           : launch_wino8_t<NS_, D_, 2, 2, 2, R_>(a, B, Lmax, stream));
