@@ -414,10 +414,14 @@ int run_s2tc(const DevS2tc& dc, const float* x, float* out, const int32_t* lengt
              int len_default, int olen_default, int B, int ldx, int ldo, int Lmax_out, hipStream_t stream);
 
 // misc kernels (gen_misc.hip)
+struct ZeroSpans {  // ZERO_TAIL floats at each pointer, zeroed by the forward's first kernel
+  float* p[DISSC_MAX_RK];
+  int n;
+};
 void launch_embed_concat(const int64_t* code, const float* f0, const int64_t* spkr,
                          const float* dict_w, const float* spkr_w, const int32_t* lengths, int B,
                          int T, int E, int has_f0, int has_spkr, int n_codes, int n_spk, float* x,
-                         int ldx, hipStream_t stream);
+                         int ldx, const ZeroSpans& zs, hipStream_t stream);
 void launch_conv_post(const float* x, const float* w, const float* bias, const int32_t* lengths,
                       int len_mul, int B, int C, int KS, int L, int ldx, long long x_bstride,
                       float slope, float* wav, int ldw, hipStream_t stream);

@@ -572,12 +572,15 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
   float* ACC = base + nbuf;
   float* TMPj[DISSC_MAX_RK];
   float* XKj[DISSC_MAX_RK];
+  ZeroSpans zs;
   for (int j = 0; j < g->cfg.num_kernels; ++j) {
     TMPj[j] = base + (size_t)(2 + 2 * j) * nbuf + BUF_GUARD;
     XKj[j] = base + (size_t)(3 + 2 * j) * nbuf;
-    // the floats right in front of a scratch buffer are the left halo of its first row when a conv stages it by LDS-DMA
-    DISSC_HIP_CHECK(hipMemsetAsync(TMPj[j] - ZERO_TAIL, 0, ZERO_TAIL * sizeof(float), stream));
+    // the floats right in front of a scratch buffer are the left halo of its first row when a conv stages it by LDS-DMA:
+    // zeroed by the forward's first kernel (embed_concat, on `stream` before the chains fork)
+    zs.p[j] = TMPj[j] - ZERO_TAIL;
   }
+  zs.n = g->cfg.num_kernels;
   float* TMP = TMPj[0];
   const bool multi = g->ev_x != nullptr;
   const DisscGenConfig& c = g->cfg;
@@ -586,7 +589,7 @@ static int gen_forward_body(dissc_gen_t g, const int64_t* code, const float* f0,
   // 1. conditioning -> TMP [B, in_dim, ld0]
   const int ld0 = (int)round_up(Tmax, 4);
   launch_embed_concat(code, f0, spkr, g->dict_w, g->spkr_w, lengths, B, Tmax, c.embedding_dim,
-                      c.has_f0, c.has_spkr, c.num_embeddings, c.num_speakers, TMP, ld0, stream);
+                      c.has_f0, c.has_spkr, c.num_embeddings, c.num_speakers, TMP, ld0, zs, stream);
   // 2. conv_pre -> ACC [B, c0, ld0]
   if ((rc = run_conv(g->conv_pre, TMP, ACC, nullptr, nullptr, lengths, Tmax, 1, B, c.model_in_dim,
                      ld0, ld0, Tmax, 1.0f, EPI_STORE, 1.f, stream)))
