@@ -36,7 +36,7 @@ void set_error(const char* fmt, ...);
   X(ragged_enum, 1, "ragged_enum") \
   X(lin128, 1, "lin128") \
   X(conv2s128, 1, "conv2s128") \
-  X(xcd_order, 3, "xcd_order") \
+  X(xcd_order, 11, "xcd_order") \
   X(xcd_mg, 0, "xcd_mg") \
   X(small_grid, 1, "small_grid") \
   X(kernel_dbg, 0, "kernel_dbg") \

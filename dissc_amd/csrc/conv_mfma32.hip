@@ -329,7 +329,8 @@ static const TileCfg32 kCfgs32[] = {
 // option "conv_pad_lds" (Options::conv_pad_lds, default 0): "conv_pad_lds" option (diagnostics): extra LDS bytes per workgroup
 // option "c64_wide" (Options::c64_wide, default 1): "c64_wide" option: 64 x 256 tile (64 x 64 wave tiles) for the DMA-staged second convs of the C = 64 stage
 // option "conv2_dma" (Options::conv2_dma, default 1): "conv2_dma" option: stride-2 valid convs stage their window with global_load_lds
-// option "xcd_order" (Options::xcd_order, default 3): XCD-aware workgroup order (bit 0: 1x1 convs, 1: stride-2 convs, 2: the rest).
+// option "xcd_order" (Options::xcd_order, default 11): XCD-aware workgroup order (bit 0: 1x1 convs, 1: stride-2 convs, 2: the rest,
+//   3: the fused attention, hubert.hip).
 //   Encoder, 32 x 10 s (profiles/r05/xcd_order.md): fabric traffic (PMC) 39.60 -> 31.25 GB per forward (conv1 7.98 -> 5.41,
 //   fc1 1.217 -> 0.746, qkv 0.752 -> 0.569), time unchanged (27.66 vs 27.66 ms); the generator's few instances: no change
 //   in either (bit 2 stays off).

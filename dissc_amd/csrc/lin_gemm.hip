@@ -374,10 +374,22 @@ static int launch_lin128_t(ConvArgs a, int B, int Lmax_out, hipStream_t stream) 
   const long long tt_pad = ((long long)grid.x * B + 7) / 8 * 8;
   a.xcd = ((opts().xcd_order & 1) && mt >= 2) ? 1 : 0;
   if (a.xcd) {
+    // M tiles per sweep: the divisor of the M tile count with the least modelled fabric traffic (whole sweeps only: a short last sweep
+    // adds a partly filled round of workgroups).  Per sweep every XCD reads its windows once (sweeps x the activation bytes in all) and
+    // the sweep's weight slabs once -- if they stay L2-resident next to the streamed windows (<= 3.2 MB of the 4) -- or once per round
+    // of co-resident workgroups if they do not.  Measured (profiles/r06/lin_xcd_mg.txt, 32 x 499 frames): fc2 (K = 3072: 1.5 MB slabs
+    // AND 1.5 MB windows) 0.776 GB per launch in sweeps of 2 -> 0.523 in one sweep of 6, which this rule now picks; qkv (6 of 18) and
+    // fc1 (8 of 24) stay where the "slabs that fit" rule had them; times do not move (the linears are matrix-pipe bound).
     const double slab = (double)BM * a.CIN * sizeof(float);
-    int mg = (int)(3.2 * 1024 * 1024 / slab);
-    if (mg < 2 || mg > mt) mg = mt;
-    while (mt % mg) --mg;
+    const double xbytes = (double)tt_pad * BN * a.CIN * sizeof(float), wbytes = slab * mt;
+    int mg = mt;
+    double best = 0.0;
+    for (int c = 1; c <= mt; ++c) {
+      if (mt % c) continue;
+      const double rounds = c * slab <= 3.2 * 1024 * 1024 ? 1.0 : (double)((tt_pad / 8 * c + WGPC * 32 - 1) / (WGPC * 32));
+      const double cost = (double)(mt / c) * xbytes + 8.0 * wbytes * rounds;
+      if (c == 1 || cost <= best) best = cost, mg = c;
+    }
     if (opts().xcd_mg > 0) mg = opts().xcd_mg < mt ? opts().xcd_mg : mt;
     if (tt_pad * mg * ((mt + mg - 1) / mg) > 0x7fffffffLL) {
       a.xcd = 0;  // beyond a 1-D grid: keep the 3-D one

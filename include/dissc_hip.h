@@ -199,11 +199,13 @@ int dissc_conv_s2_bench(int B, int C, int L, int form, int iters, float* ms_out)
  *                        fill the partly filled last workgroup rounds of each other's launches (0 never, 1 unless the
  *                        whole batch fills whole rounds by itself, N >= 2 always N parts); the units do not depend on it
  *   mfast (0)            M-fastest block order for convs with many M tiles
- *   xcd_order (3)        XCD-aware workgroup order of the 32x32x2 implicit-GEMM launches with >= 2 M tiles (bit 0: 1x1 convs =
+ *   xcd_order (11)       XCD-aware workgroup order of the 32x32x2 implicit-GEMM launches with >= 2 M tiles (bit 0: 1x1 convs =
  *                        HuBERT's linears, bit 1: stride-2 convs = its feature extractor, bit 2: every other instance): a 1-D
  *                        grid whose ids are dealt in sweeps over groups of M tiles (weight slabs that fit one XCD's L2 together),
  *                        the M tiles of one input window on consecutive slots of one XCD.  Same tiles, same arithmetic, bit-
- *                        identical results; 21 % less fabric traffic on the encoder.  xcd_mg (0 = automatic): M tiles per sweep
+ *                        identical results; 21 % less fabric traffic on the encoder.  xcd_mg (0 = automatic): M tiles per sweep.
+ *                        Bit 3: the fused attention's workgroups in XCD order (the query tiles of one (utterance, head) on one
+ *                        XCD: its K / V rows cross the fabric once)
  * Unknown keys return DISSC_EINVAL. */
 int dissc_set_option(const char* key, int value);
 /* Read back any option's DEFAULT (so that a wrapper can set an option around the creation of one handle and restore it), plus

@@ -144,11 +144,12 @@ def test_split_batch_forward_is_bit_identical(env):
 
 
 def test_xcd_workgroup_order_is_bit_identical(env):
-    """option "xcd_order" (default 3): the implicit-GEMM launches of the encoder deal their workgroups in XCD order -- sweeps over
+    """option "xcd_order" (default 11): the implicit-GEMM launches of the encoder deal their workgroups in XCD order -- sweeps over
     groups of M tiles whose weight slabs share an L2, the M tiles of one input window on one XCD (conv_mfma32.hip) -- which
     changes WHO computes a tile and WHEN, never what: units and dense features equal those of the plain 3-D grid bit for bit,
     on a ragged batch with NaN padding (tiles that do not exist are skipped by both enumerations), for the automatic sweep
-    size and for forced ones that leave a short last sweep."""
+    size and for forced ones that leave a short last sweep.  Bit 3: the fused attention's 1-D grid that keeps the query tiles of one
+    (utterance, head) on one XCD (15 utterances x 12 heads = 180 pairs: not a multiple of 8, the padded tail is exercised)."""
     from dissc_amd import _lib
     from dissc_amd.hubert import HubertEncoder
     synth = env["synth"]
@@ -159,14 +160,14 @@ def test_xcd_workgroup_order_is_bit_identical(env):
         wav[i, :n] = torch.from_numpy(synth.synth_waveform(n, seed=700 + i))
     outs = []
     try:
-        for order, mg in ((0, 0), (3, 0), (3, 2), (1, 5), (2, 1)):  # (options are frozen per handle: one encoder per setting)
+        for order, mg in ((0, 0), (3, 0), (11, 0), (8, 0), (3, 2), (1, 5), (2, 1)):  # (options are frozen per handle: one encoder per setting)
             assert _lib.lib.dissc_set_option(b"xcd_order", order) == 0 and _lib.lib.dissc_set_option(b"xcd_mg", mg) == 0
             enc = HubertEncoder(env["sd"], env["centers"], n_layers=6).to("cuda:0")
             o = enc(wav, n_samples=torch.tensor(ns))
             outs.append((o["units"].cpu(), o["dense"].cpu(), o["frames"].cpu()))
             del enc
     finally:
-        _lib.lib.dissc_set_option(b"xcd_order", 3)
+        _lib.lib.dissc_set_option(b"xcd_order", 11)
         _lib.lib.dissc_set_option(b"xcd_mg", 0)
     for u, d, f in outs[1:]:
         assert torch.equal(f, outs[0][2])
