@@ -338,193 +338,8 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S
   for (int j = lane; j < T; j += 64) p[j] = __fdiv_rn(p[j], sum);
 }
 
-// ---- fused exact attention for one (utterance, head, 64-query tile) ---------------------------
-// qkv is channels-first [B][3D][ld] (rows: Q | K | V, head h owns rows h*64..h*64+63 of each,
-// Q already scaled by 1/sqrt(64)).  Per wave: 16 queries.  S^T[key][query] = K^T Q is formed on
-// the matrix pipe with rows = keys, so a lane's 4 accumulator registers are 4 keys of ONE
-// query: the online-softmax reductions are in-lane plus two cross-group shuffles, and the
-// probabilities are already in MFMA B-operand position for O[d][query] += V[d][key] P^T[key][query]
-// (k-step s of the PV product uses key 4*g + s, i.e. register s of the same lane) -- no LDS
-// round trip for P, no HBM round trip for S.
-constexpr int AT_NQ = 2;    // groups of 16 queries per wave
-constexpr int AT_Q = 64 * AT_NQ;  // queries per block (4 waves x AT_NQ x 16)
-constexpr int AT_LDQQ = AT_Q + 16;  // row stride of the Q tile (% 32 == 16: conflict-free fragment reads)
-constexpr int AT_K = 64;    // keys per LDS tile
-constexpr int AT_LDQ = 80;  // row stride of the Q / K tiles (80 % 32 == 16: conflict-free fragment reads)
-constexpr int AT_LDV = 65;  // row stride of the V tile (odd: lanes walk rows)
-
-__global__ void __launch_bounds__(256) attn_fused_kernel(const float* __restrict__ qkv,
-                                                         const int32_t* __restrict__ lens, int D,
-                                                         int hd, int ld, float* __restrict__ out, int nqt, int H, int B) {
-  __shared__ float Qs[64 * AT_LDQQ];
-  __shared__ float Ks[64 * AT_LDQ];
-  __shared__ float Vs[64 * AT_LDV];
-  // Grid: nqt >= 0: the 3-D grid (query tile, head, utterance).  nqt < 0 (option "xcd_order" bit 3): a 1-D grid in XCD order -- workgroup
-  // ids go round-robin over the 8 XCDs, so id -> (XCD = id & 7, slot = id >> 3); the -nqt query tiles of one (utterance, head) take
-  // consecutive slots of ONE XCD and share its L2 for that head's K / V rows (the 3-D grid sent them to -nqt different XCDs: K and V
-  // crossed the fabric once per query tile, 0.54 GB per launch against 0.20 algorithmic at 32 x 499 frames).
-  int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
-  if (nqt < 0) {
-    const int n = -nqt, slot = blockIdx.x >> 3;
-    const int p = (slot / n) * 8 + (blockIdx.x & 7);
-    if (p >= H * B) return;
-    qt = slot % n;
-    b = p / H;
-    h = p - b * H;
-  }
-  const int T = lens[b];
-  const int q0 = qt * AT_Q;
-  if (q0 >= T) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, g = lane >> 4;
-  const float* qb = qkv + ((size_t)b * 3 * D + (size_t)h * hd) * ld;
-  const float* kb = qb + (size_t)D * ld;
-  const float* vb = qb + (size_t)2 * D * ld;
-  // Q tile -> LDS (zero beyond T)
-  for (int e = tid; e < 64 * (AT_Q / 4); e += 256) {
-    const int d = e / (AT_Q / 4), c = (e - d * (AT_Q / 4)) * 4;
-    int col = q0 + c;
-    col = col > ld - 4 ? ld - 4 : col;
-    f32x4 v = *reinterpret_cast<const f32x4*>(qb + (size_t)d * ld + col);
-#pragma unroll
-    for (int e2 = 0; e2 < 4; ++e2) v[e2] = (q0 + c + e2 < T) ? v[e2] : 0.f;
-    *reinterpret_cast<f32x4*>(Qs + d * AT_LDQQ + c) = v;
-  }
-  __syncthreads();
-  // this wave's AT_NQ groups of 16 queries: k-step ks -> Q[d = 4*ks + g][query = (wave*AT_NQ + j)*16 + l15].
-  // The groups share every K / V fragment read and give the matrix pipe independent accumulator chains.
-  float qf[AT_NQ][16];
-#pragma unroll
-  for (int j = 0; j < AT_NQ; ++j)
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) qf[j][ks] = Qs[(4 * ks + g) * AT_LDQQ + (wave * AT_NQ + j) * 16 + l15];
-  f32x4 o[AT_NQ][4];
-  float m[AT_NQ], l[AT_NQ];
-#pragma unroll
-  for (int j = 0; j < AT_NQ; ++j) {
-    m[j] = -INFINITY;
-    l[j] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // K / V tiles of 64 keys: the NEXT tile is fetched into registers (16 B per lane, clamped in-bounds
-  // loads) while the current one is on the matrix pipe, and written to LDS between the two barriers.
-  f32x4 kr[4], vr[4];
-  auto tile_load = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256;
-      const int d = e >> 4, c = (e & 15) * 4;
-      int col = k0 + c;
-      col = col > ld - 4 ? ld - 4 : col;  // beyond the row: every key of this slot is >= T and masked below
-      kr[i] = *reinterpret_cast<const f32x4*>(kb + (size_t)d * ld + col);
-      vr[i] = *reinterpret_cast<const f32x4*>(vb + (size_t)d * ld + col);
-    }
-  };
-  auto tile_store = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256;
-      const int d = e >> 4, c = (e & 15) * 4;
-      f32x4 kv = kr[i], vv = vr[i];
-#pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {
-        const bool ok = k0 + c + e2 < T;  // V must be 0 beyond T: p = 0 there, and 0 * garbage may be NaN
-        kv[e2] = ok ? kv[e2] : 0.f;
-        vv[e2] = ok ? vv[e2] : 0.f;
-      }
-      *reinterpret_cast<f32x4*>(Ks + d * AT_LDQ + c) = kv;
-#pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) Vs[d * AT_LDV + c + e2] = vv[e2];
-    }
-  };
-  tile_load(0);
-  for (int k0 = 0; k0 < T; k0 += AT_K) {
-    __syncthreads();  // previous tile fully consumed
-    tile_store(k0);
-    __syncthreads();
-    if (k0 + AT_K < T) tile_load(k0 + AT_K);
-    __builtin_amdgcn_sched_barrier(0);
-    // S^T for all 64 keys of the tile: sT[j][sub][r] = S[query l15 of group j][key k0 + sub*16 + 4g + r]
-    f32x4 sT[AT_NQ][4];
-#pragma unroll
-    for (int j = 0; j < AT_NQ; ++j)
-#pragma unroll
-      for (int sub = 0; sub < 4; ++sub) sT[j][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const float kf = Ks[(4 * ks + g) * AT_LDQ + sub * 16 + l15];
-#pragma unroll
-        for (int j = 0; j < AT_NQ; ++j)
-          sT[j][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, qf[j][ks], sT[j][sub], 0, 0, 0);
-      }
-    if (k0 + AT_K > T) {  // uniform: only the last tile has keys beyond T
-#pragma unroll
-      for (int j = 0; j < AT_NQ; ++j)
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (k0 + sub * 16 + 4 * g + r >= T) sT[j][sub][r] = -INFINITY;
-    }
-    // one online-softmax step per 64 keys (exp through v_exp_f32: e^x = 2^(x log2 e))
-#pragma unroll
-    for (int j = 0; j < AT_NQ; ++j) {
-      float mx = -INFINITY;
-#pragma unroll
-      for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sT[j][sub][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float mn = fmaxf(m[j], mx);  // finite: the tile has at least one valid key
-      const float alpha = __expf(m[j] - mn);
-      float ps = 0.f;
-#pragma unroll
-      for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sT[j][sub][r] = __expf(sT[j][sub][r] - mn);
-          ps += sT[j][sub][r];
-        }
-      ps += __shfl_xor(ps, 16);
-      ps += __shfl_xor(ps, 32);
-      l[j] = l[j] * alpha + ps;
-      m[j] = mn;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        o[j][i][0] *= alpha; o[j][i][1] *= alpha; o[j][i][2] *= alpha; o[j][i][3] *= alpha;
-      }
-    }
-    // O += V P^T: k-step st of sub-tile sub uses key sub*16 + 4g + st = register st of the same lane
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          const float vf = Vs[(i * 16 + l15) * AT_LDV + sub * 16 + 4 * g + st];
-#pragma unroll
-          for (int j = 0; j < AT_NQ; ++j)
-            o[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, sT[j][sub][st], o[j][i], 0, 0, 0);
-        }
-  }
-  // o[j][i][r] = O[d = i*16 + 4g + r][query = (wave*AT_NQ + j)*16 + l15] (unnormalised)
-#pragma unroll
-  for (int j = 0; j < AT_NQ; ++j) {
-    const int q = q0 + (wave * AT_NQ + j) * 16 + l15;
-    if (q < T) {
-      const float inv = 1.f / l[j];
-      float* ob = out + ((size_t)b * D + (size_t)h * hd) * ld + q;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ob[(size_t)(i * 16 + 4 * g + r) * ld] = o[j][i][r] * inv;
-    }
-  }
-}
+// ---- fused exact attention: attn.hip (a translation unit of its own: it is compiled with -amdgpu-mfma-vgpr-form) ----------------
+int launch_attn_fused(const float* qkv, const int32_t* lens, int D, int hd, int ld, float* out, int T, int H, int B, hipStream_t st);
 
 // ---- k-means assignment (the quantiser's predict(): reference data/encode.py:21-22 via textless KMeansQuantizer -> sklearn) -----
 // units[t] = the FIRST k minimising  s_k = cnorm[k] - 2 <x_t, c_k>   (sklearn's dense predict: ||c||^2 - 2 x.c, first minimum).
@@ -1086,12 +901,7 @@ static int hubert_forward_part(dissc_hubert_t m, const float* wav, const int32_t
     auto& L = m->layers[i];
     if ((rc = run_conv_ex(L.qkv, w.x, w.qkv, nullptr, ioT, B, D, ldT, ldT, T, 1.0f, EPI_STORE, st))) return rc;
     if (opts().attn_fused && hd == 64) {
-      const int nqt = (T + AT_Q - 1) / AT_Q;
-      if (opts().xcd_order & 8)
-        hipLaunchKernelGGL(attn_fused_kernel, dim3((unsigned)((H * B + 7) / 8 * 8 * nqt)), dim3(256), 0, st, w.qkv, lensT, D, hd, ldT,
-                           w.t1, -nqt, H, B);
-      else
-        hipLaunchKernelGGL(attn_fused_kernel, dim3(nqt, H, B), dim3(256), 0, st, w.qkv, lensT, D, hd, ldT, w.t1, nqt, H, B);
+      if ((rc = launch_attn_fused(w.qkv, lensT, D, hd, ldT, w.t1, T, H, B, st))) return rc;
     } else {
     BGemmArgs a;
       // S[b,h][i][j] = sum_d Q[d][i] K[d][j]      (Q already scaled by 1/sqrt(hd))
