@@ -87,6 +87,27 @@ def test_hubert_10s_against_oracle(env):
                  out["dense"][0].cpu().numpy())
 
 
+def test_attention_tile_boundaries_against_oracle(env):
+    """Frame counts on and around the fused attention's tile edges (csrc/attn.hip: 64-key LDS tiles, 128-query workgroups; the key
+    masks exist only in a tile that crosses T): T = 63 / 64 / 65 (one key tile, full, one key more), 127 / 128 / 129 (the query
+    tile's edge), 193 -- one ragged batch with NaN padding, every utterance against the oracle."""
+    hr, synth = env["hr"], env["synth"]
+    Ts = [63, 64, 65, 127, 128, 129, 193]
+    ns = [400 + 320 * (T - 1) for T in Ts]
+    wav = torch.full((len(ns), max(ns) + 7), float("nan"))
+    for i, n in enumerate(ns):
+        wav[i, :n] = torch.from_numpy(synth.synth_waveform(n, seed=900 + i))
+    out = env["enc"](wav, n_samples=torch.tensor(ns))
+    for i, (T, n) in enumerate(zip(Ts, ns)):
+        assert int(out["frames"][i]) == T == hr.num_frames(n)
+        u_ref, d_ref = hr.encode(env["sd"], env["centers"], wav[i:i + 1, :n])
+        d = out["dense"][i, :T].cpu()
+        assert torch.isfinite(d).all()
+        err = float((d - d_ref).abs().max())
+        assert err <= FEAT_MAX_REL * max(1.0, float(d_ref.abs().max())), (T, err)
+        _check_units(hr, out["units"][i, :T].cpu().numpy(), d_ref.numpy(), env["centers"], u_ref.numpy(), f"T={T}", d.numpy())
+
+
 def test_hubert_batch32_ragged_2_to_10s_against_oracle(env):
     """The encode shape the pipeline runs (B=32, ragged 2-10 s, NaN in the padding): the oracle on 4
     utterances (longest, shortest, two in between), B=1 equality of the units on all 32."""
