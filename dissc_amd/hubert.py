@@ -135,7 +135,7 @@ class HubertEncoder:
     MAX_CHUNK = 1600000
 
     def forward(self, wav, n_samples=None, want_dense=True):
-        """wav f32 [B,N] -> dict(units i64 [B,T], dense f32 [B,T,768], frames i32 [B])"""
+        """wav f32 [B,N] -> dict(units i64 [B,T], dense f32 [B,T,768], frames i32 [B] on the host, frames_dev: the same on the device)"""
         self._ensure()
         dev = self.device
         wav = torch.as_tensor(wav).to(dev, torch.float32)
@@ -157,6 +157,15 @@ class HubertEncoder:
             if ns.device.type == "cpu" and (int(ns.min()) < 0 or int(ns.max()) > N):
                 raise ValueError(f"n_samples must lie in [0, {N}] (row length of wav)")
             ns = ns.to(dev, torch.int32).contiguous()
+        # frames per utterance (host arithmetic), uploaded BEFORE the forward's kernels are queued: an H2D copy from pageable memory
+        # blocks the host until everything queued before it has run -- behind the encoder's launches it would block for the whole
+        # encode and keep the caller from queueing its next stage (the Converter's predictors) under it
+        if n_samples is None:
+            frames = torch.full((B,), T, dtype=torch.int32)
+        else:
+            frames = torch.tensor([max(lib.dissc_hubert_frames(int(n)), 0) for n in torch.as_tensor(n_samples).tolist()],
+                                  dtype=torch.int32)
+        frames_dev = frames.to(dev)
         with torch.cuda.device(dev):
             need = lib.dissc_hubert_workspace_bytes(self._handle, B, N)
             if self._ws is None or self._ws.numel() < need:
@@ -168,12 +177,7 @@ class HubertEncoder:
                                            B, N, dense.data_ptr() if dense is not None else None,
                                            units.data_ptr() if units is not None else None, self._ws.data_ptr(),
                                            need, _lib.current_stream_ptr(dev)), "dissc_hubert_forward")
-        if n_samples is None:
-            frames = torch.full((B,), T, dtype=torch.int32)
-        else:
-            frames = torch.tensor([max(lib.dissc_hubert_frames(int(n)), 0) for n in torch.as_tensor(n_samples).tolist()],
-                                  dtype=torch.int32)
-        out = {"frames": frames}
+        out = {"frames": frames, "frames_dev": frames_dev}
         if units is not None:
             out["units"] = units
         if dense is not None:
@@ -196,7 +200,7 @@ class HubertEncoder:
             parts.append(self.forward(piece.contiguous(), n_samples=n_c.to(torch.int32), want_dense=want_dense))
         frames = torch.stack([p["frames"] for p in parts]).sum(0).to(torch.int32)
         T = int(frames.max())
-        out = {"frames": frames}
+        out = {"frames": frames, "frames_dev": torch.stack([p["frames_dev"] for p in parts]).sum(0).to(torch.int32)}
         for key, shape, dt in (("units", (B, T), torch.int64), ("dense", (B, T, 768), torch.float32)):
             if key not in parts[0]:
                 continue

@@ -130,7 +130,8 @@ class Converter:
             self._mark(marks, "stage_ms")
             enc = self.encoder(wav_dev, n_samples=torch.from_numpy(ns), want_dense=False)
             units = enc["units"]                       # i64 [b,T] on the device
-            frames = enc["frames"].to(dev)             # i32 [b] (computed from n_samples on the host)
+            frames = enc["frames_dev"] if "frames_dev" in enc else enc["frames"].to(dev)  # i32 [b] (host arithmetic on n_samples, uploaded before the encoder's launches:
+                                                       # an H2D copy queued BEHIND them would block the host for the whole encode)
             self._mark(marks, "encode_ms")
             # every utterance x every target, target fastest: row = k*nt + slot
             r = P.infer_batch(units.repeat_interleave(nt, 0), frames.repeat_interleave(nt),
