@@ -74,3 +74,14 @@ def test_collective_entries_refuse_bad_arguments_without_a_gpu(built):
     assert L.dissc_comm_destroy(None) == 0
     with pytest.raises(ValueError):
         coll.WaveComm(b"short", 1, 0, device="cuda:0")
+
+
+def test_per_source_compiler_flags_name_existing_sources():
+    """__graft_entry__.EXTRA_FLAGS keys are file names of dissc_amd/csrc: a renamed source must not silently lose its flag
+    (attn.hip is only as fast as measured with -amdgpu-mfma-vgpr-form: without it the compiler moves the accumulators through AGPRs)."""
+    import __graft_entry__ as ge
+    csrc = os.path.join(ROOT, "dissc_amd", "csrc")
+    assert "attn.hip" in ge.EXTRA_FLAGS and "-amdgpu-mfma-vgpr-form" in ge.EXTRA_FLAGS["attn.hip"]
+    for name, flags in ge.EXTRA_FLAGS.items():
+        assert os.path.exists(os.path.join(csrc, name)), name
+        assert isinstance(flags, list) and all(isinstance(f, str) for f in flags)
